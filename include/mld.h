@@ -1,0 +1,226 @@
+/*
+ * mld.h — C-ABI of the MI355X-native DepthEstimator hot path.
+ *
+ * This is the drop-in boundary for monolidar_fusion's `Mono_Lidar::DepthEstimator`
+ * (reference: monolidar_fusion/include/monolidar_fusion/DepthEstimator.h:39-359).
+ * The reference has no FFI; its boundary is a C++ class.  Every entry point below names
+ * the reference member it replaces.  The C++ shim class that keeps the reference's
+ * method names on top of this ABI lives in
+ * mono_lidar_depth_amd/host/monolidar_fusion/DepthEstimator.h; INTEGRATION.md shows how
+ * a maintainer links it into tracklets_depth.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller-owned buffers; no callee resize.
+ *   - return value: MLD_OK (0) or a negative mld_status; mld_last_error() gives the text
+ *     (the reference throws `const char*` / std::string / std::runtime_error instead:
+ *     DepthEstimator.cpp:38,57,94,227,270,439,608,797).
+ *   - per-feature failures are never errors: (resultType, depth = -1), as in the reference
+ *     (eDepthResultType.h:8-30).
+ *   - one context per (GPU, stream).  A context owns `max_frames` independent frame slots so
+ *     that many frames can be processed by ONE kernel launch set (frames of a sequence, or a
+ *     micro-batch of sequences).  slot 0 alone gives the reference's one-frame-at-a-time use.
+ *   - `*_device` entry points take device pointers (zero-copy: the cloud is read in place),
+ *     are asynchronous on the context's stream, and never touch the host buffers.
+ */
+#ifndef MLD_H_
+#define MLD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLD_ABI_VERSION 1
+
+typedef enum mld_status {
+    MLD_OK = 0,
+    MLD_ERR_INVALID_ARG = -1,        /* null pointer, bad slot, bad stride ...                         */
+    MLD_ERR_NOT_INITIALIZED = -2,    /* "call of 'CalculateDepth' without 'SetInputCloud'" (:439)      */
+    MLD_ERR_UNSUPPORTED_MODE = -3,   /* neighbor_search_mode != 0 (:57), region growing (:608), ...    */
+    MLD_ERR_NO_ROAD_ESTIMATOR = -4,  /* "No road depth estimator selected." (:94)                      */
+    MLD_ERR_NO_GROUND_PLANE = -5,    /* do_use_ransac_plane set but no plane supplied for the slot     */
+    MLD_ERR_CLOUD_TOO_SMALL = -6,    /* GroundPlane::ExceptionPclInvalid (RansacPlane.cpp:44-50)       */
+    MLD_ERR_HIP = -7,                /* a HIP runtime call failed; text in mld_last_error              */
+    MLD_ERR_CAPACITY = -8            /* n / F / window larger than the context was created for         */
+} mld_status;
+
+/* DepthResultType — monolidar_fusion/include/monolidar_fusion/eDepthResultType.h:8-30 (same values). */
+typedef enum mld_result_type {
+    MLD_Unspecified = 0,
+    MLD_Success = 1,
+    MLD_RadiusSearchInsufficientPoints = 2,
+    MLD_HistogramNoLocalMax = 3,
+    MLD_TresholdDepthGlobalGreaterMax = 4,
+    MLD_TresholdDepthGlobalSmallerMin = 5,
+    MLD_TresholdDepthLocalGreaterMax = 6,
+    MLD_TresholdDepthLocalSmallerMin = 7,
+    MLD_TriangleNotPlanar = 8,
+    MLD_TriangleNotPlanarInsufficientPoints = 9,
+    MLD_CornerBehindCamera = 10,
+    MLD_PlaneViewrayNotOrthogonal = 11,
+    MLD_PcaIsPoint = 12,
+    MLD_PcaIsLine = 13,
+    MLD_PcaIsCubic = 14,
+    MLD_InsufficientRoadPoints = 15,
+    MLD_SuccessRoad = 16,
+    MLD_RegionGrowingNearestSeedNotAvailable = 17,
+    MLD_RegionGrowingSeedsOutOfRange = 18,
+    MLD_RegionGrowingInsufficientPoints = 19,
+    MLD_SuccessRegionGrowing = 20,
+    MLD_RESULT_TYPE_COUNT = 21
+} mld_result_type;
+
+/* CameraPinhole(width, height, f, cu, cv) — camera_pinhole.h:29-34. */
+typedef struct mld_camera {
+    double focal_length;
+    double principal_point_x;
+    double principal_point_y;
+    int32_t width;
+    int32_t height;
+} mld_camera;
+
+/*
+ * The fields of DepthEstimatorParameters (DepthEstimatorParameters.h:7-173) that steer the hot
+ * path, same names (including the reference's spelling).  Fields the path never reads (kd-tree,
+ * region growing, RANSAC-estimation and debug knobs) are not mirrored.
+ * Layout: all doubles first, then int32s — no implicit padding except the tail.
+ */
+typedef struct mld_params {
+    double histogram_segmentation_bin_witdh;     /* :43  */
+    double treshold_depth_local_value;           /* :92  */
+    double pca_treshold_3_abs_min;               /* :102 */
+    double pca_treshold_3_2_rel_max;             /* :103 */
+    double pca_treshold_2_1_rel_min;             /* :104 */
+    double ransac_plane_point_distance_treshold; /* :122 */
+    double plane_estimator_z_x_min_relation;     /* :141 */
+    double triangleplanar_crossnorm_treshold;    /* :154 */
+    double viewray_plane_orthoganality_treshold; /* :155 */
+    int32_t neighbor_search_mode;                /* :20  must be 0 */
+    int32_t pixelarea_search_witdh;              /* :21  */
+    int32_t pixelarea_search_height;             /* :22  */
+    int32_t radiusSearch_count_min;              /* :35  */
+    int32_t do_use_histogram_segmentation;       /* :42  */
+    int32_t histogram_segmentation_min_pointcount; /* :44 */
+    int32_t do_use_depth_segmentation;           /* :48  must be 0 (reference throws, DepthEstimator.cpp:608) */
+    int32_t treshold_depth_enabled;              /* :78  */
+    int32_t treshold_depth_mode;                 /* :79  0 Dispose, 1 Adjust */
+    int32_t treshold_depth_max;                  /* :80  (int in the reference) */
+    int32_t treshold_depth_min;                  /* :81  */
+    int32_t treshold_depth_local_enabled;        /* :89  */
+    int32_t treshold_depth_local_mode;           /* :90  */
+    int32_t treshold_depth_local_valuetype;      /* :91  0 absolute, 1 relative */
+    int32_t do_use_PCA;                          /* :100 */
+    int32_t do_use_ransac_plane;                 /* :113 */
+    int32_t plane_estimator_use_triangle_maximation; /* :140 */
+    int32_t plane_estimator_use_leastsquares;    /* :142 (Ceres variant: unsupported, UB in the reference) */
+    int32_t plane_estimator_use_mestimator;      /* :143 */
+    int32_t do_use_cut_behind_camera;            /* :151 */
+    int32_t do_use_triangle_size_maximation;     /* :152 */
+    int32_t do_check_triangleplanar_condition;   /* :153 */
+    int32_t set_all_depths_to_zero;              /* :156 */
+    int32_t reserved_;
+} mld_params;
+
+/* Header defaults of DepthEstimatorParameters.h (note viewray_plane_orthoganality_treshold{01} == 1.0). */
+void mld_params_default(mld_params* p);
+/* "C0": monolidar_fusion/parameters.yaml with do_use_depth_segmentation: 0. */
+void mld_params_c0(mld_params* p);
+/* DepthEstimatorParameters::fromFile (DepthEstimatorParameters.cpp:16-114): `key: value` YAML subset. */
+int mld_params_from_file(mld_params* p, const char* path, char* err, int err_len);
+
+typedef struct mld_ctx mld_ctx;
+
+int mld_abi_version(void);
+
+/*
+ * InitConfig + Initialize (DepthEstimator.cpp:35-154).
+ *   T_cam_lidar: row-major 3x4 [R|t] of the lidar->camera Affine3d.
+ *   max_frames:  number of frame slots (>=1).  max_points / max_features: per-slot capacities for
+ *   the host-pointer entry points (device-pointer entry points borrow the caller's buffers).
+ * Returns NULL on failure; *status_out (optional) receives the reason, and
+ * mld_create_error() the text.
+ */
+mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const double T_cam_lidar[12],
+                    int device, int max_frames, int64_t max_points, int64_t max_features, int* status_out);
+const char* mld_create_error(void);
+void mld_destroy(mld_ctx* ctx);
+const char* mld_last_error(const mld_ctx* ctx);
+
+/* The hipStream_t the context launches on (as void*), for callers that order their own work. */
+void* mld_get_stream(mld_ctx* ctx);
+int mld_synchronize(mld_ctx* ctx);
+
+/*
+ * setInputCloud (DepthEstimator.cpp:220-312): projection + pixel->point map for one slot.
+ *   pts: x,y,z[,..] float32 records, stride_bytes 16 (packed xyzi) or 32 (pcl::PointXYZI layout,
+ *   DepthEstimator.cpp:169 reads rows 0-2 of the 8-float map).
+ */
+int mld_set_cloud(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, int stride_bytes);
+int mld_set_cloud_device(mld_ctx* ctx, int slot, const void* pts_dev, int64_t n, int stride_bytes);
+/* All slots [0, n_slots) in ONE launch; pts_dev[i] / n[i] are host arrays of device pointers / counts. */
+int mld_set_clouds_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev, const int64_t* n,
+                          int stride_bytes);
+
+/*
+ * The GroundPlane object handed to setInputCloud/CalculateDepth (RansacPlane.h:38-123):
+ * coefficients a,b,c,d in the LIDAR frame + the inlier index set keyed by ORIGINAL cloud index
+ * (`_pointIsInPlane`, RansacPlane.h:116-122).  coeffs == NULL: "ransacPlane == nullptr"
+ * (road fallback skipped, DepthEstimator.cpp:580).  Must be called after the slot's cloud is set.
+ */
+int mld_set_ground_plane(mld_ctx* ctx, int slot, const float coeffs[4], const int32_t* inlier_idx_host,
+                         int64_t n_inliers);
+int mld_set_ground_plane_device(mld_ctx* ctx, int slot, const float coeffs[4], const int32_t* inlier_idx_dev,
+                                int64_t n_inliers);
+/* Same, with the inlier set already as a device bitmask (bit i of word i/32 = point i is an inlier). */
+int mld_set_ground_plane_mask_device(mld_ctx* ctx, int slot, const float coeffs[4], const uint32_t* mask_dev);
+
+/*
+ * CalculateDepth(Matrix2Xd, VectorXd&, VectorXi&, GroundPlane::Ptr) (DepthEstimator.cpp:429-488).
+ *   uv: 2 x F column-major (u0,v0,u1,v1,...) float64, as Eigen::Matrix2Xd stores it.
+ *   depth_out: F float64 (metres, camera-frame z of the intersection, -1 on failure);
+ *   type_out: F int32 mld_result_type (may be NULL: the overload without resultType, :422-427).
+ * The host-pointer form copies in, runs, copies out and synchronises.
+ */
+int mld_calculate_depth(mld_ctx* ctx, int slot, const double* uv_host, int64_t F, double* depth_out_host,
+                        int32_t* type_out_host);
+int mld_calculate_depth_device(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, double* depth_out_dev,
+                               int32_t* type_out_dev);
+/* All slots [0, n_slots) in ONE launch set (host arrays of device pointers / counts). */
+int mld_calculate_depths_device(mld_ctx* ctx, int n_slots, const double* const* uv_dev, const int64_t* F,
+                                double* const* depth_out_dev, int32_t* const* type_out_dev);
+
+/*
+ * Debug / parity getters (host buffers; each synchronises).
+ *   mld_get_visible_count           -> _points_cs_image_visible.cols()         (DepthEstimator.cpp:192)
+ *   mld_get_visible_image_points    -> getPointsCloudImageCs, 2 x Nvis col-major (:392-394)
+ *   mld_get_point_index             -> PointcloudData::_pointIndex, Nvis int32   (:203)
+ *   mld_get_cloud_camera_cs         -> getCloudCameraCs, 3 x N col-major float64 (:314-334)
+ *   mld_get_pixel_map               -> NeighborFinderPixel::_img_points_lidar, W*H int32, index x + y*W,
+ *                                      value = VISIBLE index or -1               (NeighborFinderPixel.cpp:38-55)
+ *   mld_get_point_depth_cam_visible -> getPointDepthCamVisible(index)            (DepthEstimator.h:111-113)
+ */
+int mld_get_visible_count(mld_ctx* ctx, int slot, int64_t* n_visible);
+int mld_get_visible_image_points(mld_ctx* ctx, int slot, double* uv_out, int64_t capacity);
+int mld_get_point_index(mld_ctx* ctx, int slot, int32_t* index_out, int64_t capacity);
+int mld_get_cloud_camera_cs(mld_ctx* ctx, int slot, double* xyz_out, int64_t capacity);
+int mld_get_pixel_map(mld_ctx* ctx, int slot, int32_t* map_out, int64_t capacity);
+int mld_get_point_depth_cam_visible(mld_ctx* ctx, int slot, int64_t visible_index, double* depth_out);
+
+/* DepthCalculationStatistics counterpart: histogram of a resultType array (counts[MLD_RESULT_TYPE_COUNT]). */
+int mld_result_histogram(const int32_t* types, int64_t F, int64_t counts[MLD_RESULT_TYPE_COUNT]);
+
+/*
+ * Measurement hooks for bench.py (HIP events on the context's stream).
+ *   mld_kernel_time_ms: average duration in ms of the `which` kernel (0 = project/scatter,
+ *   1 = feature depth) over the launches since mld_timing_reset, measured with hipEvents recorded
+ *   around each launch when timing is enabled.
+ */
+int mld_timing_enable(mld_ctx* ctx, int enable);
+int mld_timing_reset(mld_ctx* ctx);
+int mld_kernel_time_ms(mld_ctx* ctx, int which, double* avg_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLD_H_ */

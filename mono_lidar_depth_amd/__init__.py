@@ -1,0 +1,12 @@
+"""MI355X-native DepthEstimator hot path (monolidar_fusion) behind the reference's interface.
+
+Layout: csrc/ (HIP kernels + C-ABI, built to lib/libmld_hip.so), host/ (C++ shim class with the reference's
+method names), depth_estimator.py (Python mirror used by tests and bench), synth.py (seeded synthetic frames),
+sharding.py (sequence -> GPU assignment and the calibration broadcast).
+"""
+from .capi import MldCamera, MldParams, params_c0, params_default, params_from_file, RESULT_TYPE_NAMES
+from .depth_estimator import (CameraPinhole, DepthEstimator, DepthEstimatorError, ExceptionPclInvalid,
+                              GroundPlane)
+
+__all__ = ["MldCamera", "MldParams", "params_c0", "params_default", "params_from_file", "RESULT_TYPE_NAMES",
+           "CameraPinhole", "DepthEstimator", "DepthEstimatorError", "ExceptionPclInvalid", "GroundPlane"]

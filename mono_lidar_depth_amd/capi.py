@@ -1,0 +1,176 @@
+"""ctypes binding of the C-ABI in include/mld.h (libmld_hip.so).
+
+The library is built in-tree by `mono_lidar_depth_amd/csrc/Makefile` (see `__graft_entry__.build`).
+There is no fallback: if the shared library is missing, importing the symbols raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "lib" / "libmld_hip.so"
+
+MLD_OK = 0
+MLD_ERR_INVALID_ARG = -1
+MLD_ERR_NOT_INITIALIZED = -2
+MLD_ERR_UNSUPPORTED_MODE = -3
+MLD_ERR_NO_ROAD_ESTIMATOR = -4
+MLD_ERR_NO_GROUND_PLANE = -5
+MLD_ERR_CLOUD_TOO_SMALL = -6
+MLD_ERR_HIP = -7
+MLD_ERR_CAPACITY = -8
+MLD_RESULT_TYPE_COUNT = 21
+
+# eDepthResultType.h:8-30
+RESULT_TYPE_NAMES = {
+    0: "Unspecified", 1: "Success", 2: "RadiusSearchInsufficientPoints", 3: "HistogramNoLocalMax",
+    4: "TresholdDepthGlobalGreaterMax", 5: "TresholdDepthGlobalSmallerMin", 6: "TresholdDepthLocalGreaterMax",
+    7: "TresholdDepthLocalSmallerMin", 8: "TriangleNotPlanar", 9: "TriangleNotPlanarInsufficientPoints",
+    10: "CornerBehindCamera", 11: "PlaneViewrayNotOrthogonal", 12: "PcaIsPoint", 13: "PcaIsLine",
+    14: "PcaIsCubic", 15: "InsufficientRoadPoints", 16: "SuccessRoad",
+    17: "RegionGrowingNearestSeedNotAvailable", 18: "RegionGrowingSeedsOutOfRange",
+    19: "RegionGrowingInsufficientPoints", 20: "SuccessRegionGrowing",
+}
+
+
+class MldCamera(C.Structure):
+    _fields_ = [
+        ("focal_length", C.c_double),
+        ("principal_point_x", C.c_double),
+        ("principal_point_y", C.c_double),
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+    ]
+
+
+class MldParams(C.Structure):
+    _fields_ = [
+        ("histogram_segmentation_bin_witdh", C.c_double),
+        ("treshold_depth_local_value", C.c_double),
+        ("pca_treshold_3_abs_min", C.c_double),
+        ("pca_treshold_3_2_rel_max", C.c_double),
+        ("pca_treshold_2_1_rel_min", C.c_double),
+        ("ransac_plane_point_distance_treshold", C.c_double),
+        ("plane_estimator_z_x_min_relation", C.c_double),
+        ("triangleplanar_crossnorm_treshold", C.c_double),
+        ("viewray_plane_orthoganality_treshold", C.c_double),
+        ("neighbor_search_mode", C.c_int32),
+        ("pixelarea_search_witdh", C.c_int32),
+        ("pixelarea_search_height", C.c_int32),
+        ("radiusSearch_count_min", C.c_int32),
+        ("do_use_histogram_segmentation", C.c_int32),
+        ("histogram_segmentation_min_pointcount", C.c_int32),
+        ("do_use_depth_segmentation", C.c_int32),
+        ("treshold_depth_enabled", C.c_int32),
+        ("treshold_depth_mode", C.c_int32),
+        ("treshold_depth_max", C.c_int32),
+        ("treshold_depth_min", C.c_int32),
+        ("treshold_depth_local_enabled", C.c_int32),
+        ("treshold_depth_local_mode", C.c_int32),
+        ("treshold_depth_local_valuetype", C.c_int32),
+        ("do_use_PCA", C.c_int32),
+        ("do_use_ransac_plane", C.c_int32),
+        ("plane_estimator_use_triangle_maximation", C.c_int32),
+        ("plane_estimator_use_leastsquares", C.c_int32),
+        ("plane_estimator_use_mestimator", C.c_int32),
+        ("do_use_cut_behind_camera", C.c_int32),
+        ("do_use_triangle_size_maximation", C.c_int32),
+        ("do_check_triangleplanar_condition", C.c_int32),
+        ("set_all_depths_to_zero", C.c_int32),
+        ("reserved_", C.c_int32),
+    ]
+
+    def copy(self) -> "MldParams":
+        out = MldParams()
+        C.memmove(C.byref(out), C.byref(self), C.sizeof(MldParams))
+        return out
+
+    def replace(self, **kw) -> "MldParams":
+        out = self.copy()
+        for k, v in kw.items():
+            if not hasattr(out, k):
+                raise AttributeError(k)
+            setattr(out, k, v)
+        return out
+
+
+# Every symbol include/mld.h declares: (name, restype, argtypes)
+_P = C.POINTER
+_SIGNATURES = [
+    ("mld_params_default", None, [_P(MldParams)]),
+    ("mld_params_c0", None, [_P(MldParams)]),
+    ("mld_params_from_file", C.c_int, [_P(MldParams), C.c_char_p, C.c_char_p, C.c_int]),
+    ("mld_abi_version", C.c_int, []),
+    ("mld_create", C.c_void_p, [_P(MldParams), _P(MldCamera), _P(C.c_double), C.c_int, C.c_int, C.c_int64,
+                                C.c_int64, _P(C.c_int)]),
+    ("mld_create_error", C.c_char_p, []),
+    ("mld_destroy", None, [C.c_void_p]),
+    ("mld_last_error", C.c_char_p, [C.c_void_p]),
+    ("mld_get_stream", C.c_void_p, [C.c_void_p]),
+    ("mld_synchronize", C.c_int, [C.c_void_p]),
+    ("mld_set_cloud", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
+    ("mld_set_cloud_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
+    ("mld_set_clouds_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64), C.c_int]),
+    ("mld_set_ground_plane", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p, C.c_int64]),
+    ("mld_set_ground_plane_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p, C.c_int64]),
+    ("mld_set_ground_plane_mask_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p]),
+    ("mld_calculate_depth", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("mld_calculate_depth_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("mld_calculate_depths_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64),
+                                              _P(C.c_void_p), _P(C.c_void_p)]),
+    ("mld_get_visible_count", C.c_int, [C.c_void_p, C.c_int, _P(C.c_int64)]),
+    ("mld_get_visible_image_points", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    ("mld_get_point_index", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    ("mld_get_cloud_camera_cs", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    ("mld_get_pixel_map", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
+    ("mld_get_point_depth_cam_visible", C.c_int, [C.c_void_p, C.c_int, C.c_int64, _P(C.c_double)]),
+    ("mld_result_histogram", C.c_int, [C.c_void_p, C.c_int64, _P(C.c_int64)]),
+    ("mld_timing_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("mld_timing_reset", C.c_int, [C.c_void_p]),
+    ("mld_kernel_time_ms", C.c_int, [C.c_void_p, C.c_int, _P(C.c_double), _P(C.c_int64)]),
+]
+EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libmld_hip.so.  Raises (never falls back) when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("MLD_HIP_LIBRARY", LIB_PATH))
+    if not path.exists():
+        raise RuntimeError(
+            f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C mono_lidar_depth_amd/csrc`). There is no CPU fallback for this path.")
+    lib = C.CDLL(str(path))
+    for name, restype, argtypes in _SIGNATURES:
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def params_c0() -> MldParams:
+    p = MldParams()
+    load().mld_params_c0(C.byref(p))
+    return p
+
+
+def params_default() -> MldParams:
+    p = MldParams()
+    load().mld_params_default(C.byref(p))
+    return p
+
+
+def params_from_file(path: str) -> MldParams:
+    p = MldParams()
+    err = C.create_string_buffer(512)
+    rc = load().mld_params_from_file(C.byref(p), str(path).encode(), err, 512)
+    if rc != MLD_OK:
+        raise RuntimeError(err.value.decode())
+    return p

@@ -1,0 +1,813 @@
+// C-ABI (include/mld.h) of the MI355X DepthEstimator path: context, frame slots, launches.
+//
+// Host counterpart of Mono_Lidar::DepthEstimator (monolidar_fusion/src/DepthEstimator.cpp): Initialize /
+// InitConfig -> mld_create, setInputCloud -> mld_set_cloud*, CalculateDepth -> mld_calculate_depth*.
+// There is no CPU fallback: every entry point that computes goes through the HIP kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mld.h"
+#include "mld_device.h"
+#include "mld_kernels.hip"
+
+using namespace mld;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Slot {
+    SlotDesc d{};
+    bool cloud_set = false;
+    bool plane_decided = false;
+    // buffers owned by the context (host-pointer entry points)
+    unsigned char* cloud_buf = nullptr;
+    size_t cloud_cap = 0;
+    double* uv_buf = nullptr;
+    double* depth_buf = nullptr;
+    int32_t* type_buf = nullptr;
+    size_t feat_cap = 0;
+    int32_t* inl_buf = nullptr;
+    size_t inl_cap = 0;
+    uint32_t* mask_buf = nullptr;
+    size_t mask_words = 0;
+    // lazy PointcloudData for the debug getters
+    bool full_valid = false;
+    size_t dbg_cap = 0;
+    double* cam = nullptr;
+    double* img = nullptr;
+    int32_t* vis = nullptr;
+    int32_t* rank = nullptr;
+    int32_t* pidx = nullptr;
+    double* img_vis = nullptr;
+    int32_t* block_sums = nullptr;
+    int32_t* d_total = nullptr;
+    int64_t nvis = 0;
+};
+
+struct TimedLaunch {
+    hipEvent_t e0, e1;
+    int which;
+};
+
+}  // namespace
+
+struct mld_ctx {
+    mld_params P{};
+    mld_camera cam{};
+    Calib calib{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::vector<Slot> slots;
+    SlotDesc* d_slots = nullptr;
+    std::vector<SlotDesc> h_descs;
+    size_t lds_bytes = 0;
+    std::string err;
+    bool timing = false;
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, call)                                                                                  \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                 \
+            return MLD_ERR_HIP;                                                                             \
+        }                                                                                                   \
+    } while (0)
+
+int fail(mld_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+// 3x3 inverse by cofactors (Eigen compute_inverse<Matrix3d>): result(i,j) = cofactor<j,i> / det.
+double cof(const double m[9], int i, int j) {
+    int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return m[i1 * 3 + j1] * m[i2 * 3 + j2] - m[i1 * 3 + j2] * m[i2 * 3 + j1];
+}
+void inverse3(const double m[9], double out[9]) {
+    double c0 = cof(m, 0, 0), c1 = cof(m, 1, 0), c2 = cof(m, 2, 0);
+    double det = c0 * m[0] + (c1 * m[3] + c2 * m[6]);
+    double invdet = 1.0 / det;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) out[i * 3 + j] = cof(m, j, i) * invdet;
+}
+
+// Upper bound on the cells one search window can cover: floor(2*half) + 2 columns / rows.
+int window_cells(double halfX, double halfY) {
+    int nx = (int)std::floor(2.0 * halfX) + 2, ny = (int)std::floor(2.0 * halfY) + 2;
+    if (nx < 1) nx = 1;
+    if (ny < 1) ny = 1;
+    return nx * ny;
+}
+
+int validate_params(const mld_params& P, std::string& why) {
+    if (P.neighbor_search_mode != 0) {
+        why = "neighbor_search_mode has the invalid value: " + std::to_string(P.neighbor_search_mode);  // :57
+        return MLD_ERR_UNSUPPORTED_MODE;
+    }
+    if (P.do_use_depth_segmentation) {
+        why = "DepthEstimator: Region growing not supported!";  // :608
+        return MLD_ERR_UNSUPPORTED_MODE;
+    }
+    if (P.do_use_ransac_plane) {
+        if (P.plane_estimator_use_triangle_maximation) {
+        } else if (P.plane_estimator_use_leastsquares) {
+            why = "plane_estimator_use_leastsquares (Ceres variant) is not supported: out-of-bounds read in the "
+                  "reference (PlaneEstimationLeastSquares.cpp:19,41)";
+            return MLD_ERR_UNSUPPORTED_MODE;
+        } else if (P.plane_estimator_use_mestimator) {
+        } else {
+            why = "No road depth estimator selected.";  // :94
+            return MLD_ERR_NO_ROAD_ESTIMATOR;
+        }
+    }
+    if (P.pixelarea_search_witdh < 0 || P.pixelarea_search_height < 0) {
+        why = "negative search window";
+        return MLD_ERR_INVALID_ARG;
+    }
+    return MLD_OK;
+}
+
+void build_calib(mld_ctx* ctx, const double T[12]) {
+    Calib& c = ctx->calib;
+    const mld_params& P = ctx->P;
+    std::memcpy(c.T, T, sizeof(double) * 12);
+    // _transform_cam_to_lidar = transform_lidar_to_cam.inverse()   (DepthEstimator.cpp:44)
+    double L[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]}, Li[9];
+    inverse3(L, Li);
+    double t[3] = {T[3], T[7], T[11]};
+    for (int i = 0; i < 3; i++) {
+        c.Tinv[i * 4 + 0] = Li[i * 3 + 0];
+        c.Tinv[i * 4 + 1] = Li[i * 3 + 1];
+        c.Tinv[i * 4 + 2] = Li[i * 3 + 2];
+        c.Tinv[i * 4 + 3] = (-Li[i * 3 + 0]) * t[0] + ((-Li[i * 3 + 1]) * t[1] + (-Li[i * 3 + 2]) * t[2]);
+    }
+    double K[9] = {ctx->cam.focal_length, 0, ctx->cam.principal_point_x, 0, ctx->cam.focal_length,
+                   ctx->cam.principal_point_y, 0, 0, 1};
+    inverse3(K, c.Kinv);
+    c.f = ctx->cam.focal_length;
+    c.cu = ctx->cam.principal_point_x;
+    c.cv = ctx->cam.principal_point_y;
+    c.W = ctx->cam.width;
+    c.H = ctx->cam.height;
+    // NeighborFinderPixel.cpp:67-68, scales (1,1) and (2.0f,1.5f) (DepthEstimator.cpp:509,585)
+    c.halfX1 = (double)P.pixelarea_search_witdh * 0.5 * (double)1.0f;
+    c.halfY1 = (double)P.pixelarea_search_height * 0.5 * (double)1.0f;
+    c.halfX2 = (double)P.pixelarea_search_witdh * 0.5 * (double)2.0f;
+    c.halfY2 = (double)P.pixelarea_search_height * 0.5 * (double)1.5f;
+    int cap = window_cells(c.halfX1, c.halfY1);
+    if (P.do_use_ransac_plane) cap = std::max(cap, window_cells(c.halfX2, c.halfY2));
+    cap = (cap + 1) & ~1;
+    c.cap = cap;
+    c.binW = P.histogram_segmentation_bin_witdh;
+    c.minCount = P.histogram_segmentation_min_pointcount;
+    c.countMin = (unsigned)P.radiusSearch_count_min;
+    c.useHist = P.do_use_histogram_segmentation;
+    c.thrG_en = P.treshold_depth_enabled;
+    c.thrG_mode = P.treshold_depth_mode;
+    c.thrG_min = (double)P.treshold_depth_min;
+    c.thrG_max = (double)P.treshold_depth_max;
+    c.thrL_en = P.treshold_depth_local_enabled;
+    c.thrL_mode = P.treshold_depth_local_mode;
+    c.thrL_type = P.treshold_depth_local_valuetype;
+    c.thrL_val = P.treshold_depth_local_value;
+    c.useTriMax = P.do_use_triangle_size_maximation;
+    c.checkPlanar = P.do_check_triangleplanar_condition;
+    c.planarThr = P.triangleplanar_crossnorm_treshold;
+    c.orthThr = P.viewray_plane_orthoganality_treshold;
+    c.cutBehind = P.do_use_cut_behind_camera;
+    c.useRoad = P.do_use_ransac_plane;
+    c.roadMode = P.plane_estimator_use_triangle_maximation ? 1 : 0;
+    c.roadDistThr = P.ransac_plane_point_distance_treshold;
+    c.zxMinRel = P.plane_estimator_z_x_min_relation;
+    c.usePCA = P.do_use_PCA;
+    c.pcaAbsMin = P.pca_treshold_3_abs_min;
+    c.pcaRelMax = P.pca_treshold_3_2_rel_max;
+    c.pcaRelMin = P.pca_treshold_2_1_rel_min;
+    ctx->lds_bytes = (size_t)cap * (3 * sizeof(double) + 2 * sizeof(int)) + (size_t)kRecFields * kWave * sizeof(double);
+}
+
+int check_slot(mld_ctx* ctx, int slot) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= (int)ctx->slots.size()) return fail(ctx, MLD_ERR_INVALID_ARG, "slot out of range");
+    return MLD_OK;
+}
+
+int bind_device(mld_ctx* ctx) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return MLD_OK;
+}
+
+template <typename T>
+int grow(mld_ctx* ctx, T*& ptr, size_t& cap, size_t need) {
+    if (need <= cap && ptr) return MLD_OK;
+    if (ptr) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(ptr));
+        ptr = nullptr;
+    }
+    size_t n = need < 1 ? 1 : need;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T)));
+    cap = n;
+    return MLD_OK;
+}
+
+hipEvent_t get_event(mld_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ScopedTimer {
+    mld_ctx* ctx;
+    TimedLaunch t{};
+    bool on;
+    ScopedTimer(mld_ctx* c, int which) : ctx(c), on(c->timing) {
+        if (on) {
+            t.e0 = get_event(ctx);
+            t.e1 = get_event(ctx);
+            t.which = which;
+            (void)hipEventRecord(t.e0, ctx->stream);
+        }
+    }
+    ~ScopedTimer() {
+        if (on) {
+            (void)hipEventRecord(t.e1, ctx->stream);
+            ctx->timed.push_back(t);
+        }
+    }
+};
+
+// New cloud for a slot: bump the map tag (zero-fill on wrap), forget the previous plane / debug data.
+int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int stride) {
+    if (n < 0 || n > kMaxPoints) return fail(ctx, MLD_ERR_CAPACITY, "cloud larger than 16 777 215 points");
+    if (stride != 16 && stride != 32) return fail(ctx, MLD_ERR_INVALID_ARG, "stride_bytes must be 16 or 32");
+    if (!dev_ptr && n > 0) return fail(ctx, MLD_ERR_INVALID_ARG, "null cloud pointer");
+    if (((size_t)dev_ptr & 3) != 0) return fail(ctx, MLD_ERR_INVALID_ARG, "cloud pointer must be 4-byte aligned");
+    if (s.d.tag >= kMaxTag) {
+        HIP_TRY(ctx, hipMemsetAsync(s.d.map, 0, (size_t)ctx->cam.width * ctx->cam.height * sizeof(uint32_t),
+                                    ctx->stream));
+        s.d.tag = 1;
+    } else {
+        s.d.tag += 1;
+    }
+    s.d.cloud = static_cast<const unsigned char*>(dev_ptr);
+    s.d.n = n;
+    s.d.stride = stride;
+    s.d.has_plane = 0;
+    s.d.inlier_mask = nullptr;
+    s.cloud_set = true;
+    s.plane_decided = false;
+    s.full_valid = false;
+    return MLD_OK;
+}
+
+int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int slot) {
+    if (max_n <= 0) return MLD_OK;
+    const int per_block = kProjThreads * kProjPerThread;
+    int per_slot = (int)((max_n + per_block - 1) / per_block);
+    ScopedTimer tm(ctx, 0);
+    if (single) {
+        hipLaunchKernelGGL(k_project_scatter, dim3(per_slot), dim3(kProjThreads), 0, ctx->stream, ctx->d_slots,
+                           ctx->slots[slot].d, 1, ctx->calib, 1, per_slot);
+    } else {
+        hipLaunchKernelGGL(k_project_scatter, dim3((unsigned)per_slot * n_slots), dim3(kProjThreads), 0, ctx->stream,
+                           ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return MLD_OK;
+}
+
+int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int slot) {
+    if (max_F <= 0) return MLD_OK;
+    int per_slot = (int)((max_F + kWave - 1) / kWave);
+    ScopedTimer tm(ctx, 1);
+    if (single) {
+        hipLaunchKernelGGL(k_feature_depth, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
+                           ctx->slots[slot].d, 1, ctx->calib, 1, per_slot);
+    } else {
+        hipLaunchKernelGGL(k_feature_depth, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
+                           ctx->stream, ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return MLD_OK;
+}
+
+int upload_descs(mld_ctx* ctx, int n_slots) {
+    // pageable source: the runtime stages it before returning, so h_descs may be rewritten afterwards
+    for (int i = 0; i < n_slots; i++) ctx->h_descs[i] = ctx->slots[i].d;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slots, ctx->h_descs.data(), sizeof(SlotDesc) * n_slots, hipMemcpyHostToDevice,
+                                ctx->stream));
+    return MLD_OK;
+}
+
+int precheck_calc(mld_ctx* ctx, Slot& s, int64_t F) {
+    if (!s.cloud_set) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "call of 'CalculateDepth' without 'SetInputCloud'");
+    if (F < 0) return fail(ctx, MLD_ERR_INVALID_ARG, "negative feature count");
+    if (ctx->P.do_use_ransac_plane && !s.plane_decided && !ctx->P.set_all_depths_to_zero)
+        return fail(ctx, MLD_ERR_NO_GROUND_PLANE,
+                    "do_use_ransac_plane is set but no ground plane was supplied for this cloud "
+                    "(mld_set_ground_plane; pass NULL coefficients for 'no plane')");
+    return MLD_OK;
+}
+
+int set_plane_common(mld_ctx* ctx, Slot& s, const float coeffs[4]) {
+    if (!s.cloud_set) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "ground plane set before the slot's cloud");
+    s.plane_decided = true;
+    if (!coeffs) {
+        s.d.has_plane = 0;
+        s.d.inlier_mask = nullptr;
+        return 1;  // handled
+    }
+    std::memcpy(s.d.coeffs, coeffs, sizeof(float) * 4);
+    // DepthEstimator.cpp:289-291: prior = Hyperplane(Vector3d(a,b,c).normalized(), d)
+    double a = (double)coeffs[0], b = (double)coeffs[1], cc = (double)coeffs[2];
+    double z = a * a + (b * b + cc * cc);
+    if (z > 0.0) {
+        double nrm = std::sqrt(z);
+        a /= nrm;
+        b /= nrm;
+        cc /= nrm;
+    }
+    s.d.prior_n[0] = a;
+    s.d.prior_n[1] = b;
+    s.d.prior_n[2] = cc;
+    s.d.prior_off = (double)coeffs[3];
+    s.d.has_plane = 1;
+    return MLD_OK;
+}
+
+int build_mask_from_indices(mld_ctx* ctx, Slot& s, const int32_t* idx_dev, int64_t n_inl) {
+    size_t words = (size_t)((s.d.n + 31) / 32);
+    int rc = grow(ctx, s.mask_buf, s.mask_words, words);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(s.mask_buf, 0, (words < 1 ? 1 : words) * sizeof(uint32_t), ctx->stream));
+    if (n_inl > 0) {
+        int blocks = (int)((n_inl + 255) / 256);
+        hipLaunchKernelGGL(k_build_mask, dim3(blocks), dim3(256), 0, ctx->stream, idx_dev, (long long)n_inl,
+                           (long long)s.d.n, s.mask_buf);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    s.d.inlier_mask = s.mask_buf;
+    return MLD_OK;
+}
+
+int ensure_full(mld_ctx* ctx, Slot& s) {
+    if (!s.cloud_set) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "no cloud set for this slot");
+    if (s.full_valid) return MLD_OK;
+    size_t n = (size_t)s.d.n;
+    if (n > s.dbg_cap || !s.cam) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        void* olds[] = {s.cam, s.img, s.vis, s.rank, s.pidx, s.img_vis, s.block_sums, s.d_total};
+        for (void* p : olds)
+            if (p) HIP_TRY(ctx, hipFree(p));
+        size_t m = n < 1 ? 1 : n;
+        size_t nb = (m + kScanBlock - 1) / kScanBlock;
+        HIP_TRY(ctx, hipMalloc((void**)&s.cam, m * 3 * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void**)&s.img, m * 2 * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void**)&s.vis, m * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&s.rank, m * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&s.pidx, m * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&s.img_vis, m * 2 * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void**)&s.block_sums, nb * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&s.d_total, sizeof(int32_t)));
+        s.dbg_cap = m;
+    }
+    int32_t total = 0;
+    if (n > 0) {
+        int nb = (int)((n + kScanBlock - 1) / kScanBlock);
+        hipLaunchKernelGGL(k_project_full, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, s.d,
+                           ctx->calib, s.cam, s.img, s.vis);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(kScanBlock), 0, ctx->stream, s.vis, (long long)n,
+                           s.block_sums);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, ctx->stream, s.block_sums, nb, s.d_total);
+        hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(kScanBlock), 0, ctx->stream, s.vis, (long long)n,
+                           s.block_sums, s.img, s.rank, s.pidx, s.img_vis);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipMemcpyAsync(&total, s.d_total, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    s.nvis = total;
+    s.full_valid = true;
+    return MLD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mld_create_error(void) { return g_create_error.c_str(); }
+
+mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const double T_cam_lidar[12], int device,
+                    int max_frames, int64_t max_points, int64_t max_features, int* status_out) {
+    auto bail = [&](int code, const std::string& msg) -> mld_ctx* {
+        g_create_error = msg;
+        if (status_out) *status_out = code;
+        return nullptr;
+    };
+    if (status_out) *status_out = MLD_OK;
+    if (!params || !camera || !T_cam_lidar) return bail(MLD_ERR_INVALID_ARG, "null argument");
+    if (max_frames < 1) return bail(MLD_ERR_INVALID_ARG, "max_frames must be >= 1");
+    if (camera->width < 1 || camera->height < 1) return bail(MLD_ERR_INVALID_ARG, "bad image size");
+    if (max_points > kMaxPoints) return bail(MLD_ERR_CAPACITY, "max_points exceeds 16 777 215");
+    std::string why;
+    int v = validate_params(*params, why);
+    if (v != MLD_OK) return bail(v, why);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return bail(MLD_ERR_HIP, std::string("no HIP device available (") + hipGetErrorString(e) +
+                                     "): the DepthEstimator path has no CPU fallback");
+    if (device < 0 || device >= ndev) return bail(MLD_ERR_INVALID_ARG, "device index out of range");
+
+    mld_ctx* ctx = new mld_ctx();
+    ctx->P = *params;
+    ctx->cam = *camera;
+    ctx->device = device;
+    build_calib(ctx, T_cam_lidar);
+    auto hip_bail = [&](hipError_t err, const char* what) -> mld_ctx* {
+        std::string m = std::string(what) + ": " + hipGetErrorString(err);
+        mld_destroy(ctx);
+        return bail(MLD_ERR_HIP, m);
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return hip_bail(e, "hipSetDevice");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return hip_bail(e, "hipGetDeviceProperties");
+    if (ctx->lds_bytes > (size_t)prop.sharedMemPerBlock) {
+        mld_destroy(ctx);
+        return bail(MLD_ERR_CAPACITY, "search window too large for the LDS-staged neighbour list");
+    }
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+        return hip_bail(e, "hipStreamCreate");
+    if (ctx->lds_bytes > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_depth),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
+        if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute");
+    }
+    ctx->slots.resize(max_frames);
+    ctx->h_descs.resize(max_frames);
+    if ((e = hipMalloc((void**)&ctx->d_slots, sizeof(SlotDesc) * max_frames)) != hipSuccess)
+        return hip_bail(e, "hipMalloc(slots)");
+    size_t cells = (size_t)camera->width * camera->height;
+    for (Slot& s : ctx->slots) {
+        if ((e = hipMalloc((void**)&s.d.map, cells * sizeof(uint32_t))) != hipSuccess) return hip_bail(e, "hipMalloc(map)");
+        if ((e = hipMemsetAsync(s.d.map, 0, cells * sizeof(uint32_t), ctx->stream)) != hipSuccess)
+            return hip_bail(e, "hipMemset(map)");
+        s.d.tag = 0;
+        if (max_points > 0) {
+            if ((e = hipMalloc((void**)&s.cloud_buf, (size_t)max_points * 32)) != hipSuccess)
+                return hip_bail(e, "hipMalloc(cloud)");
+            s.cloud_cap = (size_t)max_points * 32;
+        }
+        if (max_features > 0) {
+            size_t F = (size_t)max_features;
+            if ((e = hipMalloc((void**)&s.uv_buf, F * 2 * sizeof(double))) != hipSuccess) return hip_bail(e, "hipMalloc(uv)");
+            if ((e = hipMalloc((void**)&s.depth_buf, F * sizeof(double))) != hipSuccess) return hip_bail(e, "hipMalloc(depth)");
+            if ((e = hipMalloc((void**)&s.type_buf, F * sizeof(int32_t))) != hipSuccess) return hip_bail(e, "hipMalloc(type)");
+            s.feat_cap = F;
+        }
+    }
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return hip_bail(e, "hipStreamSynchronize");
+    return ctx;
+}
+
+void mld_destroy(mld_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (Slot& s : ctx->slots) {
+        void* ptrs[] = {s.d.map,  s.cloud_buf, s.uv_buf, s.depth_buf, s.type_buf, s.inl_buf,    s.mask_buf, s.cam,
+                        s.img,    s.vis,       s.rank,   s.pidx,      s.img_vis,  s.block_sums, s.d_total};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+    if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    for (TimedLaunch& t : ctx->timed) {
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+    }
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->stream && ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* mld_last_error(const mld_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+void* mld_get_stream(mld_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int mld_synchronize(mld_ctx* ctx) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MLD_OK;
+}
+
+// ---------------------------------------------------------------------------- setInputCloud
+int mld_set_cloud_device(mld_ctx* ctx, int slot, const void* pts_dev, int64_t n, int stride_bytes) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    if ((rc = begin_cloud(ctx, s, pts_dev, n, stride_bytes))) return rc;
+    return launch_project(ctx, 1, n, true, slot);
+}
+
+int mld_set_cloud(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, int stride_bytes) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    if (n < 0 || (!pts_host && n > 0)) return fail(ctx, MLD_ERR_INVALID_ARG, "bad cloud");
+    if (stride_bytes != 16 && stride_bytes != 32) return fail(ctx, MLD_ERR_INVALID_ARG, "stride_bytes must be 16 or 32");
+    Slot& s = ctx->slots[slot];
+    size_t bytes = (size_t)n * (size_t)stride_bytes;
+    if ((rc = grow(ctx, s.cloud_buf, s.cloud_cap, bytes))) return rc;
+    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(s.cloud_buf, pts_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = begin_cloud(ctx, s, s.cloud_buf, n, stride_bytes))) return rc;
+    return launch_project(ctx, 1, n, true, slot);
+}
+
+int mld_set_clouds_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev, const int64_t* n, int stride_bytes) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    if (n_slots < 1 || n_slots > (int)ctx->slots.size() || !pts_dev || !n)
+        return fail(ctx, MLD_ERR_INVALID_ARG, "bad slot count / null arrays");
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    int64_t max_n = 0;
+    for (int i = 0; i < n_slots; i++) {
+        if ((rc = begin_cloud(ctx, ctx->slots[i], pts_dev[i], n[i], stride_bytes))) return rc;
+        max_n = std::max(max_n, n[i]);
+    }
+    if ((rc = upload_descs(ctx, n_slots))) return rc;
+    return launch_project(ctx, n_slots, max_n, false, 0);
+}
+
+// ---------------------------------------------------------------------------- ground plane
+int mld_set_ground_plane_device(mld_ctx* ctx, int slot, const float coeffs[4], const int32_t* inlier_idx_dev,
+                                int64_t n_inliers) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    rc = set_plane_common(ctx, s, coeffs);
+    if (rc == 1) return MLD_OK;
+    if (rc) return rc;
+    if (n_inliers < 0 || (!inlier_idx_dev && n_inliers > 0)) return fail(ctx, MLD_ERR_INVALID_ARG, "bad inlier list");
+    return build_mask_from_indices(ctx, s, inlier_idx_dev, n_inliers);
+}
+
+int mld_set_ground_plane(mld_ctx* ctx, int slot, const float coeffs[4], const int32_t* inlier_idx_host,
+                         int64_t n_inliers) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    rc = set_plane_common(ctx, s, coeffs);
+    if (rc == 1) return MLD_OK;
+    if (rc) return rc;
+    if (n_inliers < 0 || (!inlier_idx_host && n_inliers > 0)) return fail(ctx, MLD_ERR_INVALID_ARG, "bad inlier list");
+    if ((rc = grow(ctx, s.inl_buf, s.inl_cap, (size_t)n_inliers))) return rc;
+    if (n_inliers)
+        HIP_TRY(ctx, hipMemcpyAsync(s.inl_buf, inlier_idx_host, (size_t)n_inliers * sizeof(int32_t),
+                                    hipMemcpyHostToDevice, ctx->stream));
+    return build_mask_from_indices(ctx, s, s.inl_buf, n_inliers);
+}
+
+int mld_set_ground_plane_mask_device(mld_ctx* ctx, int slot, const float coeffs[4], const uint32_t* mask_dev) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    Slot& s = ctx->slots[slot];
+    rc = set_plane_common(ctx, s, coeffs);
+    if (rc == 1) return MLD_OK;
+    if (rc) return rc;
+    if (!mask_dev) return fail(ctx, MLD_ERR_INVALID_ARG, "null mask");
+    s.d.inlier_mask = mask_dev;
+    return MLD_OK;
+}
+
+// ---------------------------------------------------------------------------- CalculateDepth
+static int calc_one(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, double* depth_dev, int32_t* type_dev) {
+    Slot& s = ctx->slots[slot];
+    s.d.uv = uv_dev;
+    s.d.F = F;
+    s.d.depth = depth_dev;
+    s.d.type = type_dev;
+    if (F == 0) return MLD_OK;
+    if (ctx->P.set_all_depths_to_zero) {
+        hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, ctx->stream, depth_dev,
+                           type_dev, (long long)F);
+        HIP_TRY(ctx, hipGetLastError());
+        return MLD_OK;
+    }
+    return launch_features(ctx, 1, F, true, slot);
+}
+
+int mld_calculate_depth_device(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, double* depth_out_dev,
+                               int32_t* type_out_dev) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    if ((rc = precheck_calc(ctx, ctx->slots[slot], F))) return rc;
+    if (F > 0 && (!uv_dev || !depth_out_dev)) return fail(ctx, MLD_ERR_INVALID_ARG, "null feature/output pointer");
+    return calc_one(ctx, slot, uv_dev, F, depth_out_dev, type_out_dev);
+}
+
+int mld_calculate_depth(mld_ctx* ctx, int slot, const double* uv_host, int64_t F, double* depth_out_host,
+                        int32_t* type_out_host) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    if ((rc = precheck_calc(ctx, s, F))) return rc;
+    if (F == 0) return MLD_OK;
+    if (!uv_host || !depth_out_host) return fail(ctx, MLD_ERR_INVALID_ARG, "null feature/output pointer");
+    if ((size_t)F > s.feat_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        void* olds[] = {s.uv_buf, s.depth_buf, s.type_buf};
+        for (void* p : olds)
+            if (p) HIP_TRY(ctx, hipFree(p));
+        s.uv_buf = nullptr;
+        s.depth_buf = nullptr;
+        s.type_buf = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&s.uv_buf, (size_t)F * 2 * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void**)&s.depth_buf, (size_t)F * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void**)&s.type_buf, (size_t)F * sizeof(int32_t)));
+        s.feat_cap = (size_t)F;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(s.uv_buf, uv_host, (size_t)F * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = calc_one(ctx, slot, s.uv_buf, F, s.depth_buf, s.type_buf))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(depth_out_host, s.depth_buf, (size_t)F * sizeof(double), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    if (type_out_host)
+        HIP_TRY(ctx, hipMemcpyAsync(type_out_host, s.type_buf, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                    ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MLD_OK;
+}
+
+int mld_calculate_depths_device(mld_ctx* ctx, int n_slots, const double* const* uv_dev, const int64_t* F,
+                                double* const* depth_out_dev, int32_t* const* type_out_dev) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    if (n_slots < 1 || n_slots > (int)ctx->slots.size() || !uv_dev || !F || !depth_out_dev)
+        return fail(ctx, MLD_ERR_INVALID_ARG, "bad slot count / null arrays");
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    int64_t max_F = 0;
+    for (int i = 0; i < n_slots; i++) {
+        Slot& s = ctx->slots[i];
+        if ((rc = precheck_calc(ctx, s, F[i]))) return rc;
+        if (F[i] > 0 && (!uv_dev[i] || !depth_out_dev[i])) return fail(ctx, MLD_ERR_INVALID_ARG, "null feature/output pointer");
+        s.d.uv = uv_dev[i];
+        s.d.F = F[i];
+        s.d.depth = depth_out_dev[i];
+        s.d.type = type_out_dev ? type_out_dev[i] : nullptr;
+        max_F = std::max(max_F, F[i]);
+    }
+    if (ctx->P.set_all_depths_to_zero) {
+        for (int i = 0; i < n_slots; i++)
+            if (F[i] > 0)
+                hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)((F[i] + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   depth_out_dev[i], type_out_dev ? type_out_dev[i] : nullptr, (long long)F[i]);
+        HIP_TRY(ctx, hipGetLastError());
+        return MLD_OK;
+    }
+    if ((rc = upload_descs(ctx, n_slots))) return rc;
+    return launch_features(ctx, n_slots, max_F, false, 0);
+}
+
+// ---------------------------------------------------------------------------- getters
+int mld_get_visible_count(mld_ctx* ctx, int slot, int64_t* n_visible) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if (!n_visible) return fail(ctx, MLD_ERR_INVALID_ARG, "null output");
+    if ((rc = bind_device(ctx))) return rc;
+    if ((rc = ensure_full(ctx, ctx->slots[slot]))) return rc;
+    *n_visible = ctx->slots[slot].nvis;
+    return MLD_OK;
+}
+
+int mld_get_visible_image_points(mld_ctx* ctx, int slot, double* uv_out, int64_t capacity) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    if ((rc = ensure_full(ctx, s))) return rc;
+    if (capacity < s.nvis) return fail(ctx, MLD_ERR_CAPACITY, "output buffer too small");
+    if (s.nvis) {
+        HIP_TRY(ctx, hipMemcpyAsync(uv_out, s.img_vis, (size_t)s.nvis * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MLD_OK;
+}
+
+int mld_get_point_index(mld_ctx* ctx, int slot, int32_t* index_out, int64_t capacity) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    if ((rc = ensure_full(ctx, s))) return rc;
+    if (capacity < s.nvis) return fail(ctx, MLD_ERR_CAPACITY, "output buffer too small");
+    if (s.nvis) {
+        HIP_TRY(ctx, hipMemcpyAsync(index_out, s.pidx, (size_t)s.nvis * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MLD_OK;
+}
+
+int mld_get_cloud_camera_cs(mld_ctx* ctx, int slot, double* xyz_out, int64_t capacity) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    if ((rc = ensure_full(ctx, s))) return rc;
+    if (capacity < s.d.n) return fail(ctx, MLD_ERR_CAPACITY, "output buffer too small");
+    if (s.d.n) {
+        HIP_TRY(ctx, hipMemcpyAsync(xyz_out, s.cam, (size_t)s.d.n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return MLD_OK;
+}
+
+int mld_get_pixel_map(mld_ctx* ctx, int slot, int32_t* map_out, int64_t capacity) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    if ((rc = ensure_full(ctx, s))) return rc;
+    long long cells = (long long)ctx->cam.width * ctx->cam.height;
+    if (capacity < cells) return fail(ctx, MLD_ERR_CAPACITY, "output buffer too small");
+    int32_t* tmp = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&tmp, (size_t)cells * sizeof(int32_t)));
+    hipLaunchKernelGGL(k_export_map, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, s.d.map, s.d.tag,
+                       s.rank, cells, tmp);
+    hipError_t e = hipMemcpyAsync(map_out, tmp, (size_t)cells * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    HIP_TRY(ctx, e);
+    return MLD_OK;
+}
+
+int mld_get_point_depth_cam_visible(mld_ctx* ctx, int slot, int64_t visible_index, double* depth_out) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    if ((rc = ensure_full(ctx, s))) return rc;
+    if (!depth_out || visible_index < 0 || visible_index >= s.nvis) return fail(ctx, MLD_ERR_INVALID_ARG, "index out of range");
+    int32_t raw = 0;
+    HIP_TRY(ctx, hipMemcpy(&raw, s.pidx + visible_index, sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(depth_out, s.cam + 3 * (size_t)raw + 2, sizeof(double), hipMemcpyDeviceToHost));
+    return MLD_OK;
+}
+
+// ---------------------------------------------------------------------------- timing
+int mld_timing_enable(mld_ctx* ctx, int enable) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    ctx->timing = enable != 0;
+    return MLD_OK;
+}
+
+int mld_timing_reset(mld_ctx* ctx) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (TimedLaunch& t : ctx->timed) {
+        ctx->event_pool.push_back(t.e0);
+        ctx->event_pool.push_back(t.e1);
+    }
+    ctx->timed.clear();
+    return MLD_OK;
+}
+
+int mld_kernel_time_ms(mld_ctx* ctx, int which, double* avg_ms, int64_t* launches) {
+    if (!ctx || !avg_ms) return MLD_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double total = 0;
+    int64_t cnt = 0;
+    for (TimedLaunch& t : ctx->timed) {
+        if (t.which != which) continue;
+        float ms = 0;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, t.e0, t.e1));
+        total += ms;
+        cnt++;
+    }
+    *avg_ms = cnt ? total / (double)cnt : 0.0;
+    if (launches) *launches = cnt;
+    return MLD_OK;
+}
+
+}  // extern "C"

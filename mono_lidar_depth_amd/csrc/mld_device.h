@@ -1,0 +1,60 @@
+// Shared host/device declarations of the MI355X DepthEstimator path (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mld {
+
+constexpr int kWave = 64;
+constexpr uint32_t kIdxBits = 24;               // pixel-map key: [tag:8 | (0xFFFFFF - origIdx):24]
+constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1u;
+constexpr int64_t kMaxPoints = (int64_t)kIdxMask;  // points per cloud representable in a key
+constexpr uint32_t kMaxTag = 255;
+
+// Per-context constants, passed to every kernel by value (kernarg segment -> SGPRs / scalar loads).
+struct Calib {
+    double T[12];     // lidar -> camera, row-major 3x4
+    double Tinv[12];  // camera -> lidar
+    double Kinv[9];   // inverse intrinsics, row-major
+    double f, cu, cv;
+    double halfX1, halfY1;  // main search window half sizes  (scale 1.0, 1.0)
+    double halfX2, halfY2;  // road search window half sizes  (scale 2.0, 1.5)
+    double binW;
+    double thrG_min, thrG_max;
+    double thrL_val;
+    double planarThr, orthThr;
+    double roadDistThr, zxMinRel;
+    double pcaAbsMin, pcaRelMax, pcaRelMin;
+    int W, H;
+    int cap;  // capacity (entries) of the per-wave neighbour list in LDS
+    int minCount;
+    unsigned countMin;
+    int useHist;
+    int thrG_en, thrG_mode;
+    int thrL_en, thrL_mode, thrL_type;
+    int useTriMax, checkPlanar, cutBehind;
+    int useRoad;   // do_use_ransac_plane
+    int roadMode;  // 0 = M-estimator, 1 = max spanning triangle
+    int usePCA;
+};
+
+// Per-frame-slot descriptor (device-resident array, or passed by value for single-slot calls).
+struct SlotDesc {
+    const unsigned char* cloud;   // float32 records, `stride` bytes apart (x,y,z first)
+    uint32_t* map;                // W*H keys
+    const double* uv;             // 2 x F column-major
+    double* depth;                // F
+    int32_t* type;                // F or nullptr
+    const uint32_t* inlier_mask;  // bit i = original point i is a ground-plane inlier; nullptr = no plane
+    long long n;                  // points
+    long long F;                  // features
+    double prior_n[3];            // M-estimator prior (normalised lidar-frame normal, DepthEstimator.cpp:286-292)
+    double prior_off;
+    float coeffs[4];              // plane a,b,c,d (lidar frame)
+    int stride;
+    uint32_t tag;  // current map tag, 1..255
+    int has_plane;
+    int pad_;
+};
+
+}  // namespace mld

@@ -1,0 +1,1021 @@
+// HIP kernels of the DepthEstimator hot path for gfx950 (MI355X, CDNA4, wave64).
+//
+// Compile with -ffp-contract=off: the pixel a LiDAR point falls into depends on int(u), int(v)
+// (NeighborFinderPixel.cpp:41-42), so the projection must round exactly like the CPU path.
+//
+// Kernels
+//   k_project_scatter : Transform_Cloud_LidarToCamera + getImagePoints + InitializeLidarProjection
+//                       (DepthEstimator.cpp:156-217, camera_pinhole.h:84-97, NeighborFinderPixel.cpp:29-58)
+//                       fused: one coalesced pass over the cloud, no intermediate arrays.
+//   k_feature_depth   : the per-feature loop (DepthEstimator.cpp:455-600) for 64 features per wavefront.
+//   k_project_full / k_scan_* / k_export_* : lazy debug getters (visible list, _pointIndex, pixel map).
+//
+// Pixel map encoding.  The reference map holds the VISIBLE index of the first point (in cloud order,
+// with z_cam > 0) that falls into the pixel.  Visible indices preserve cloud order, so "first visible
+// index" == "smallest ORIGINAL index".  The device map stores
+//     key = tag << 24 | (0xFFFFFF - origIdx)         (atomicMax: smallest origIdx of the newest tag wins)
+// where tag is bumped per setInputCloud, which makes clearing the 1.86 MB map unnecessary (a stale key has
+// a smaller tag and loses / is ignored).  The map is zero-filled when the tag wraps (every 255 frames).
+// Neighbours are re-derived from the raw float point at gather time (bit-identical arithmetic), so no
+// camera-frame copy of the cloud is ever written.
+#include "mld_device.h"
+#include "../../include/mld.h"
+
+namespace mld {
+
+// ------------------------------------------------------------------------------------------------
+// wave64 helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int prefix_count(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_min_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+
+// blockIdx -> (slot, block-within-slot).  With a multiple of 8 slots, all blocks of one slot are congruent
+// mod 8, i.e. land on the same XCD under round-robin dispatch: the slot's map and cloud stay in one L2.
+// This is a speed-only mapping; nothing depends on placement.
+__device__ __forceinline__ void decode_block(int b, int n_slots, int per_slot, int& slot, int& j) {
+    if (n_slots >= 8 && (n_slots & 7) == 0) {
+        int x = b & 7, q = b >> 3;
+        int sq = q / per_slot;
+        j = q - sq * per_slot;
+        slot = sq * 8 + x;
+    } else {
+        slot = b / per_slot;
+        j = b - slot * per_slot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3-vector arithmetic with the reference's (Eigen fixed-size) evaluation order
+// ------------------------------------------------------------------------------------------------
+struct V3 {
+    double x, y, z;
+};
+__device__ __forceinline__ V3 vsub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 vadd(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 vscale(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 vdivs(V3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ double vdot(V3 a, V3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ double vsqnorm(V3 a) { return a.x * a.x + (a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ double vnorm(V3 a) { return sqrt(vsqnorm(a)); }
+__device__ __forceinline__ V3 vnormalized(V3 a) {
+    double z = vsqnorm(a);
+    if (z > 0.0) return vdivs(a, sqrt(z));
+    return a;
+}
+__device__ __forceinline__ V3 vcross(V3 a, V3 b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// Raw float point -> camera frame (DepthEstimator.cpp:169,173).
+__device__ __forceinline__ void load_point(const SlotDesc& s, long long i, double& x, double& y, double& z) {
+    const unsigned char* p = s.cloud + (size_t)i * (size_t)s.stride;
+    if ((((size_t)s.cloud) & 15) == 0) {
+        float4 q = *reinterpret_cast<const float4*>(p);
+        x = (double)q.x;
+        y = (double)q.y;
+        z = (double)q.z;
+    } else {
+        const float* q = reinterpret_cast<const float*>(p);
+        x = (double)q[0];
+        y = (double)q[1];
+        z = (double)q[2];
+    }
+}
+__device__ __forceinline__ V3 lidar_to_cam(const Calib& c, double x, double y, double z) {
+    V3 r;
+    r.x = c.T[3] + ((c.T[0] * x + c.T[1] * y) + c.T[2] * z);
+    r.y = c.T[7] + ((c.T[4] * x + c.T[5] * y) + c.T[6] * z);
+    r.z = c.T[11] + ((c.T[8] * x + c.T[9] * y) + c.T[10] * z);
+    return r;
+}
+// camera_pinhole.h:88-90: q = K p with all nine products, hnormalized.
+__device__ __forceinline__ void project(const Calib& c, V3 p, double& u, double& v) {
+    double q0 = (c.f * p.x + 0.0 * p.y) + c.cu * p.z;
+    double q1 = (0.0 * p.x + c.f * p.y) + c.cv * p.z;
+    double q2 = (0.0 * p.x + 0.0 * p.y) + 1.0 * p.z;
+    u = q0 / q2;
+    v = q1 / q2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: projection + pixel-map scatter
+// ------------------------------------------------------------------------------------------------
+constexpr int kProjThreads = 256;
+constexpr int kProjPerThread = 4;
+
+__global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc* __restrict__ slots, SlotDesc single,
+                                                                  int use_single, Calib c, int n_slots, int per_slot) {
+    int slot, j;
+    decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
+    const SlotDesc s = use_single ? single : slots[slot];
+    const long long base = (long long)j * (kProjThreads * kProjPerThread) + threadIdx.x;
+    if (base >= s.n) return;
+    double px[kProjPerThread], py[kProjPerThread], pz[kProjPerThread];
+#pragma unroll
+    for (int r = 0; r < kProjPerThread; r++) {
+        long long i = base + (long long)r * kProjThreads;
+        px[r] = 0;
+        py[r] = 0;
+        pz[r] = 0;
+        if (i < s.n) load_point(s, i, px[r], py[r], pz[r]);
+    }
+    const double Wd = (double)c.W, Hd = (double)c.H;
+#pragma unroll
+    for (int r = 0; r < kProjPerThread; r++) {
+        long long i = base + (long long)r * kProjThreads;
+        if (i >= s.n) continue;
+        V3 pc = lidar_to_cam(c, px[r], py[r], pz[r]);
+        if (!(pc.z > 0.0)) continue;  // NeighborFinderPixel.cpp:51: only z > 0 enters the map
+        double u, v;
+        project(c, pc, u, v);
+        // DepthEstimator.cpp:186-187 strict bounds (imply the inclusive test of camera_pinhole.h:93-95)
+        if ((u > 0.0) && (u < Wd) && (v > 0.0) && (v < Hd)) {
+            int xi = (int)u, yi = (int)v;  // truncation, NeighborFinderPixel.cpp:41-42
+            uint32_t key = (s.tag << kIdxBits) | (kIdxMask - (uint32_t)i);
+            atomicMax(&s.map[(size_t)xi + (size_t)yi * (size_t)c.W], key);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: per-feature depth.  One wavefront per 64 features.
+//   phase 1 (lanes = window cells / neighbours, one feature at a time, wave-uniform control flow):
+//           window scan -> ordered neighbour list in LDS -> histogram segmentation -> max-spanning triangle
+//   phase 2 (lanes = features): planarity, viewing ray, ray/plane intersection, thresholds
+//   phase 3 (lanes = neighbours, only features that fell through): wide window, ground-plane inliers, fit sums
+//   phase 4 (lanes = features): road plane, intersection, thresholds
+// ------------------------------------------------------------------------------------------------
+struct Lists {
+    double* x;
+    double* y;
+    double* z;
+    int* idx;  // original cloud index
+    int* bin;
+};
+
+constexpr int kRecFields = 11;
+
+// Window scan (NeighborFinderPixel.cpp:60-95) + 3-D gather (NeighborFinderBase.cpp:15-27).  Returns the
+// neighbour count (wave-uniform); entries are in the reference's row-major scan order.
+__device__ int gather_window(const Calib& c, const SlotDesc& s, double u, double v, double halfX, double halfY,
+                             const Lists& L, int lane) {
+    if (!(isfinite(u) && isfinite(v))) return 0;  // reference: undefined behaviour (int cast of NaN)
+    double a;
+    a = u - halfX;
+    double left = (a < 0.) ? 0. : a;  // std::max(a, 0.)
+    a = u + halfX;
+    double right = ((double)(c.W - 1) < a) ? (double)(c.W - 1) : a;  // std::min(a, W-1)
+    a = v - halfY;
+    double top = (a < 0.) ? 0. : a;
+    a = v + halfY;
+    double bottom = ((double)(c.H - 1) < a) ? (double)(c.H - 1) : a;
+    int x0 = (int)left, x1 = (int)right, y0 = (int)top, y1 = (int)bottom;
+    x0 = uniform(x0);
+    x1 = uniform(x1);
+    y0 = uniform(y0);
+    y1 = uniform(y1);
+    int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+    if (nx <= 0 || ny <= 0) return 0;
+    if (x0 < 0 || y0 < 0 || x1 >= c.W || y1 >= c.H) return 0;  // unreachable for finite features
+    const int ncell = nx * ny;
+    const float rnx = 1.0f / (float)nx;
+    int k = 0;
+    for (int base = 0; base < ncell; base += kWave) {
+        int cidx = base + lane;
+        bool has = false;
+        int orig = 0;
+        if (cidx < ncell) {
+            int row = (int)(((float)cidx + 0.5f) * rnx);
+            int col = cidx - row * nx;
+            uint32_t key = s.map[(size_t)(x0 + col) + (size_t)(y0 + row) * (size_t)c.W];
+            has = (key >> kIdxBits) == s.tag;
+            orig = (int)(kIdxMask - (key & kIdxMask));
+        }
+        unsigned long long m = __ballot(has);
+        int rank = k + prefix_count(m);
+        if (has && rank < c.cap) {
+            double x, y, z;
+            load_point(s, orig, x, y, z);
+            V3 pc = lidar_to_cam(c, x, y, z);
+            L.x[rank] = pc.x;
+            L.y[rank] = pc.y;
+            L.z[rank] = pc.z;
+            L.idx[rank] = orig;
+        }
+        k += __popcll(m);
+    }
+    k = uniform(k);
+    return k < c.cap ? k : c.cap;
+}
+
+// PointHistogram::FilterPointsMinDistBlob (HistogramPointDepth.cpp:15-123, Histogram.cpp:14-49).
+// Compacts the list in place to the points of the first local-maximum bin.  Returns new count or -1.
+__device__ int hist_segment(const Calib& c, int k, const Lists& L, int lane) {
+    int md = 0;
+    for (int b = 0; b < k; b += kWave) {
+        int i = b + lane;
+        if (i < k) {
+            double d = L.z[i];
+            d = (999. < d) ? 999. : d;  // DepthEstimator.cpp:743
+            int ce = (int)ceil(d);
+            md = max(md, ce);
+        }
+    }
+    md = uniform(wave_max_i32(md));
+    const int binCount = (int)((double)md / c.binW + 1.0);  // HistogramPointDepth.cpp:43
+    if (binCount <= 1) return -1;
+    int bmin = 0x7fffffff;
+    for (int b = 0; b < k; b += kWave) {
+        int i = b + lane;
+        if (i < k) {
+            double d = L.z[i];
+            d = (999. < d) ? 999. : d;
+            double value = (1e10 < d) ? 1e10 : d;  // Histogram.cpp:29
+            double q = fabs(value / c.binW);
+            double lim = (double)binCount - 1.;
+            int bi = (int)((lim < q) ? lim : q);  // Histogram.cpp:30
+            L.bin[i] = bi;
+            bmin = min(bmin, bi);
+        }
+    }
+    bmin = uniform(wave_min_i32(bmin));
+    // HistogramPointDepth.cpp:70-85, started at the first non-empty bin (leading empty bins are no-ops)
+    int binMaxId = -1, binMaxVal = -1, binValue = 0;
+    for (int i = bmin; i < binCount; i++) {
+        int last = binValue;
+        int cnt = 0;
+        for (int b = 0; b < k; b += kWave) {
+            int e = b + lane;
+            cnt += __popcll(__ballot(e < k && L.bin[e] == i));
+        }
+        binValue = uniform(cnt);
+        if ((binValue > binMaxVal) && (binValue >= c.minCount)) {
+            binMaxVal = binValue;
+            binMaxId = i;
+        } else if (binValue < binMaxVal)
+            break;
+        if ((last > 0) && (binValue == 0)) return -1;
+    }
+    if (binMaxId < 0) return -1;
+    const double lower = (double)binMaxId * c.binW - 0.0 * c.binW;   // :99
+    const double higher = (double)binMaxId * c.binW + 1.0 * c.binW;  // :100
+    int kk = 0;
+    for (int b = 0; b < k; b += kWave) {
+        int i = b + lane;
+        bool keep = false;
+        double x = 0, y = 0, z = 0;
+        int id = 0;
+        if (i < k) {
+            z = L.z[i];
+            double d = (999. < z) ? 999. : z;
+            keep = (d >= lower) && (d < higher);
+            x = L.x[i];
+            y = L.y[i];
+            id = L.idx[i];
+        }
+        unsigned long long m = __ballot(keep);
+        int rank = kk + prefix_count(m);
+        if (keep) {
+            L.x[rank] = x;
+            L.y[rank] = y;
+            L.z[rank] = z;
+            L.idx[rank] = id;
+        }
+        kk += __popcll(m);
+    }
+    return uniform(kk);
+}
+
+// PlaneEstimationCalcMaxSpanningTriangle::CalculatePlaneCorners (PlaneEstimationCalcMaxSpanningTriangle.cpp:37-100)
+// with _distTreshold = 0.  Serial tie-breaking is reproduced: strict '>' keeps the FIRST maximal pair in
+// (i,j)-lexicographic order and the first maximal k.
+__device__ bool max_spanning_triangle(int n, const Lists& L, int lane, int& ci, int& cj, int& ck) {
+    if (n < 3) return false;
+    double best = -1.0;
+    int bi = -1, bj = -1;
+    const int total = n * n;
+    const float rn = 1.0f / (float)n;
+    for (int b = 0; b < total; b += kWave) {
+        int id = b + lane;
+        int i = (int)(((float)id + 0.5f) * rn);
+        int j = id - i * n;
+        bool valid = (id < total) && (i < j);
+        double d = -2.0;
+        if (valid) {
+            V3 pi = {L.x[i], L.y[i], L.z[i]}, pj = {L.x[j], L.y[j], L.z[j]};
+            d = vsqnorm(vsub(pi, pj));
+        }
+        double m = wave_max_f64(d);
+        if (m > best) {
+            unsigned long long who = __ballot(valid && d == m);
+            int first = __ffsll((long long)who) - 1;
+            int fid = b + first;
+            best = m;
+            bi = (int)(((float)fid + 0.5f) * rn);
+            bj = fid - bi * n;
+        }
+    }
+    bi = uniform(bi);
+    bj = uniform(bj);
+    if (best <= 0.0) return false;  // :65
+    V3 pa = {L.x[bi], L.y[bi], L.z[bi]}, pb = {L.x[bj], L.y[bj], L.z[bj]};
+    double best2 = -1.0;
+    int bk = -1;
+    for (int b = 0; b < n - 1; b += kWave) {  // :71 last point never considered
+        int kx = b + lane;
+        bool valid = (kx < n - 1) && (kx != bi) && (kx != bj);
+        double d = -2.0;
+        if (valid) {
+            V3 pk = {L.x[kx], L.y[kx], L.z[kx]};
+            double d1 = vsqnorm(vsub(pk, pa));
+            double d2 = vsqnorm(vsub(pk, pb));
+            valid = !(d1 <= 0.0) && !(d2 <= 0.0);
+            if (valid) d = d1 + d2;
+        }
+        double m = wave_max_f64(d);
+        if (m > best2) {
+            unsigned long long who = __ballot(valid && d == m);
+            if (who) {
+                int first = __ffsll((long long)who) - 1;
+                best2 = m;
+                bk = b + first;
+            }
+        }
+    }
+    bk = uniform(bk);
+    if (bi == -1 || bj == -1 || bk == -1) return false;
+    ci = bi;
+    cj = bj;
+    ck = bk;
+    return true;
+}
+
+__device__ __forceinline__ void store_rec(double* rec, int f, int field, double v) { rec[field * kWave + f] = v; }
+__device__ __forceinline__ double load_rec(const double* rec, int f, int field) { return rec[field * kWave + f]; }
+
+// min / max of z over the first n list entries (TresholdDepthLocal.cpp:23-29)
+__device__ void list_minmax_z(int n, const Lists& L, int lane, double& mn, double& mx) {
+    double a = 1.7976931348623157e308, b = -1.7976931348623157e308;
+    for (int base = 0; base < n; base += kWave) {
+        int i = base + lane;
+        if (i < n) {
+            double z = L.z[i];
+            if (z < a) a = z;
+            if (z > b) b = z;
+        }
+    }
+    mn = wave_min_f64(a);
+    mx = wave_max_f64(b);
+}
+
+// Cyclic Jacobi eigen-decomposition of a symmetric 3x3 (a[0..5] = xx,xy,xz,yy,yz,zz).  Returns the
+// eigenvalues ascending in ev[] and the eigenvector of the smallest in n0.
+__device__ void jacobi_eig3(const double s[6], double ev[3], V3& n0) {
+    double a[3][3] = {{s[0], s[1], s[2]}, {s[1], s[3], s[4]}, {s[2], s[4], s[5]}};
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (!(off > 1e-300) || off <= 1e-32 * diag) break;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int q = p + 1; q < 3; q++) {
+                double apq = a[p][q];
+                if (apq == 0.0) continue;
+                double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = cs * akp - sn * akq;
+                    a[k][q] = sn * akp + cs * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = cs * apk - sn * aqk;
+                    a[q][k] = sn * apk + cs * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = cs * vkp - sn * vkq;
+                    v[k][q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    double d0 = a[0][0], d1 = a[1][1], d2 = a[2][2];
+    // stable ascending order of (d0,d1,d2) by index (matches std::sort on distinct values)
+    int i0 = 0, i1 = 1, i2 = 2;
+    if (d1 < d0) {
+        double t = d0;
+        d0 = d1;
+        d1 = t;
+        int ti = i0;
+        i0 = i1;
+        i1 = ti;
+    }
+    if (d2 < d1) {
+        double t = d1;
+        d1 = d2;
+        d2 = t;
+        int ti = i1;
+        i1 = i2;
+        i2 = ti;
+        if (d1 < d0) {
+            t = d0;
+            d0 = d1;
+            d1 = t;
+            ti = i0;
+            i0 = i1;
+            i1 = ti;
+        }
+    }
+    ev[0] = d0;
+    ev[1] = d1;
+    ev[2] = d2;
+    n0.x = (i0 == 0) ? v[0][0] : ((i0 == 1) ? v[0][1] : v[0][2]);
+    n0.y = (i0 == 0) ? v[1][0] : ((i0 == 1) ? v[1][1] : v[1][2]);
+    n0.z = (i0 == 0) ? v[2][0] : ((i0 == 1) ? v[2][1] : v[2][2]);
+}
+
+struct Plane {
+    V3 n;
+    double offset;
+};
+
+// Eigen::Hyperplane<double,3>::Through (call site LinePlaneIntersectionBase.cpp:41).
+__device__ Plane plane_through(V3 p0, V3 p1, V3 p2) {
+    V3 v0 = vsub(p2, p0), v1 = vsub(p1, p0);
+    V3 n = vcross(v0, v1);
+    double nn = vnorm(n);
+    Plane r;
+    if (nn <= vnorm(v0) * vnorm(v1) * 2.220446049250313e-16) {
+        // degenerate triangle: smallest eigenvector of m^T m, m = [v0^T; v1^T]
+        double s[6] = {v0.x * v0.x + v1.x * v1.x, v0.x * v0.y + v1.x * v1.y, v0.x * v0.z + v1.x * v1.z,
+                       v0.y * v0.y + v1.y * v1.y, v0.y * v0.z + v1.y * v1.z, v0.z * v0.z + v1.z * v1.z};
+        double ev[3];
+        jacobi_eig3(s, ev, r.n);
+    } else {
+        r.n = vdivs(n, nn);
+    }
+    r.offset = -vdot(p0, r.n);
+    return r;
+}
+
+// CameraPinhole::getViewingRays (camera_pinhole.h:52-69) + flip (DepthEstimator.cpp:938-939)
+__device__ V3 viewing_ray(const Calib& c, double u, double v) {
+    V3 d = {(c.Kinv[0] * u + c.Kinv[1] * v) + c.Kinv[2], (c.Kinv[3] * u + c.Kinv[4] * v) + c.Kinv[5],
+            (c.Kinv[6] * u + c.Kinv[7] * v) + c.Kinv[8]};
+    d = vnormalized(d);
+    if (d.z < 0) d = vscale(d, -1.0);
+    return d;
+}
+
+// LinePlaneIntersection{OrthogonalTreshold,Normal}::GetIntersection
+__device__ bool intersect(const Calib& c, bool orth, Plane pl, V3 n0, V3 n1, double& depth) {
+    if (orth) {
+        V3 ln = vnormalized(n1), pn = vnormalized(pl.n);
+        if (!(fabs(vdot(pn, ln)) >= c.orthThr)) return false;
+    }
+    V3 dir = vnormalized(vsub(n1, n0));  // ParametrizedLine::Through(n0, n1)
+    double t = -(pl.offset + vdot(pl.n, n0)) / vdot(pl.n, dir);
+    V3 p = vadd(n0, vscale(dir, t));
+    depth = p.z;
+    return true;
+}
+
+// TresholdDepthGlobal::CheckInDepth / TresholdDepthLocal::CheckInBounds, then the caller's mapping to
+// result types.  Returns 0 when in bounds (depth possibly adjusted) or the failing result type.
+__device__ int apply_thresholds(const Calib& c, double minZ, double maxZ, double& depth) {
+    if (c.thrG_en) {
+        if (depth < c.thrG_min) {
+            if (c.thrG_mode == 0) return MLD_TresholdDepthGlobalSmallerMin;
+            depth = c.thrG_min;
+        } else if (depth > c.thrG_max) {
+            if (c.thrG_mode == 0) return MLD_TresholdDepthGlobalGreaterMax;
+            depth = c.thrG_max;
+        }
+    }
+    if (c.thrL_en) {
+        double interval = maxZ - minZ, lo, hi;
+        if (c.thrL_type == 1) {
+            double r = interval * c.thrL_val;
+            lo = minZ - r;
+            hi = maxZ + r;
+        } else {
+            lo = minZ - c.thrL_val;
+            hi = maxZ + c.thrL_val;
+        }
+        if (depth < lo) {
+            if (c.thrL_mode == 0) return MLD_TresholdDepthLocalSmallerMin;
+            depth = lo;
+        } else if (depth > hi) {
+            if (c.thrL_mode == 0) return MLD_TresholdDepthLocalGreaterMax;
+            depth = hi;
+        }
+    }
+    return 0;
+}
+
+// Weighted / unweighted first and second moments over the first n list entries whose flag is set
+// (flag == nullptr: all).  Used by the M-estimator (weights 1/|prior distance|) and PCA (weights 1).
+// Tree reductions across lanes: the summation ORDER differs from the serial CPU loops (results agree to
+// rounding; parity tolerance for these paths is 1e-4 m, not bit-exact).
+__device__ void moments(int n, const Lists& L, int lane, bool weighted, const SlotDesc& s, double center[3],
+                        double cov[6], bool divide_by_n) {
+    double sw = 0, sx = 0, sy = 0, sz = 0;
+    for (int b = 0; b < n; b += kWave) {
+        int i = b + lane;
+        if (i < n) {
+            V3 p = {L.x[i], L.y[i], L.z[i]};
+            double w = 1.0;
+            if (weighted) {
+                V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
+                w = 1 / fabs(vdot(pn, p) + s.prior_off);  // PlaneEstimationMEstimator.cpp:32
+            }
+            sw += w;
+            sx += w * p.x;
+            sy += w * p.y;
+            sz += w * p.z;
+        }
+    }
+    sw = wave_sum_f64(sw);
+    sx = wave_sum_f64(sx);
+    sy = wave_sum_f64(sy);
+    sz = wave_sum_f64(sz);
+    double den = divide_by_n ? (double)n : sw;
+    double cx = sx / den, cy = sy / den, cz = sz / den;
+    double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+    for (int b = 0; b < n; b += kWave) {
+        int i = b + lane;
+        if (i < n) {
+            V3 p = {L.x[i], L.y[i], L.z[i]};
+            double w = 1.0;
+            if (weighted) {
+                V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
+                w = 1 / fabs(vdot(pn, p) + s.prior_off);
+            }
+            double dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
+            c0 += w * dx * dx;
+            c1 += w * dx * dy;
+            c2 += w * dx * dz;
+            c3 += w * dy * dy;
+            c4 += w * dy * dz;
+            c5 += w * dz * dz;
+        }
+    }
+    center[0] = cx;
+    center[1] = cy;
+    center[2] = cz;
+    cov[0] = wave_sum_f64(c0);
+    cov[1] = wave_sum_f64(c1);
+    cov[2] = wave_sum_f64(c2);
+    cov[3] = wave_sum_f64(c3);
+    cov[4] = wave_sum_f64(c4);
+    cov[5] = wave_sum_f64(c5);
+}
+
+enum : int {
+    ST_FINAL = 0,       // mytype/mydepth are final
+    ST_TRIANGLE = 1,    // record = 3 corners + minZ,maxZ           -> phase 2
+    ST_PCA = 2,         // record = mean, cov, minZ,maxZ            -> phase 2
+    ST_ROAD_MEST = 3,   // record = centre, cov, minZ,maxZ          -> phase 4
+    ST_ROAD_TRI = 4     // record = 3 corners + minZ,maxZ           -> phase 4
+};
+
+__global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restrict__ slots, SlotDesc single,
+                                                         int use_single, Calib c, int n_slots, int per_slot) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int slot, j;
+    decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
+    const SlotDesc s = use_single ? single : slots[slot];
+    const long long f0 = (long long)j * kWave;
+    if (f0 >= s.F) return;
+    const int lane = threadIdx.x;
+    const int nf = (int)((s.F - f0) < (long long)kWave ? (s.F - f0) : (long long)kWave);
+
+    Lists L;
+    L.x = reinterpret_cast<double*>(smem);
+    L.y = L.x + c.cap;
+    L.z = L.y + c.cap;
+    L.idx = reinterpret_cast<int*>(L.z + c.cap);
+    L.bin = L.idx + c.cap;
+    double* rec = reinterpret_cast<double*>(L.bin + c.cap);
+
+    double myu = 0, myv = 0;
+    if (lane < nf) {
+        const double* q = s.uv + 2 * (f0 + lane);
+        myu = q[0];
+        myv = q[1];
+    }
+    int mystate = ST_FINAL;
+    int mytype = MLD_Unspecified;
+    double mydepth = -1.0;
+
+    // ---------------- phase 1 ----------------
+    for (int fi = 0; fi < nf; fi++) {
+        const double u = readlane_f64(myu, fi), v = readlane_f64(myv, fi);
+        int state = ST_FINAL, type = MLD_Unspecified;
+        int k = gather_window(c, s, u, v, c.halfX1, c.halfY1, L, lane);
+        if ((unsigned)k < c.countMin) {  // DepthEstimator.cpp:680
+            type = MLD_RadiusSearchInsufficientPoints;
+        } else {
+            int ks = k;
+            if (c.useHist) ks = hist_segment(c, k, L, lane);  // DepthEstimator.cpp:726-780
+            if (ks < 0) {
+                type = MLD_HistogramNoLocalMax;
+            } else {
+                // CalculateDepthSegmented, corner selection (DepthEstimator.cpp:915-926)
+                int ci = 0, cj = 1, ck = 2;
+                bool ok = true;
+                if (!c.usePCA && c.useTriMax) {
+                    ok = max_spanning_triangle(ks, L, lane, ci, cj, ck);
+                    if (!ok) type = MLD_TriangleNotPlanarInsufficientPoints;
+                } else if (ks < 3) {
+                    ok = false;
+                    type = MLD_HistogramNoLocalMax;
+                }
+                if (ok) {
+                    double mn, mx;
+                    list_minmax_z(ks, L, lane, mn, mx);
+                    if (c.usePCA) {
+                        double ctr[3], cov[6];
+                        moments(ks, L, lane, false, s, ctr, cov, true);
+                        if (lane == 0) {
+                            for (int t = 0; t < 3; t++) store_rec(rec, fi, t, ctr[t]);
+                            for (int t = 0; t < 6; t++) store_rec(rec, fi, 3 + t, cov[t]);
+                        }
+                        state = ST_PCA;
+                    } else {
+                        if (lane == 0) {
+                            store_rec(rec, fi, 0, L.x[ci]);
+                            store_rec(rec, fi, 1, L.y[ci]);
+                            store_rec(rec, fi, 2, L.z[ci]);
+                            store_rec(rec, fi, 3, L.x[cj]);
+                            store_rec(rec, fi, 4, L.y[cj]);
+                            store_rec(rec, fi, 5, L.z[cj]);
+                            store_rec(rec, fi, 6, L.x[ck]);
+                            store_rec(rec, fi, 7, L.y[ck]);
+                            store_rec(rec, fi, 8, L.z[ck]);
+                        }
+                        state = ST_TRIANGLE;
+                    }
+                    if (lane == 0) {
+                        store_rec(rec, fi, 9, mn);
+                        store_rec(rec, fi, 10, mx);
+                    }
+                }
+            }
+        }
+        if (lane == fi) {
+            mystate = state;
+            mytype = type;
+        }
+    }
+
+    // ---------------- phase 2 (lane = feature) ----------------
+    const bool orth = c.orthThr > 0;  // DepthEstimator.cpp:77-81
+    if (mystate == ST_TRIANGLE || mystate == ST_PCA) {
+        double r[kRecFields];
+#pragma unroll
+        for (int t = 0; t < kRecFields; t++) r[t] = load_rec(rec, lane, t);
+        int type = MLD_Success;
+        double depth = -1.0;
+        V3 dir = viewing_ray(c, myu, myv);
+        V3 support = {0, 0, 0};
+        if (mystate == ST_TRIANGLE) {
+            V3 c1 = {r[0], r[1], r[2]}, c2 = {r[3], r[4], r[5]}, c3 = {r[6], r[7], r[8]};
+            if (c.checkPlanar) {  // PlaneEstimationCheckPlanar.cpp:18-44
+                V3 e1 = vnormalized(vsub(c2, c1)), e2 = vnormalized(vsub(c3, c1)), e3 = vnormalized(vsub(c3, c2));
+                double l12 = vnorm(vcross(e1, e2)), l13 = vnorm(vcross(e1, e3)), l23 = vnorm(vcross(e2, e3));
+                if (!((l12 >= c.planarThr) && (l13 >= c.planarThr) && (l23 >= c.planarThr)))
+                    type = MLD_TriangleNotPlanar;
+            }
+            if (type == MLD_Success) {
+                Plane pl = plane_through(c1, c2, c3);
+                if (!intersect(c, orth, pl, support, dir, depth)) type = MLD_PlaneViewrayNotOrthogonal;
+            }
+        } else {
+            // Mono_LidarPipeline::PCA (PCA.cpp:11-62)
+            double ev[3];
+            V3 n0;
+            jacobi_eig3(&r[3], ev, n0);
+            n0 = vdivs(n0, vnorm(n0));
+            float planarity = (float)((ev[1] - ev[0]) / ev[2]);
+            float linearity = (float)((ev[2] - ev[1]) / ev[2]);
+            if ((double)planarity < c.pcaRelMin)
+                type = MLD_PcaIsCubic;
+            else if ((double)linearity > c.pcaRelMax)
+                type = MLD_PcaIsLine;
+            else if (ev[2] < c.pcaAbsMin)
+                type = MLD_PcaIsPoint;
+            if (type == MLD_Success) {
+                V3 mean = {r[0], r[1], r[2]};
+                Plane pl = {n0, -vdot(n0, mean)};
+                if (!intersect(c, orth, pl, support, dir, depth)) type = MLD_PlaneViewrayNotOrthogonal;
+            }
+        }
+        if (type == MLD_Success) {
+            int t = apply_thresholds(c, r[9], r[10], depth);
+            if (t) type = t;
+        }
+        if (type == MLD_Success && depth < 0 && c.cutBehind) type = MLD_CornerBehindCamera;
+        mytype = type;
+        mydepth = (type == MLD_Success) ? depth : -1.0;
+        mystate = ST_FINAL;
+    }
+
+    // ---------------- phase 3: road fallback (DepthEstimator.cpp:578-597) ----------------
+    // Candidates: everything that is not Success and did not already return at :509-510.
+    const bool road_on = c.useRoad && s.has_plane;
+    bool cand = road_on && (lane < nf) && (mytype != MLD_Success) && (mytype != MLD_RadiusSearchInsufficientPoints);
+    unsigned long long cm = __ballot(cand);
+    while (cm) {
+        const int fi = __ffsll((long long)cm) - 1;
+        cm &= cm - 1;
+        const double u = readlane_f64(myu, fi), v = readlane_f64(myv, fi);
+        const int resultOld = __builtin_amdgcn_readlane(mytype, fi);
+        int state = ST_FINAL, type = resultOld;
+        int k = gather_window(c, s, u, v, c.halfX2, c.halfY2, L, lane);  // :585 scale 2.0, 1.5
+        if ((unsigned)k < c.countMin) {
+            type = MLD_RadiusSearchInsufficientPoints;
+        } else {
+            // CalculateDepthSegmentationPlane (DepthEstimator.cpp:782-900)
+            bool anyFar = false;
+            int kk = 0;
+            for (int b = 0; b < k; b += kWave) {
+                int i = b + lane;
+                bool far = false, inl = false;
+                double x = 0, y = 0, z = 0;
+                int id = 0;
+                if (i < k) {
+                    x = L.x[i];
+                    y = L.y[i];
+                    z = L.z[i];
+                    id = L.idx[i];
+                    // :810 T_lidar_cam * p (fixed-size product order), :811 float, :812 float plane distance
+                    double xl = c.Tinv[3] + (c.Tinv[0] * x + (c.Tinv[1] * y + c.Tinv[2] * z));
+                    double yl = c.Tinv[7] + (c.Tinv[4] * x + (c.Tinv[5] * y + c.Tinv[6] * z));
+                    double zl = c.Tinv[11] + (c.Tinv[8] * x + (c.Tinv[9] * y + c.Tinv[10] * z));
+                    float xf = (float)xl, yf = (float)yl, zf = (float)zl;
+                    float d = fabsf(s.coeffs[0] * xf + s.coeffs[1] * yf + s.coeffs[2] * zf + s.coeffs[3]);
+                    far = (double)d > c.roadDistThr;
+                    inl = (s.inlier_mask[id >> 5] >> (id & 31)) & 1u;
+                }
+                anyFar = anyFar || (__ballot(far) != 0ull);
+                unsigned long long m = __ballot(inl);
+                int rank = kk + prefix_count(m);
+                if (inl) {
+                    L.x[rank] = x;
+                    L.y[rank] = y;
+                    L.z[rank] = z;
+                    L.idx[rank] = id;
+                }
+                kk += __popcll(m);
+            }
+            kk = uniform(kk);
+            if (anyFar || kk < 3) {
+                type = resultOld;  // :591
+            } else {
+                double mn, mx;
+                list_minmax_z(kk, L, lane, mn, mx);
+                if (c.roadMode == 0) {
+                    double ctr[3], cov[6];
+                    moments(kk, L, lane, true, s, ctr, cov, false);
+                    if (lane == 0) {
+                        for (int t = 0; t < 3; t++) store_rec(rec, fi, t, ctr[t]);
+                        for (int t = 0; t < 6; t++) store_rec(rec, fi, 3 + t, cov[t]);
+                    }
+                    state = ST_ROAD_MEST;
+                } else {
+                    // RoadDepthEstimatorMaxSpanningTriangle::CalculateDepth (:24-75)
+                    int ci, cj, ck;
+                    if (!max_spanning_triangle(kk, L, lane, ci, cj, ck)) {
+                        type = MLD_RadiusSearchInsufficientPoints;
+                    } else {
+                        // LinePlaneIntersectionCeckXZTreshold::Check
+                        double ax = 1.7976931348623157e308, bx = -1.7976931348623157e308;
+                        for (int b = 0; b < kk; b += kWave) {
+                            int i = b + lane;
+                            if (i < kk) {
+                                double x = L.x[i];
+                                if (x < ax) ax = x;
+                                if (x > bx) bx = x;
+                            }
+                        }
+                        ax = wave_min_f64(ax);
+                        bx = wave_max_f64(bx);
+                        double relation = (mx - mn) / (bx - ax);
+                        if (!(relation >= c.zxMinRel)) {
+                            type = MLD_InsufficientRoadPoints;
+                        } else {
+                            if (lane == 0) {
+                                store_rec(rec, fi, 0, L.x[ci]);
+                                store_rec(rec, fi, 1, L.y[ci]);
+                                store_rec(rec, fi, 2, L.z[ci]);
+                                store_rec(rec, fi, 3, L.x[cj]);
+                                store_rec(rec, fi, 4, L.y[cj]);
+                                store_rec(rec, fi, 5, L.z[cj]);
+                                store_rec(rec, fi, 6, L.x[ck]);
+                                store_rec(rec, fi, 7, L.y[ck]);
+                                store_rec(rec, fi, 8, L.z[ck]);
+                            }
+                            state = ST_ROAD_TRI;
+                        }
+                    }
+                }
+                if (state != ST_FINAL && lane == 0) {
+                    store_rec(rec, fi, 9, mn);
+                    store_rec(rec, fi, 10, mx);
+                }
+            }
+        }
+        if (lane == fi) {
+            mystate = state;
+            mytype = type;
+            mydepth = -1.0;
+        }
+    }
+
+    // ---------------- phase 4 (lane = feature) ----------------
+    if (mystate == ST_ROAD_MEST || mystate == ST_ROAD_TRI) {
+        double r[kRecFields];
+#pragma unroll
+        for (int t = 0; t < kRecFields; t++) r[t] = load_rec(rec, lane, t);
+        V3 dir = viewing_ray(c, myu, myv);
+        V3 support = {0, 0, 0};
+        Plane pl;
+        if (mystate == ST_ROAD_MEST) {
+            // PlaneEstimationMEstimator::EstimatePlane (:18-55): direction of least weighted variance
+            V3 center = {r[0], r[1], r[2]};
+            double ev[3];
+            V3 n0;
+            jacobi_eig3(&r[3], ev, n0);
+            if (isnan(center.x) || isnan(center.y) || isnan(center.z)) {
+                double qn = __builtin_nan("");
+                n0 = {qn, qn, qn};
+            }
+            n0 = vnormalized(n0);
+            pl.n = n0;
+            pl.offset = -vdot(n0, center);
+        } else {
+            pl = plane_through({r[0], r[1], r[2]}, {r[3], r[4], r[5]}, {r[6], r[7], r[8]});
+        }
+        double depth = -1.0;
+        intersect(c, false, pl, dir, support, depth);  // n0 = direction, n1 = support (swapped, as the reference)
+        int type = MLD_SuccessRoad;
+        int t = apply_thresholds(c, r[9], r[10], depth);
+        if (t) type = t;
+        mytype = type;
+        mydepth = (type == MLD_SuccessRoad) ? depth : -1.0;
+    }
+
+    if (lane < nf) {
+        s.depth[f0 + lane] = mydepth;
+        if (s.type) s.type[f0 + lane] = mytype;
+    }
+}
+
+// set_all_depths_to_zero short-circuit (DepthEstimator.cpp:448-453)
+__global__ void k_fill_zero(double* depth, int32_t* type, long long F) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < F) {
+        depth[i] = -1.0;
+        if (type) type[i] = 1;
+    }
+}
+
+// Inlier index list -> bitmask keyed by original cloud index (replaces std::map<int,bool>, RansacPlane.h:116-122)
+__global__ void k_build_mask(const int32_t* __restrict__ idx, long long n_inl, long long n_points, uint32_t* mask) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_inl) {
+        int id = idx[i];
+        if (id >= 0 && (long long)id < n_points) atomicOr(&mask[id >> 5], 1u << (id & 31));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lazy debug getters: full PointcloudData (PointcloudData.h:13-68)
+// ------------------------------------------------------------------------------------------------
+// cam: 3 x N col-major, img: 2 x N, vis: N flags (in range && strict bounds)
+__global__ void k_project_full(SlotDesc s, Calib c, double* cam, double* img, int32_t* vis) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.n) return;
+    double x, y, z;
+    load_point(s, i, x, y, z);
+    V3 pc = lidar_to_cam(c, x, y, z);
+    double u, v;
+    project(c, pc, u, v);
+    cam[3 * i] = pc.x;
+    cam[3 * i + 1] = pc.y;
+    cam[3 * i + 2] = pc.z;
+    img[2 * i] = u;
+    img[2 * i + 1] = v;
+    const double Wd = (double)c.W, Hd = (double)c.H;
+    bool inr = (u >= 0.) && (u <= Wd) && (v >= 0.) && (v <= Hd);
+    bool strict = (u > 0.) && (u < Wd) && (v > 0.) && (v < Hd);
+    vis[i] = (inr && strict) ? 1 : 0;
+}
+
+constexpr int kScanBlock = 1024;
+
+// Exclusive scan of vis[] in three steps (block sums, scan of block sums by one block, final ranks).
+__global__ __launch_bounds__(kScanBlock) void k_scan_block_sums(const int32_t* __restrict__ vis, long long n,
+                                                               int32_t* block_sums) {
+    __shared__ int wsum[kScanBlock / kWave];
+    long long i = (long long)blockIdx.x * kScanBlock + threadIdx.x;
+    int v = (i < n) ? vis[i] : 0;
+    int cnt = __popcll(__ballot(v != 0));
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[threadIdx.x / kWave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < kScanBlock / kWave; w++) t += wsum[w];
+        block_sums[blockIdx.x] = t;
+    }
+}
+__global__ void k_scan_sums(int32_t* block_sums, int n_blocks, int32_t* total) {
+    // one thread: n_blocks <= 16384 for 16.7 M points; debug path only
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int acc = 0;
+        for (int b = 0; b < n_blocks; b++) {
+            int t = block_sums[b];
+            block_sums[b] = acc;
+            acc += t;
+        }
+        *total = acc;
+    }
+}
+// rank[i] = visible index of point i (valid where vis[i]); also emits the compacted lists.
+__global__ __launch_bounds__(kScanBlock) void k_scan_final(const int32_t* __restrict__ vis, long long n,
+                                                          const int32_t* __restrict__ block_off,
+                                                          const double* __restrict__ img, int32_t* rank,
+                                                          int32_t* point_index, double* img_vis) {
+    __shared__ int wsum[kScanBlock / kWave];
+    long long i = (long long)blockIdx.x * kScanBlock + threadIdx.x;
+    int v = (i < n) ? vis[i] : 0;
+    unsigned long long m = __ballot(v != 0);
+    int within = prefix_count(m);
+    int w = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[w] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < w; q++) woff += wsum[q];
+    int r = block_off[blockIdx.x] + woff + within;
+    if (i < n) {
+        rank[i] = v ? r : -1;
+        if (v) {
+            point_index[r] = (int32_t)i;
+            img_vis[2 * (long long)r] = img[2 * i];
+            img_vis[2 * (long long)r + 1] = img[2 * i + 1];
+        }
+    }
+}
+// Reference-format pixel map: visible index of the winning point, or -1.
+__global__ void k_export_map(const uint32_t* __restrict__ map, uint32_t tag, const int32_t* __restrict__ rank,
+                             long long cells, int32_t* out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    uint32_t key = map[i];
+    int32_t r = -1;
+    if ((key >> kIdxBits) == tag) r = rank[kIdxMask - (key & kIdxMask)];
+    out[i] = r;
+}
+
+}  // namespace mld

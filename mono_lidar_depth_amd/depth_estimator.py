@@ -1,0 +1,362 @@
+"""Python mirror of the reference's DepthEstimator interface over the C-ABI.
+
+Same method names, argument meaning and error behaviour as `Mono_Lidar::DepthEstimator`
+(monolidar_fusion/include/monolidar_fusion/DepthEstimator.h:39-359) so that the parity tests read like
+the reference's own call sites (tracklets_depth/src/tracklet_depth_module.cpp:80,115,401,413).  numpy arrays
+take the host-pointer entry points; torch CUDA tensors take the zero-copy device entry points.  All compute
+runs in libmld_hip.so on the GPU; nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from .capi import MldCamera, MldParams
+
+
+class DepthEstimatorError(RuntimeError):
+    """Counterpart of the reference's `throw "..."` usage errors; `.code` holds the mld_status."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+class ExceptionPclInvalid(DepthEstimatorError):
+    """GroundPlane::ExceptionPclInvalid (RansacPlane.h:46-50)."""
+
+
+class CameraPinhole:
+    """CameraPinhole(width, height, f, cu, cv) — camera_pinhole.h:29-34."""
+
+    def __init__(self, width: int, height: int, focal_length: float, principal_point_x: float,
+                 principal_point_y: float):
+        self.width, self.height = int(width), int(height)
+        self.focal_length = float(focal_length)
+        self.principal_point_x = float(principal_point_x)
+        self.principal_point_y = float(principal_point_y)
+
+    def getImageSize(self):
+        return self.width, self.height
+
+    def as_struct(self) -> MldCamera:
+        return MldCamera(self.focal_length, self.principal_point_x, self.principal_point_y, self.width, self.height)
+
+
+class GroundPlane:
+    """The GroundPlane object the path consumes (RansacPlane.h:38-123): coefficients + inlier index set.
+
+    In this build the plane is an INPUT: `coeffs` a,b,c,d in the lidar frame, `inliers` the
+    original-cloud indices that `CheckPointInPlane` would accept.
+    """
+
+    def __init__(self, coeffs: Sequence[float], inliers):
+        self.coeffs = np.asarray(coeffs, dtype=np.float32).reshape(4)
+        self.inliers = inliers  # numpy int32 array or torch cuda int32 tensor
+        self._segmented = True
+
+    def isSegmented(self) -> bool:
+        return self._segmented
+
+    def getModelCoeffs(self):
+        return self.coeffs
+
+    def getInlinersIndex(self):
+        return self.inliers
+
+
+def _is_torch_cuda(x) -> bool:
+    return hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+class DepthEstimator:
+    """Drop-in mirror of Mono_Lidar::DepthEstimator for one GPU stream.
+
+    `max_frames` > 1 exposes the frame slots of the C-ABI: `setInputClouds` / `CalculateDepths` process many
+    independent frames per launch (frames of a sequence or a micro-batch of sequences).
+    """
+
+    def __init__(self, device: int = 0, max_frames: int = 1, max_points: int = 0, max_features: int = 0):
+        self._lib = capi.load()
+        self._device = int(device)
+        self._max_frames = int(max_frames)
+        self._max_points = int(max_points)
+        self._max_features = int(max_features)
+        self._parameters: Optional[MldParams] = None
+        self._camera: Optional[CameraPinhole] = None
+        self._T = None
+        self._ctx = None
+        self._isInitializedConfig = False
+        self._isInitialized = False
+        self._keepalive = {}
+
+    # ------------------------------------------------------------------ lifecycle
+    def InitConfig(self, parameters=None, printparams: bool = False) -> bool:
+        """InitConfig(path | parameters) — DepthEstimator.cpp:129-154."""
+        if parameters is None:
+            self._parameters = capi.params_default()
+        elif isinstance(parameters, (str, bytes)) or hasattr(parameters, "__fspath__"):
+            self._parameters = capi.params_from_file(str(parameters))
+        else:
+            self._parameters = parameters.copy()
+        if printparams:
+            for name, _ in MldParams._fields_:
+                print(f"{name}: {getattr(self._parameters, name)}")
+        self._isInitializedConfig = True
+        return True
+
+    def Initialize(self, camera: CameraPinhole, transform_lidar_to_cam) -> bool:
+        """Initialize(camera, T_cam_lidar) — DepthEstimator.cpp:35-127.  T: 4x4 or 3x4 (lidar -> camera)."""
+        if not self._isInitializedConfig:
+            raise DepthEstimatorError(capi.MLD_ERR_NOT_INITIALIZED, "Call 'InitConfig' before calling 'Initialize'.")
+        T = np.asarray(transform_lidar_to_cam, dtype=np.float64)
+        if T.shape == (4, 4):
+            T = T[:3, :]
+        if T.shape != (3, 4):
+            raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "transform must be 3x4 or 4x4")
+        self._T = np.ascontiguousarray(T)
+        self._camera = camera
+        if self._ctx is not None:
+            self._lib.mld_destroy(self._ctx)
+            self._ctx = None
+        status = C.c_int(0)
+        cam = camera.as_struct()
+        ctx = self._lib.mld_create(C.byref(self._parameters), C.byref(cam),
+                                   self._T.ctypes.data_as(C.POINTER(C.c_double)), self._device, self._max_frames,
+                                   self._max_points, self._max_features, C.byref(status))
+        if not ctx:
+            raise DepthEstimatorError(status.value, self._lib.mld_create_error().decode())
+        self._ctx = C.c_void_p(ctx)
+        self._isInitialized = True
+        return True
+
+    def close(self):
+        if self._ctx is not None:
+            self._lib.mld_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != capi.MLD_OK:
+            msg = self._lib.mld_last_error(self._ctx).decode() if self._ctx else "no context"
+            if rc == capi.MLD_ERR_CLOUD_TOO_SMALL:
+                raise ExceptionPclInvalid(rc, "In GroundPlane: Input pointcloud is invalid")
+            raise DepthEstimatorError(rc, msg)
+
+    def _require_init(self, what: str):
+        if not self._isInitialized:
+            raise DepthEstimatorError(capi.MLD_ERR_NOT_INITIALIZED, f"call of '{what}' without 'initialize'")
+
+    # ------------------------------------------------------------------ getters (DepthEstimator.h:98-122)
+    def getParameters(self) -> MldParams:
+        return self._parameters
+
+    def getCamera(self) -> CameraPinhole:
+        return self._camera
+
+    def getTransformLidarToCam(self):
+        return self._T.copy()
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.mld_get_stream(self._ctx) or 0)
+
+    def synchronize(self):
+        self._check(self._lib.mld_synchronize(self._ctx))
+
+    # ------------------------------------------------------------------ setInputCloud
+    @staticmethod
+    def _cloud_view(cloud):
+        """(pointer, n, stride, keepalive) of an [N,4] (packed xyzi) or [N,8] (pcl::PointXYZI) float32 cloud."""
+        if _is_torch_cuda(cloud):
+            import torch
+            if cloud.dtype != torch.float32 or cloud.dim() != 2 or cloud.shape[1] not in (4, 8) or not cloud.is_contiguous():
+                raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "cloud must be contiguous float32 [N,4] or [N,8]")
+            return cloud.data_ptr(), int(cloud.shape[0]), int(cloud.shape[1]) * 4, cloud
+        arr = np.ascontiguousarray(cloud, dtype=np.float32)
+        if arr.ndim != 2 or arr.shape[1] not in (4, 8):
+            raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "cloud must be float32 [N,4] or [N,8]")
+        return arr.ctypes.data, int(arr.shape[0]), int(arr.shape[1]) * 4, arr
+
+    def setInputCloud(self, cloud, groundPlane: Optional[GroundPlane] = None, slot: int = 0,
+                      plane_given: bool = True):
+        """setInputCloud(cloud, groundPlane) — DepthEstimator.cpp:220-312.
+
+        `groundPlane=None` with `plane_given=True` means "ransacPlane == nullptr" (road fallback skipped).
+        """
+        self._require_init("setInputCloud")
+        ptr, n, stride, keep = self._cloud_view(cloud)
+        self._keepalive[("cloud", slot)] = keep
+        if _is_torch_cuda(cloud):
+            self._check(self._lib.mld_set_cloud_device(self._ctx, slot, ptr, n, stride))
+        else:
+            self._check(self._lib.mld_set_cloud(self._ctx, slot, ptr, n, stride))
+        if plane_given:
+            self.setGroundPlane(groundPlane, slot)
+
+    def setGroundPlane(self, groundPlane: Optional[GroundPlane], slot: int = 0):
+        """The ground-plane hook of setInputCloud (DepthEstimator.cpp:273-292) with the plane as input."""
+        if groundPlane is None:
+            self._check(self._lib.mld_set_ground_plane(self._ctx, slot, None, None, 0))
+            return
+        coeffs = (C.c_float * 4)(*[float(x) for x in groundPlane.coeffs])
+        inl = groundPlane.inliers
+        if _is_torch_cuda(inl):
+            import torch
+            if inl.dtype != torch.int32 or not inl.is_contiguous():
+                raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "inliers must be contiguous int32")
+            self._keepalive[("inl", slot)] = inl
+            self._check(self._lib.mld_set_ground_plane_device(self._ctx, slot, coeffs, inl.data_ptr(), int(inl.numel())))
+        else:
+            arr = np.ascontiguousarray(inl, dtype=np.int32)
+            self._check(self._lib.mld_set_ground_plane(self._ctx, slot, coeffs, arr.ctypes.data, int(arr.size)))
+
+    def setInputClouds(self, clouds: Sequence, stride_bytes: int = 16):
+        """Batched setInputCloud: torch CUDA clouds for slots 0..len-1 in one launch."""
+        self._require_init("setInputCloud")
+        n_slots = len(clouds)
+        ptrs = (C.c_void_p * n_slots)()
+        counts = (C.c_int64 * n_slots)()
+        for i, cl in enumerate(clouds):
+            p, n, stride, keep = self._cloud_view(cl)
+            if stride != stride_bytes or not _is_torch_cuda(cl):
+                raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "setInputClouds needs CUDA clouds of one stride")
+            ptrs[i], counts[i] = p, n
+            self._keepalive[("cloud", i)] = keep
+        self._check(self._lib.mld_set_clouds_device(self._ctx, n_slots, ptrs, counts, stride_bytes))
+
+    # ------------------------------------------------------------------ CalculateDepth
+    def CalculateDepth(self, *args, slot: int = 0, return_types: bool = True):
+        """The reference's overloads (DepthEstimator.cpp:404-488):
+
+        CalculateDepth(cloud, uv, groundPlane)   -> setInputCloud + per-feature loop
+        CalculateDepth(uv)                       -> per-feature loop on the current cloud
+        `uv` is 2 x F (Eigen::Matrix2Xd layout, column i = (u,v)) or F x 2.  Returns (depths, resultTypes)
+        — the callee-resized VectorXd / VectorXi of the reference — as numpy arrays (host input) or torch
+        CUDA tensors (device input).
+        """
+        if len(args) == 3:
+            cloud, uv, gp = args
+            self.setInputCloud(cloud, gp, slot=slot)
+        elif len(args) == 1:
+            (uv,) = args
+        else:
+            raise TypeError("CalculateDepth(cloud, uv, groundPlane) or CalculateDepth(uv)")
+        self._require_init("CalculateDepth")
+        if _is_torch_cuda(uv):
+            import torch
+            uvd = self._uv_device(uv)
+            F = int(uvd.numel() // 2)
+            depth = torch.empty(F, dtype=torch.float64, device=uvd.device)
+            types = torch.empty(F, dtype=torch.int32, device=uvd.device)
+            torch.cuda.current_stream(uvd.device).synchronize()
+            self._check(self._lib.mld_calculate_depth_device(self._ctx, slot, uvd.data_ptr(), F, depth.data_ptr(),
+                                                             types.data_ptr()))
+            self.synchronize()
+            return (depth, types) if return_types else depth
+        uvh = self._uv_host(uv)
+        F = int(uvh.size // 2)
+        depth = np.empty(F, dtype=np.float64)
+        types = np.empty(F, dtype=np.int32)
+        self._check(self._lib.mld_calculate_depth(self._ctx, slot, uvh.ctypes.data, F, depth.ctypes.data,
+                                                  types.ctypes.data))
+        return (depth, types) if return_types else depth
+
+    @staticmethod
+    def _uv_host(uv) -> np.ndarray:
+        a = np.asarray(uv, dtype=np.float64)
+        if a.ndim != 2:
+            raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "uv must be 2xF or Fx2")
+        if a.shape[0] == 2 and a.shape[1] != 2:
+            a = a.T  # Matrix2Xd -> interleaved (u0,v0,u1,v1,...) == column-major 2xF
+        elif a.shape[1] != 2:
+            raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "uv must be 2xF or Fx2")
+        return np.ascontiguousarray(a)
+
+    @staticmethod
+    def _uv_device(uv):
+        import torch
+        if uv.dtype != torch.float64 or uv.dim() != 2 or uv.shape[1] != 2 or not uv.is_contiguous():
+            raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "device uv must be contiguous float64 [F,2]")
+        return uv
+
+    def CalculateDepths(self, uvs: Sequence, depths: Sequence, types: Optional[Sequence] = None):
+        """Batched CalculateDepth over slots 0..len-1 (torch CUDA tensors, asynchronous on `stream`)."""
+        n_slots = len(uvs)
+        uvp = (C.c_void_p * n_slots)()
+        dp = (C.c_void_p * n_slots)()
+        tp = (C.c_void_p * n_slots)()
+        Fs = (C.c_int64 * n_slots)()
+        for i in range(n_slots):
+            uvd = self._uv_device(uvs[i])
+            uvp[i] = uvd.data_ptr()
+            Fs[i] = int(uvd.shape[0])
+            dp[i] = depths[i].data_ptr()
+            tp[i] = types[i].data_ptr() if types is not None else None
+        self._check(self._lib.mld_calculate_depths_device(self._ctx, n_slots, uvp, Fs, dp, tp if types is not None else None))
+
+    # ------------------------------------------------------------------ debug getters
+    def getVisibleCount(self, slot: int = 0) -> int:
+        n = C.c_int64(0)
+        self._check(self._lib.mld_get_visible_count(self._ctx, slot, C.byref(n)))
+        return int(n.value)
+
+    def getPointsCloudImageCs(self, slot: int = 0) -> np.ndarray:
+        """getPointsCloudImageCs -> 2 x Nvis (DepthEstimator.cpp:392-394)."""
+        nvis = self.getVisibleCount(slot)
+        out = np.empty((nvis, 2), dtype=np.float64)
+        self._check(self._lib.mld_get_visible_image_points(self._ctx, slot, out.ctypes.data, nvis))
+        return out.T
+
+    def getPointIndex(self, slot: int = 0) -> np.ndarray:
+        nvis = self.getVisibleCount(slot)
+        out = np.empty(nvis, dtype=np.int32)
+        self._check(self._lib.mld_get_point_index(self._ctx, slot, out.ctypes.data, nvis))
+        return out
+
+    def getCloudCameraCs(self, n_points: int, slot: int = 0) -> np.ndarray:
+        """getCloudCameraCs -> 3 x N float64 (DepthEstimator.cpp:314-334)."""
+        out = np.empty((n_points, 3), dtype=np.float64)
+        self._check(self._lib.mld_get_cloud_camera_cs(self._ctx, slot, out.ctypes.data, n_points))
+        return out.T
+
+    def getPixelMap(self, slot: int = 0) -> np.ndarray:
+        """NeighborFinderPixel::_img_points_lidar as [H, W] int32 (visible index or -1)."""
+        W, H = self._camera.width, self._camera.height
+        out = np.empty(W * H, dtype=np.int32)
+        self._check(self._lib.mld_get_pixel_map(self._ctx, slot, out.ctypes.data, W * H))
+        return out.reshape(H, W)
+
+    def getPointDepthCamVisible(self, index: int, slot: int = 0) -> float:
+        d = C.c_double(0)
+        self._check(self._lib.mld_get_point_depth_cam_visible(self._ctx, slot, int(index), C.byref(d)))
+        return float(d.value)
+
+    @staticmethod
+    def resultHistogram(types) -> np.ndarray:
+        """DepthCalculationStatistics counterpart: counts per DepthResultType."""
+        t = np.ascontiguousarray(np.asarray(types.cpu() if hasattr(types, "cpu") else types), dtype=np.int32)
+        counts = (C.c_int64 * capi.MLD_RESULT_TYPE_COUNT)()
+        capi.load().mld_result_histogram(t.ctypes.data, int(t.size), counts)
+        return np.array(list(counts), dtype=np.int64)
+
+    # ------------------------------------------------------------------ measurement hooks
+    def timingEnable(self, on: bool = True):
+        self._check(self._lib.mld_timing_enable(self._ctx, 1 if on else 0))
+
+    def timingReset(self):
+        self._check(self._lib.mld_timing_reset(self._ctx))
+
+    def kernelTimeMs(self, which: int):
+        avg = C.c_double(0)
+        cnt = C.c_int64(0)
+        self._check(self._lib.mld_kernel_time_ms(self._ctx, which, C.byref(avg), C.byref(cnt)))
+        return float(avg.value), int(cnt.value)

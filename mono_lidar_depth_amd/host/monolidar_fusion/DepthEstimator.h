@@ -1,0 +1,299 @@
+// C++ shim: the reference's DepthEstimator interface on top of the C-ABI (include/mld.h).
+//
+// Mirrors Mono_Lidar::DepthEstimator (monolidar_fusion/include/monolidar_fusion/DepthEstimator.h:39-359) and
+// the companion types a caller touches — CameraPinhole (camera_pinhole.h:20-114), GroundPlane
+// (RansacPlane.h:38-123), DepthEstimatorParameters (DepthEstimatorParameters.h:7-173), DepthResultType
+// (eDepthResultType.h:8-30) — with the same method names, argument meaning and error behaviour (usage errors
+// throw, per-feature failures are (resultType, -1)).  Eigen/PCL types are replaced by std::vector / plain
+// structs with the same memory layout; when <Eigen/Core> is available the Eigen overloads are compiled too,
+// so tracklets_depth (tracklets_depth/src/tracklet_depth_module.cpp:80,115) links against this header unchanged.
+// Header-only; link with -lmld_hip.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <exception>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mld.h"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>)
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#define MLD_HAVE_EIGEN 1
+#endif
+#endif
+
+class CameraPinhole final {
+public:
+    using Ptr = std::shared_ptr<CameraPinhole>;
+    using ConstPtr = std::shared_ptr<const CameraPinhole>;
+    explicit CameraPinhole(int width, int height, double focal_length, double principal_point_x,
+                           double principal_point_y)
+            : width_(width), height_(height), focal_length_(focal_length), principal_point_x_(principal_point_x),
+              principal_point_y_(principal_point_y) {}
+    void getImageSize(int& width, int& height) const {
+        width = width_;
+        height = height_;
+    }
+    mld_camera asStruct() const { return mld_camera{focal_length_, principal_point_x_, principal_point_y_, width_, height_}; }
+
+private:
+    int width_, height_;
+    double focal_length_, principal_point_x_, principal_point_y_;
+};
+
+namespace Mono_Lidar {
+
+enum DepthResultType {
+    Unspecified = 0,
+    Success = 1,
+    RadiusSearchInsufficientPoints = 2,
+    HistogramNoLocalMax = 3,
+    TresholdDepthGlobalGreaterMax = 4,
+    TresholdDepthGlobalSmallerMin = 5,
+    TresholdDepthLocalGreaterMax = 6,
+    TresholdDepthLocalSmallerMin = 7,
+    TriangleNotPlanar = 8,
+    TriangleNotPlanarInsufficientPoints = 9,
+    CornerBehindCamera = 10,
+    PlaneViewrayNotOrthogonal = 11,
+    PcaIsPoint = 12,
+    PcaIsLine = 13,
+    PcaIsCubic = 14,
+    InsufficientRoadPoints = 15,
+    SuccessRoad = 16,
+    RegionGrowingNearestSeedNotAvailable = 17,
+    RegionGrowingSeedsOutOfRange = 18,
+    RegionGrowingInsufficientPoints = 19,
+    SuccessRegionGrowing = 20
+};
+
+// pcl::PointXYZI memory layout (8 floats, 32 bytes): x,y,z,pad, intensity,pad,pad,pad.
+struct alignas(16) PointXYZI {
+    float x, y, z, pad0_;
+    float intensity, pad1_, pad2_, pad3_;
+};
+static_assert(sizeof(PointXYZI) == 32, "PointXYZI must match pcl::PointXYZI");
+
+struct PointCloud {
+    using Ptr = std::shared_ptr<PointCloud>;
+    using ConstPtr = std::shared_ptr<const PointCloud>;
+    std::vector<PointXYZI> points;
+};
+
+class DepthEstimatorParameters : public mld_params {
+public:
+    DepthEstimatorParameters() { mld_params_default(this); }
+    void fromFile(const std::string& filePath) {
+        char err[512];
+        if (mld_params_from_file(this, filePath.c_str(), err, sizeof(err)) != MLD_OK) throw std::string(err);
+    }
+};
+
+class GroundPlane {
+public:
+    using Ptr = std::shared_ptr<GroundPlane>;
+    using Cloud = PointCloud;
+    struct ExceptionPclInvalid : public std::exception {
+        const char* what() const throw() override { return "In GroundPlane: Input pointcloud is invalid"; }
+    };
+    GroundPlane() = default;
+    // The plane as an input object: coefficients a,b,c,d (lidar frame) + inlier indices of the ORIGINAL cloud.
+    GroundPlane(const std::array<float, 4>& coeffs, std::vector<int> inliers)
+            : is_segmented_(true), _modelCoeffs(coeffs), _inliersIndex(std::move(inliers)) {}
+    virtual ~GroundPlane() = default;
+    // Hook for a per-frame estimator (RansacPlane::CalculateInliersPlane, RansacPlane.cpp:41-140).  The
+    // RANSAC implementation is a "next" row; the base class requires a pre-segmented plane.
+    virtual void CalculateInliersPlane(const Cloud::ConstPtr& pointCloud, double /*min_z*/, double /*max_z*/) {
+        if (!pointCloud || pointCloud->points.size() < 3) throw ExceptionPclInvalid();
+        throw std::runtime_error("GroundPlane: no estimator attached; supply a segmented plane");
+    }
+    bool isSegmented() const { return is_segmented_; }
+    std::array<float, 4>& getModelCoeffs() { return _modelCoeffs; }
+    const std::vector<int>& getInlinersIndex() { return _inliersIndex; }
+    bool CheckPointInPlane(const int index) const {
+        for (int i : _inliersIndex)
+            if (i == index) return true;
+        return false;
+    }
+
+protected:
+    bool is_segmented_ = false;
+    std::array<float, 4> _modelCoeffs{{0, 0, 0, 0}};
+    std::vector<int> _inliersIndex;
+};
+
+class DepthEstimator {
+public:
+    using Point = PointXYZI;
+    using Cloud = PointCloud;
+    using UniquePtr = std::unique_ptr<DepthEstimator>;
+    using SharedPtr = std::shared_ptr<DepthEstimator>;
+
+    explicit DepthEstimator(int device = 0) : _device(device) {}
+    ~DepthEstimator() {
+        if (_ctx) mld_destroy(_ctx);
+    }
+    DepthEstimator(const DepthEstimator&) = delete;
+    DepthEstimator& operator=(const DepthEstimator&) = delete;
+
+    bool InitConfig(const std::string& filePath, const bool printparams = true) {
+        (void)printparams;
+        _parameters = std::make_shared<DepthEstimatorParameters>();
+        _parameters->fromFile(filePath);
+        _isInitializedConfig = true;
+        return true;
+    }
+    bool InitConfig(std::shared_ptr<DepthEstimatorParameters> parameters = nullptr, const bool printparams = false) {
+        (void)printparams;
+        _parameters = parameters ? parameters : std::make_shared<DepthEstimatorParameters>();
+        _isInitializedConfig = true;
+        return true;
+    }
+
+    // transform_lidar_to_cam: row-major 3x4 [R|t]
+    bool Initialize(const std::shared_ptr<CameraPinhole>& camera, const std::array<double, 12>& transform_lidar_to_cam) {
+        if (!_isInitializedConfig) throw "Call 'InitConfig' before calling 'Initialize'.";
+        _camera = camera;
+        _transform = transform_lidar_to_cam;
+        if (_ctx) {
+            mld_destroy(_ctx);
+            _ctx = nullptr;
+        }
+        int status = 0;
+        mld_camera cam = camera->asStruct();
+        _ctx = mld_create(_parameters.get(), &cam, _transform.data(), _device, 1, 0, 0, &status);
+        if (!_ctx) {
+            if (status == MLD_ERR_NO_ROAD_ESTIMATOR) throw "No road depth estimator selected.";
+            throw std::string(mld_create_error());
+        }
+        _isInitialized = true;
+        return true;
+    }
+#ifdef MLD_HAVE_EIGEN
+    bool Initialize(const std::shared_ptr<CameraPinhole>& camera, const Eigen::Affine3d& transform_lidar_to_cam) {
+        std::array<double, 12> T;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) T[r * 4 + c] = transform_lidar_to_cam.matrix()(r, c);
+        return Initialize(camera, T);
+    }
+#endif
+
+    void setInputCloud(const Cloud::ConstPtr& cloud, GroundPlane::Ptr& groundPlane) {
+        if (!_isInitialized) throw "call of 'setInputCloud' without 'initialize'";
+        check(mld_set_cloud(_ctx, 0, cloud->points.data(), (int64_t)cloud->points.size(), (int)sizeof(PointXYZI)));
+        _numPoints = (int64_t)cloud->points.size();
+        _isInitializedPointCloud = true;
+        if (_parameters->do_use_ransac_plane) {
+            if (groundPlane == nullptr) groundPlane = std::make_shared<GroundPlane>();      // DepthEstimator.cpp:275-278
+            if (!groundPlane->isSegmented())                                                 // :281-283
+                groundPlane->CalculateInliersPlane(cloud, -10000., 10000.);
+            const auto& c = groundPlane->getModelCoeffs();
+            const auto& inl = groundPlane->getInlinersIndex();
+            check(mld_set_ground_plane(_ctx, 0, c.data(), inl.data(), (int64_t)inl.size()));
+        } else {
+            check(mld_set_ground_plane(_ctx, 0, nullptr, nullptr, 0));
+        }
+    }
+
+    std::shared_ptr<DepthEstimatorParameters> getParameters() { return _parameters; }
+    std::shared_ptr<CameraPinhole> getCamera() { return _camera; }
+    std::array<double, 12> getTransformLidarToCam() { return _transform; }
+    double getPointDepthCamVisible(int index) {
+        double d = 0;
+        check(mld_get_point_depth_cam_visible(_ctx, 0, index, &d));
+        return d;
+    }
+
+    // getCloudCameraCs: 3 x N column-major (x0,y0,z0,x1,...)
+    void getCloudCameraCs(std::vector<double>& xyz) {
+        xyz.resize((size_t)_numPoints * 3);
+        check(mld_get_cloud_camera_cs(_ctx, 0, xyz.data(), _numPoints));
+    }
+    // getPointsCloudImageCs: 2 x Nvis column-major
+    void getPointsCloudImageCs(std::vector<double>& uv) {
+        int64_t n = 0;
+        check(mld_get_visible_count(_ctx, 0, &n));
+        uv.resize((size_t)n * 2);
+        check(mld_get_visible_image_points(_ctx, 0, uv.data(), n));
+    }
+
+    // CalculateDepth overloads (DepthEstimator.cpp:404-488).  uv: 2 x F column-major.
+    void CalculateDepth(const Cloud::ConstPtr& pointCloud, const std::vector<double>& points_image_cs,
+                        std::vector<double>& points_depths, GroundPlane::Ptr& ransacPlane) {
+        setInputCloud(pointCloud, ransacPlane);
+        CalculateDepth(points_image_cs, points_depths, ransacPlane);
+    }
+    void CalculateDepth(const Cloud::ConstPtr& pointCloud, const std::vector<double>& points_image_cs,
+                        std::vector<double>& points_depths, std::vector<int>& resultType, GroundPlane::Ptr& ransacPlane) {
+        setInputCloud(pointCloud, ransacPlane);
+        CalculateDepth(points_image_cs, points_depths, resultType, ransacPlane);
+    }
+    void CalculateDepth(const std::vector<double>& points_image_cs, std::vector<double>& points_depths,
+                        const GroundPlane::Ptr& ransacPlane) {
+        std::vector<int> types;
+        CalculateDepth(points_image_cs, points_depths, types, ransacPlane);
+    }
+    void CalculateDepth(const std::vector<double>& points_image_cs, std::vector<double>& points_depths,
+                        std::vector<int>& resultType, const GroundPlane::Ptr& ransacPlane) {
+        if (!_isInitializedPointCloud) throw "call of 'CalculateDepth' without 'SetInputCloud'";
+        if (ransacPlane == nullptr && _parameters->do_use_ransac_plane)
+            check(mld_set_ground_plane(_ctx, 0, nullptr, nullptr, 0));  // "ransacPlane == nullptr": no road fallback
+        const int64_t F = (int64_t)(points_image_cs.size() / 2);
+        points_depths.resize((size_t)F);  // callee-resized outputs, DepthEstimator.cpp:442-443
+        resultType.resize((size_t)F);
+        static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
+        check(mld_calculate_depth(_ctx, 0, points_image_cs.data(), F, points_depths.data(),
+                                  reinterpret_cast<int32_t*>(resultType.data())));
+    }
+    std::pair<DepthResultType, double> CalculateDepth(const std::array<double, 2>& point_image_cs,
+                                                      const GroundPlane::Ptr& ransacPlane) {
+        std::vector<double> uv{point_image_cs[0], point_image_cs[1]}, d;
+        std::vector<int> t;
+        CalculateDepth(uv, d, t, ransacPlane);
+        return {static_cast<DepthResultType>(t[0]), d[0]};
+    }
+#ifdef MLD_HAVE_EIGEN
+    void CalculateDepth(const Cloud::ConstPtr& pointCloud, const Eigen::Matrix2Xd& points_image_cs,
+                        Eigen::VectorXd& points_depths, GroundPlane::Ptr& ransacPlane) {
+        Eigen::VectorXi types;
+        CalculateDepth(pointCloud, points_image_cs, points_depths, types, ransacPlane);
+    }
+    void CalculateDepth(const Cloud::ConstPtr& pointCloud, const Eigen::Matrix2Xd& points_image_cs,
+                        Eigen::VectorXd& points_depths, Eigen::VectorXi& resultType, GroundPlane::Ptr& ransacPlane) {
+        setInputCloud(pointCloud, ransacPlane);
+        const int64_t F = points_image_cs.cols();
+        points_depths.resize(F);
+        resultType.resize(F);
+        check(mld_calculate_depth(_ctx, 0, points_image_cs.data(), F, points_depths.data(), resultType.data()));
+    }
+#endif
+
+    // DepthCalculationStatistics counterpart
+    static std::array<int64_t, MLD_RESULT_TYPE_COUNT> getDepthCalcStats(const std::vector<int>& resultType) {
+        std::array<int64_t, MLD_RESULT_TYPE_COUNT> c{};
+        mld_result_histogram(reinterpret_cast<const int32_t*>(resultType.data()), (int64_t)resultType.size(), c.data());
+        return c;
+    }
+
+private:
+    void check(int rc) {
+        if (rc == MLD_OK) return;
+        if (rc == MLD_ERR_CLOUD_TOO_SMALL) throw GroundPlane::ExceptionPclInvalid();
+        throw std::runtime_error(std::string("DepthEstimator: ") + mld_last_error(_ctx));
+    }
+    int _device;
+    mld_ctx* _ctx = nullptr;
+    bool _isInitialized = false, _isInitializedConfig = false, _isInitializedPointCloud = false;
+    std::shared_ptr<DepthEstimatorParameters> _parameters;
+    std::shared_ptr<CameraPinhole> _camera;
+    std::array<double, 12> _transform{};
+    int64_t _numPoints = 0;
+};
+
+}  // namespace Mono_Lidar

@@ -1,0 +1,90 @@
+// Drives the C++ shim exactly the way tracklets_depth does (tracklet_depth_module.cpp:401,413,80):
+// InitConfig -> Initialize -> CalculateDepth(cloud, uv, depths, groundPlane).
+//
+// usage: mld_shim_demo <params.yaml|-> <cloud.bin> <uv.bin> <inliers.bin|-> <out.bin>
+//   cloud.bin  : N x 8 float32 (pcl::PointXYZI layout)     uv.bin : F x 2 float64 (= 2 x F column-major)
+//   inliers.bin: int32 indices; plane coefficients are fixed to (0,0,1,1.73)
+//   out.bin    : F float64 depths followed by F int32 result types
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <iterator>
+
+#include "monolidar_fusion/DepthEstimator.h"
+
+template <typename T>
+static std::vector<T> slurp(const char* path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error(std::string("cannot open ") + path);
+    std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    std::vector<T> out(raw.size() / sizeof(T));
+    std::memcpy(out.data(), raw.data(), out.size() * sizeof(T));
+    return out;
+}
+
+int main(int argc, char** argv) {
+    if (argc != 6) {
+        std::cerr << "usage: mld_shim_demo <params.yaml|-> <cloud.bin> <uv.bin> <inliers.bin|-> <out.bin>\n";
+        return 2;
+    }
+    try {
+        using namespace Mono_Lidar;
+        DepthEstimator est(0);
+        if (std::strcmp(argv[1], "-") == 0) {
+            auto p = std::make_shared<DepthEstimatorParameters>();
+            mld_params_c0(p.get());
+            est.InitConfig(p);
+        } else {
+            est.InitConfig(std::string(argv[1]), false);
+        }
+        auto cam = std::make_shared<CameraPinhole>(1242, 375, 721.5377, 609.5593, 172.854);
+        std::array<double, 12> T = {0, -1, 0, 0.0, 0, 0, -1, -0.08, 1, 0, 0, -0.27};
+        est.Initialize(cam, T);
+
+        auto cloud = std::make_shared<PointCloud>();
+        cloud->points = slurp<PointXYZI>(argv[2]);
+        std::vector<double> uv = slurp<double>(argv[3]);
+        GroundPlane::Ptr gp;
+        if (std::strcmp(argv[4], "-") != 0) {
+            std::vector<int> inl = slurp<int>(argv[4]);
+            gp = std::make_shared<GroundPlane>(std::array<float, 4>{0.f, 0.f, 1.f, 1.73f}, inl);
+        } else {
+            est.getParameters()->do_use_ransac_plane = 0;
+            est.Initialize(cam, T);
+        }
+        std::vector<double> depths;
+        std::vector<int> types;
+        PointCloud::ConstPtr ccloud = cloud;
+        est.CalculateDepth(ccloud, uv, depths, types, gp);
+
+        std::ofstream out(argv[5], std::ios::binary);
+        out.write(reinterpret_cast<const char*>(depths.data()), (std::streamsize)(depths.size() * sizeof(double)));
+        out.write(reinterpret_cast<const char*>(types.data()), (std::streamsize)(types.size() * sizeof(int)));
+        auto stats = DepthEstimator::getDepthCalcStats(types);
+        std::cout << "features " << types.size() << " success " << stats[Success] << " road " << stats[SuccessRoad]
+                  << " insufficient " << stats[RadiusSearchInsufficientPoints] << "\n";
+        // usage error as in the reference: CalculateDepth before setInputCloud
+        DepthEstimator fresh(0);
+        fresh.InitConfig();
+        bool threw = false;
+        try {
+            fresh.Initialize(cam, T);
+            std::vector<double> d2;
+            fresh.CalculateDepth(uv, d2, gp);
+        } catch (const char* msg) {
+            threw = std::string(msg) == "call of 'CalculateDepth' without 'SetInputCloud'";
+        }
+        std::cout << "usage_error_ok " << (threw ? 1 : 0) << "\n";
+    } catch (const std::exception& e) {
+        std::cerr << "error: " << e.what() << "\n";
+        return 1;
+    } catch (const char* msg) {
+        std::cerr << "error: " << msg << "\n";
+        return 1;
+    } catch (const std::string& msg) {
+        std::cerr << "error: " << msg << "\n";
+        return 1;
+    }
+    return 0;
+}

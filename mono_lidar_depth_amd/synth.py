@@ -1,0 +1,116 @@
+"""Seeded synthetic LiDAR frames / features / ground planes.
+
+Shared by the parity tests, the CPU baseline and the GPU benchmark.  A spinning scanner (R rings x A azimuth
+steps, ring-major order) ray-casts a scene of a ground plane, 12 axis-aligned boxes and enclosing walls; range
+noise N(0, 0.02 m); 2 % drop-outs are emitted as NaN points so that N = R*A stays fixed (a non-dense PCL cloud).
+No file, dataset or reference code is involved.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+# KITTI-like camera
+KITTI_W, KITTI_H = 1242, 375
+KITTI_F, KITTI_CU, KITTI_CV = 721.5377, 609.5593, 172.854
+GROUND_Z = -1.73
+
+# lidar (x fwd, y left, z up) -> camera (x right, y down, z fwd): (x,y,z)_l -> (-y, -z, x); t = (0, -0.08, -0.27)
+T_CAM_LIDAR = np.array([[0.0, -1.0, 0.0, 0.0],
+                        [0.0, 0.0, -1.0, -0.08],
+                        [1.0, 0.0, 0.0, -0.27]], dtype=np.float64)
+
+
+@dataclass(frozen=True)
+class Scanner:
+    rings: int
+    azimuth_steps: int
+    elev_top_deg: float
+    elev_bottom_deg: float
+    max_range: float = 120.0
+
+
+HDL64 = Scanner(64, 2048, 2.0, -24.9)          # config 2: 131 072 points
+HDL64_KITTI = Scanner(64, 1875, 2.0, -24.9)    # config 1: ~120 k points
+VLP16 = Scanner(16, 1800, 15.0, -15.0)         # config 3: 28 800 points
+DENSE128 = Scanner(128, 4096, 15.0, -25.0)     # config 5: 524 288 points
+
+
+def make_scene(seed: int):
+    """12 boxes on the ground (centres 5..60 m ahead / +-20 m lateral) + walls."""
+    rng = np.random.default_rng(1000 + seed)
+    cx = rng.uniform(5.0, 60.0, 12)
+    cy = rng.uniform(-20.0, 20.0, 12)
+    sx = rng.uniform(1.0, 5.0, 12)
+    sy = rng.uniform(1.0, 5.0, 12)
+    h = rng.uniform(1.0, 3.0, 12)
+    lo = np.stack([cx - sx / 2, cy - sy / 2, np.full(12, GROUND_Z)], axis=1)
+    hi = np.stack([cx + sx / 2, cy + sy / 2, GROUND_Z + h], axis=1)
+    walls_lo = np.array([-80.0, -80.0, GROUND_Z - 1.0])
+    walls_hi = np.array([180.0, 80.0, 40.0])
+    return lo, hi, walls_lo, walls_hi
+
+
+def make_cloud(scanner: Scanner, seed: int = 0, frame: int = 0, stride_floats: int = 4) -> np.ndarray:
+    """One frame as float32 [N, stride_floats]: x,y,z,(pad),intensity(...) in the lidar frame.
+
+    stride_floats = 4: packed xyzi; 8: pcl::PointXYZI memory layout (x,y,z,pad,intensity,pad,pad,pad).
+    The sensor advances 1 m per frame along x through the scene `seed`.
+    """
+    lo, hi, wlo, whi = make_scene(seed)
+    R, A = scanner.rings, scanner.azimuth_steps
+    el = np.deg2rad(np.linspace(scanner.elev_top_deg, scanner.elev_bottom_deg, R))
+    az = 2.0 * np.pi * np.arange(A) / A
+    ce, se = np.cos(el)[:, None], np.sin(el)[:, None]
+    d = np.stack([ce * np.cos(az)[None, :], ce * np.sin(az)[None, :], np.broadcast_to(se, (R, A))], axis=-1)
+    d = d.reshape(-1, 3)  # ring-major
+    o = np.array([float(frame), 0.0, 0.0])
+    n = d.shape[0]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / d
+        # ground
+        t_ground = np.where(d[:, 2] < 0, (GROUND_Z - o[2]) * inv[:, 2], np.inf)
+        # walls: exit distance of the enclosing box
+        t1 = (wlo[None, :] - o[None, :]) * inv
+        t2 = (whi[None, :] - o[None, :]) * inv
+        t_wall = np.nanmin(np.maximum(t1, t2), axis=1)
+        best = np.minimum(t_ground, t_wall)
+        # boxes: entry distance (slab test)
+        for b in range(lo.shape[0]):
+            ta = (lo[b][None, :] - o[None, :]) * inv
+            tb = (hi[b][None, :] - o[None, :]) * inv
+            tn = np.nanmax(np.minimum(ta, tb), axis=1)
+            tf = np.nanmin(np.maximum(ta, tb), axis=1)
+            hit = (tn <= tf) & (tn > 0)
+            best = np.where(hit & (tn < best), tn, best)
+    rng = np.random.default_rng(seed * 100003 + frame)
+    rngs = best + rng.normal(0.0, 0.02, n)
+    valid = np.isfinite(best) & (best < scanner.max_range) & (best > 0.5)
+    valid &= rng.random(n) >= 0.02  # drop-outs
+    pts = d * rngs[:, None]
+    out = np.zeros((n, stride_floats), dtype=np.float32)
+    out[:, :3] = pts.astype(np.float32)
+    out[:, 4 if stride_floats == 8 else 3] = rng.uniform(0.0, 1.0, n).astype(np.float32)
+    out[~valid, :3] = np.nan
+    return out
+
+
+def make_features(n: int, seed: int = 0, integer: bool = False, width: int = KITTI_W, height: int = KITTI_H) -> np.ndarray:
+    """[F, 2] float64 features, uniform over the image (integer-valued for the tracklet API, config 5)."""
+    rng = np.random.default_rng(77000 + seed)
+    uv = np.stack([rng.uniform(0, width, n), rng.uniform(0, height, n)], axis=1)
+    if integer:
+        uv = np.floor(uv)
+    return np.ascontiguousarray(uv, dtype=np.float64)
+
+
+def make_ground_plane(cloud: np.ndarray, subsample: int = 0, seed: int = 0):
+    """Analytic plane of the scene in the lidar frame (0,0,1,1.73) + inliers |z + 1.73| < 0.3."""
+    z = cloud[:, 2]
+    inl = np.nonzero(np.abs(z - GROUND_Z) < 0.3)[0].astype(np.int32)
+    if subsample and inl.size > subsample:
+        rng = np.random.default_rng(5150 + seed)
+        inl = np.sort(rng.choice(inl, subsample, replace=False)).astype(np.int32)
+    coeffs = np.array([0.0, 0.0, 1.0, -GROUND_Z], dtype=np.float32)
+    return coeffs, inl

@@ -1,0 +1,24 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _native_built():
+    """Build libmld_hip.so / the oracle if they are missing (hipcc cross-compiles without a GPU)."""
+    from mono_lidar_depth_amd import capi
+    from oracle import oracle
+    if not capi.LIB_PATH.exists() or not oracle.LIB_PATH.exists():
+        import __graft_entry__
+        __graft_entry__.build()
+    yield

@@ -1,0 +1,212 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on identical seeded inputs."""
+import numpy as np
+import pytest
+
+from mono_lidar_depth_amd import GroundPlane, capi, synth
+
+from helpers import assert_depth_parity, kitti_camera, make_estimator, make_oracle, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(scanner, seed, nfeat, frame=0, integer=False, stride=4):
+    cloud = synth.make_cloud(scanner, seed=seed, frame=frame, stride_floats=stride)
+    uv = synth.make_features(nfeat, seed=seed, integer=integer)
+    plane = synth.make_ground_plane(cloud)
+    return cloud, uv, plane
+
+
+def test_projection_pixelmap_bit_exact():
+    """_pointIndex, visible image points, camera-frame cloud and the pixel map are bit-identical."""
+    P = capi.params_c0()
+    cloud, uv, plane = _frame(synth.HDL64, 0, 16)
+    est = make_estimator(P)
+    est.setInputCloud(cloud, GroundPlane(*plane))
+    ref = make_oracle(P)
+    ref.set_cloud(cloud)
+    assert est.getVisibleCount() == ref.nvis
+    assert np.array_equal(est.getPointIndex(), ref.point_index())
+    assert np.array_equal(est.getPointsCloudImageCs(), ref.visible_image_points())
+    cam_gpu, cam_ref = est.getCloudCameraCs(cloud.shape[0]), ref.cloud_camera_cs()
+    assert np.array_equal(np.isnan(cam_gpu), np.isnan(cam_ref))
+    assert np.array_equal(np.nan_to_num(cam_gpu), np.nan_to_num(cam_ref))
+    assert np.array_equal(est.getPixelMap(), ref.pixel_map())
+    k = ref.nvis // 2
+    assert est.getPointDepthCamVisible(k) == ref.cloud_camera_cs()[2, ref.point_index()[k]]
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_config2_depth_parity(seed):
+    """BASELINE config 2: 64x2048 cloud, 2000 features, C0 parameters."""
+    P = capi.params_c0()
+    cloud, uv, plane = _frame(synth.HDL64, seed, 2000, frame=seed * 7)
+    est = make_estimator(P)
+    depth, types = est.CalculateDepth(cloud, uv, GroundPlane(*plane))
+    _, (d0, t0) = run_oracle(P, cloud, uv, plane)
+    assert_depth_parity(depth, types, d0, t0)
+    assert (types == 1).sum() > 50 and (types == 16).sum() > 50
+
+
+def test_pcl_stride_and_repeat_calls():
+    """32-byte pcl::PointXYZI records; CalculateDepth twice on one cloud; a second cloud on the same slot."""
+    P = capi.params_c0()
+    cloud8, uv, plane = _frame(synth.HDL64_KITTI, 5, 500, stride=8)
+    est = make_estimator(P)
+    gp = GroundPlane(*plane)
+    d1, t1 = est.CalculateDepth(cloud8, uv, gp)
+    d2, t2 = est.CalculateDepth(uv)
+    assert np.array_equal(d1, d2, equal_nan=True) and np.array_equal(t1, t2)
+    _, (d0, t0) = run_oracle(P, cloud8, uv, plane)
+    assert_depth_parity(d1, t1, d0, t0)
+    # new cloud on the same slot: stale map entries must not leak
+    cloudb, uvb, planeb = _frame(synth.HDL64_KITTI, 6, 500, frame=40)
+    d3, t3 = est.CalculateDepth(cloudb, uvb, GroundPlane(*planeb))
+    _, (d0b, t0b) = run_oracle(P, cloudb, uvb, planeb)
+    assert_depth_parity(d3, t3, d0b, t0b)
+
+
+def test_tag_wraparound():
+    """More than 255 setInputCloud calls on one slot: the map tag wraps and the map is re-zeroed."""
+    P = capi.params_c0()
+    sc = synth.Scanner(16, 360, 2.0, -24.9)
+    est = make_estimator(P)
+    clouds = [synth.make_cloud(sc, seed=9, frame=f) for f in range(4)]
+    uv = synth.make_features(256, seed=9)
+    for it in range(300):
+        cl = clouds[it % 4]
+        est.setInputCloud(cl, None)
+    cl = clouds[299 % 4]
+    depth, types = est.CalculateDepth(uv)
+    _, (d0, t0) = run_oracle(P, cl, uv, None)
+    assert_depth_parity(depth, types, d0, t0)
+
+
+@pytest.mark.parametrize("tmode,lmode,ltype", [(0, 0, 1), (1, 0, 0), (0, 1, 0), (1, 1, 1)])
+def test_config3_sparse_cloud_threshold_modes(tmode, lmode, ltype):
+    """BASELINE config 3: VLP-16 sparse cloud, 5000 features, threshold treatment modes swept."""
+    P = capi.params_c0().replace(treshold_depth_mode=tmode, treshold_depth_local_mode=lmode,
+                                 treshold_depth_local_valuetype=ltype, treshold_depth_max=30,
+                                 treshold_depth_min=4, treshold_depth_local_value=0.05)
+    cloud, uv, plane = _frame(synth.VLP16, 11, 5000)
+    est = make_estimator(P)
+    depth, types = est.CalculateDepth(cloud, uv, GroundPlane(*plane))
+    _, (d0, t0) = run_oracle(P, cloud, uv, plane)
+    assert_depth_parity(depth, types, d0, t0)
+
+
+def test_wide_window_many_neighbours():
+    """Header-default window (12x15 -> up to 238 cells, road window 624): multi-chunk lists and pair search."""
+    P = capi.params_default().replace(viewray_plane_orthoganality_treshold=0.03, radiusSearch_count_min=3)
+    cloud, uv, plane = _frame(synth.DENSE128, 21, 1500)
+    est = make_estimator(P)
+    depth, types = est.CalculateDepth(cloud, uv, GroundPlane(*plane))
+    ref, (d0, t0) = run_oracle(P, cloud, uv, plane)
+    assert_depth_parity(depth, types, d0, t0)
+    traces = [ref.trace_feature(*uv[i]) for i in range(0, 1500, 10)]
+    assert max(len(t["nb_idx"]) for t in traces) > 64, "test should exercise lists longer than one wavefront"
+    assert max(len(t["road_idx"]) for t in traces) > 128
+
+
+MODE_CASES = {
+    "no_plane": dict(_plane=False),
+    "no_ransac": dict(do_use_ransac_plane=0),
+    "no_hist": dict(do_use_histogram_segmentation=0),
+    "no_trimax": dict(do_use_triangle_size_maximation=0),
+    "no_planar_check": dict(do_check_triangleplanar_condition=0),
+    "normal_intersection": dict(viewray_plane_orthoganality_treshold=0.0),
+    "header_orth_1": dict(viewray_plane_orthoganality_treshold=1.0),
+    "no_thresholds": dict(treshold_depth_enabled=0, treshold_depth_local_enabled=0, do_use_cut_behind_camera=0),
+    "count_min_5": dict(radiusSearch_count_min=5),
+    "hist_min1_bin1": dict(histogram_segmentation_min_pointcount=1, histogram_segmentation_bin_witdh=1.0),
+    "hist_min0": dict(histogram_segmentation_min_pointcount=0),
+    "pca": dict(do_use_PCA=1, pca_treshold_2_1_rel_min=0.5),
+    "road_triangle": dict(plane_estimator_use_triangle_maximation=1, plane_estimator_use_mestimator=0,
+                          plane_estimator_z_x_min_relation=0.2),
+    "zero": dict(set_all_depths_to_zero=1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MODE_CASES))
+def test_parameter_modes(name):
+    kw = dict(MODE_CASES[name])
+    with_plane = kw.pop("_plane", True)
+    P = capi.params_c0().replace(**kw)
+    cloud, uv, plane = _frame(synth.HDL64_KITTI, 31, 1200)
+    est = make_estimator(P)
+    gp = GroundPlane(*plane) if with_plane else None
+    depth, types = est.CalculateDepth(cloud, uv, gp)
+    _, (d0, t0) = run_oracle(P, cloud, uv, plane if with_plane else None)
+    exact = name not in ("pca",)
+    assert_depth_parity(depth, types, d0, t0, exact_main=exact)
+
+
+def test_edge_features_and_empty_inputs():
+    """Features on / outside the image border, integer pixels, F = 0, an empty cloud, an all-NaN cloud."""
+    P = capi.params_c0()
+    cloud, _, plane = _frame(synth.HDL64_KITTI, 41, 1)
+    W, H = synth.KITTI_W, synth.KITTI_H
+    uv = np.array([[0, 0], [W - 1, H - 1], [W, H], [-3.5, 200], [W + 2.9, 300], [600.5, -4.4], [600.5, H + 4.4],
+                   [0.49, 374.51], [1241.99, 0.01], [-100, -100], [5000, 5000], [620, 250], [3.0, 371.0]], dtype=np.float64)
+    uv = np.concatenate([uv, synth.make_features(200, seed=41, integer=True)])
+    est = make_estimator(P)
+    depth, types = est.CalculateDepth(cloud, uv, GroundPlane(*plane))
+    _, (d0, t0) = run_oracle(P, cloud, uv, plane)
+    assert_depth_parity(depth, types, d0, t0)
+    # F = 0
+    d, t = est.CalculateDepth(np.zeros((0, 2)))
+    assert d.shape == (0,) and t.shape == (0,)
+    # empty cloud and all-NaN cloud: every feature is RadiusSearchInsufficientPoints
+    for cl in (np.zeros((0, 4), np.float32), np.full((100, 4), np.nan, np.float32)):
+        d, t = est.CalculateDepth(cl, uv[:20], None)
+        assert (t == 2).all() and (d == -1).all()
+
+
+def test_usage_errors():
+    """Error behaviour of the reference's usage errors (DepthEstimator.cpp:38,57,94,439,608)."""
+    from mono_lidar_depth_amd import DepthEstimator, DepthEstimatorError
+    est = DepthEstimator()
+    with pytest.raises(DepthEstimatorError, match="InitConfig"):
+        est.Initialize(kitti_camera(), synth.T_CAM_LIDAR)
+    for kw, code in ((dict(neighbor_search_mode=1), capi.MLD_ERR_UNSUPPORTED_MODE),
+                     (dict(do_use_depth_segmentation=1), capi.MLD_ERR_UNSUPPORTED_MODE),
+                     (dict(plane_estimator_use_mestimator=0), capi.MLD_ERR_NO_ROAD_ESTIMATOR)):
+        e2 = DepthEstimator()
+        e2.InitConfig(capi.params_c0().replace(**kw))
+        with pytest.raises(DepthEstimatorError) as ei:
+            e2.Initialize(kitti_camera(), synth.T_CAM_LIDAR)
+        assert ei.value.code == code
+    e3 = make_estimator(capi.params_c0())
+    with pytest.raises(DepthEstimatorError, match="without 'SetInputCloud'"):
+        e3.CalculateDepth(np.zeros((4, 2)))
+    cloud = synth.make_cloud(synth.Scanner(8, 90, 2, -20), 1)
+    e3.setInputCloud(cloud, None, plane_given=False)
+    with pytest.raises(DepthEstimatorError) as ei:
+        e3.CalculateDepth(np.zeros((4, 2)))
+    assert ei.value.code == capi.MLD_ERR_NO_GROUND_PLANE
+
+
+def test_batched_slots_match_single_slot():
+    """Frame slots: 16 frames in one launch set (torch device tensors) == one frame at a time."""
+    import torch
+    P = capi.params_c0()
+    B, F = 16, 700
+    sc = synth.HDL64_KITTI
+    est = make_estimator(P, max_frames=B)
+    clouds = [synth.make_cloud(sc, seed=50 + (b % 3), frame=b) for b in range(B)]
+    uvs = [synth.make_features(F + 13 * b, seed=60 + b) for b in range(B)]
+    planes = [synth.make_ground_plane(c) for c in clouds]
+    dev = torch.device("cuda:0")
+    t_clouds = [torch.from_numpy(c).to(dev) for c in clouds]
+    t_uvs = [torch.from_numpy(u).to(dev) for u in uvs]
+    t_inl = [torch.from_numpy(p[1]).to(dev) for p in planes]
+    t_depth = [torch.full((u.shape[0],), 7.0, dtype=torch.float64, device=dev) for u in uvs]
+    t_type = [torch.full((u.shape[0],), -7, dtype=torch.int32, device=dev) for u in uvs]
+    torch.cuda.synchronize()
+    est.setInputClouds(t_clouds, 16)
+    for b in range(B):
+        est.setGroundPlane(GroundPlane(planes[b][0], t_inl[b]), slot=b)
+    est.CalculateDepths(t_uvs, t_depth, t_type)
+    est.synchronize()
+    for b in range(B):
+        _, (d0, t0) = run_oracle(P, clouds[b], uvs[b], planes[b])
+        assert_depth_parity(t_depth[b].cpu().numpy(), t_type[b].cpu().numpy(), d0, t0)
