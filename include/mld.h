@@ -174,6 +174,8 @@ int mld_set_ground_plane_device(mld_ctx* ctx, int slot, const float coeffs[4], c
                                 int64_t n_inliers);
 /* Same, with the inlier set already as a device bitmask (bit i of word i/32 = point i is an inlier). */
 int mld_set_ground_plane_mask_device(mld_ctx* ctx, int slot, const float coeffs[4], const uint32_t* mask_dev);
+/* Slots [0, n_slots): coeffs is n_slots x 4 (host), mask_dev a host array of device bitmask pointers. */
+int mld_set_ground_planes_mask_device(mld_ctx* ctx, int n_slots, const float* coeffs, const uint32_t* const* mask_dev);
 
 /*
  * CalculateDepth(Matrix2Xd, VectorXd&, VectorXi&, GroundPlane::Ptr) (DepthEstimator.cpp:429-488).

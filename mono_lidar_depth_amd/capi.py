@@ -116,6 +116,7 @@ _SIGNATURES = [
     ("mld_set_ground_plane", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p, C.c_int64]),
     ("mld_set_ground_plane_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p, C.c_int64]),
     ("mld_set_ground_plane_mask_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p]),
+    ("mld_set_ground_planes_mask_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), _P(C.c_void_p)]),
     ("mld_calculate_depth", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("mld_calculate_depth_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("mld_calculate_depths_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64),
@@ -141,6 +142,14 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP runtimes in one process cannot
+    # both own the GPU, so when torch is installed it is imported FIRST: the dynamic loader then resolves this
+    # library's libamdhip64.so.7 dependency to the runtime torch already loaded.  (A C++ caller without torch
+    # simply gets /opt/rocm's runtime.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = Path(os.environ.get("MLD_HIP_LIBRARY", LIB_PATH))
     if not path.exists():
         raise RuntimeError(

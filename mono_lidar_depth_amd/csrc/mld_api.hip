@@ -600,6 +600,17 @@ int mld_set_ground_plane_mask_device(mld_ctx* ctx, int slot, const float coeffs[
     return MLD_OK;
 }
 
+int mld_set_ground_planes_mask_device(mld_ctx* ctx, int n_slots, const float* coeffs, const uint32_t* const* mask_dev) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    if (n_slots < 1 || n_slots > (int)ctx->slots.size() || !coeffs || !mask_dev)
+        return fail(ctx, MLD_ERR_INVALID_ARG, "bad slot count / null arrays");
+    for (int i = 0; i < n_slots; i++) {
+        int rc = mld_set_ground_plane_mask_device(ctx, i, coeffs + 4 * i, mask_dev[i]);
+        if (rc) return rc;
+    }
+    return MLD_OK;
+}
+
 // ---------------------------------------------------------------------------- CalculateDepth
 static int calc_one(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, double* depth_dev, int32_t* type_dev) {
     Slot& s = ctx->slots[slot];

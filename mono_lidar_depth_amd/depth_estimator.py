@@ -219,6 +219,41 @@ class DepthEstimator:
             arr = np.ascontiguousarray(inl, dtype=np.int32)
             self._check(self._lib.mld_set_ground_plane(self._ctx, slot, coeffs, arr.ctypes.data, int(arr.size)))
 
+    def setGroundPlanesMask(self, coeffs, masks: Sequence):
+        """Batched ground-plane hook: `coeffs` [B,4] float32 (host), `masks` B torch CUDA int32 bitmask tensors
+        (bit i of word i/32 set = original point i is a plane inlier; the device form of `_pointIsInPlane`)."""
+        n_slots = len(masks)
+        c = np.ascontiguousarray(coeffs, dtype=np.float32).reshape(n_slots, 4)
+        ptrs = (C.c_void_p * n_slots)(*[int(m.data_ptr()) for m in masks])
+        self._keepalive["masks"] = list(masks)
+        self._check(self._lib.mld_set_ground_planes_mask_device(
+            self._ctx, n_slots, c.ctypes.data_as(C.POINTER(C.c_float)), ptrs))
+
+    def prepareBatch(self, clouds: Sequence, uvs: Sequence, depths: Sequence, types: Sequence, coeffs, masks: Sequence,
+                     stride_bytes: int = 16):
+        """Pre-marshal the pointer tables of a fixed batch so that `runBatch` is three C calls per step."""
+        n = len(clouds)
+        b = {"n": n, "stride": stride_bytes}
+        b["cloud_ptrs"] = (C.c_void_p * n)(*[int(c.data_ptr()) for c in clouds])
+        b["cloud_n"] = (C.c_int64 * n)(*[int(c.shape[0]) for c in clouds])
+        b["uv_ptrs"] = (C.c_void_p * n)(*[int(self._uv_device(u).data_ptr()) for u in uvs])
+        b["F"] = (C.c_int64 * n)(*[int(u.shape[0]) for u in uvs])
+        b["depth_ptrs"] = (C.c_void_p * n)(*[int(d.data_ptr()) for d in depths])
+        b["type_ptrs"] = (C.c_void_p * n)(*[int(t.data_ptr()) for t in types])
+        b["coeffs"] = np.ascontiguousarray(coeffs, dtype=np.float32).reshape(n, 4)
+        b["mask_ptrs"] = (C.c_void_p * n)(*[int(m.data_ptr()) for m in masks])
+        b["keep"] = (list(clouds), list(uvs), list(depths), list(types), list(masks))
+        return b
+
+    def runBatch(self, b):
+        """One pass of the hot path over the batch: setInputCloud + ground-plane hook + CalculateDepth for every
+        slot (asynchronous on `stream`)."""
+        lib, ctx, n = self._lib, self._ctx, b["n"]
+        self._check(lib.mld_set_clouds_device(ctx, n, b["cloud_ptrs"], b["cloud_n"], b["stride"]))
+        self._check(lib.mld_set_ground_planes_mask_device(ctx, n, b["coeffs"].ctypes.data_as(C.POINTER(C.c_float)),
+                                                          b["mask_ptrs"]))
+        self._check(lib.mld_calculate_depths_device(ctx, n, b["uv_ptrs"], b["F"], b["depth_ptrs"], b["type_ptrs"]))
+
     def setInputClouds(self, clouds: Sequence, stride_bytes: int = 16):
         """Batched setInputCloud: torch CUDA clouds for slots 0..len-1 in one launch."""
         self._require_init("setInputCloud")

@@ -95,8 +95,9 @@ def test_config3_sparse_cloud_threshold_modes(tmode, lmode, ltype):
 
 
 def test_wide_window_many_neighbours():
-    """Header-default window (12x15 -> up to 238 cells, road window 624): multi-chunk lists and pair search."""
-    P = capi.params_default().replace(viewray_plane_orthoganality_treshold=0.03, radiusSearch_count_min=3)
+    """Large window (20x24 -> up to 572 cells, road window 42x38): multi-chunk lists and pair search."""
+    P = capi.params_default().replace(viewray_plane_orthoganality_treshold=0.03, radiusSearch_count_min=3,
+                                      pixelarea_search_witdh=20, pixelarea_search_height=24)
     cloud, uv, plane = _frame(synth.DENSE128, 21, 1500)
     est = make_estimator(P)
     depth, types = est.CalculateDepth(cloud, uv, GroundPlane(*plane))
