@@ -670,7 +670,10 @@ bool segmentation_plane(const Frame& fr, const std::vector<V3>& nb, const std::v
         float xf = static_cast<float>(xl), yf = static_cast<float>(yl), zf = static_cast<float>(zl);
         float d = std::fabs(fr.coeffs[0] * xf + fr.coeffs[1] * yf + fr.coeffs[2] * zf + fr.coeffs[3]);
         double distance = d;
-        if (distance > thr) return false;  // :814-815
+        if (distance > thr) {              // :814-815
+            if (dbg) dbg->road_pos.clear();
+            return false;
+        }
         if (fr.inlier[raw]) {              // :817 CheckPointInPlane
             seg.push_back(nb[i]);
             if (dbg) dbg->road_pos.push_back(static_cast<int32_t>(i));

@@ -1,0 +1,336 @@
+"""Second, independent restatement of the reference path in NumPy / plain Python.
+
+TEST INFRASTRUCTURE ONLY (see oracle/mld_oracle.cpp).  Written separately from the C++ oracle, straight from the
+reference sources, to cross-check it and to generate the committed golden fixtures (tests/golden/make_golden.py).
+Per-feature work is pure-Python loops: use it on small cases only.
+
+Differences to the C++ oracle that are intentional (so that the two do not share a bug):
+  * the M-estimator normal comes from numpy.linalg.svd of the 3 x k matrix (the reference uses JacobiSVD),
+  * PCA uses numpy.linalg.eigh,
+  * 3-vector dot products use Python float arithmetic in index order (last-ulp differences are expected; the
+    cross-check tolerance on depths is 1e-9 m, while everything integer — visible list, pixel map, neighbour
+    lists, histogram selection, triangle corners, result types — must agree exactly).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+class NpDepthEstimator:
+    def __init__(self, P, cam, T):
+        self.P, self.cam = P, cam
+        self.T = np.asarray(T, dtype=np.float64)[:3, :4]
+        # Initialize (DepthEstimator.cpp:43-44)
+        A = np.eye(4)
+        A[:3, :4] = self.T
+        self.Tinv = np.linalg.inv(A)[:3, :4]
+        f, cu, cv = cam.focal_length, cam.principal_point_x, cam.principal_point_y
+        self.K = np.array([[f, 0, cu], [0, f, cv], [0, 0, 1.0]])
+        self.Kinv = np.linalg.inv(self.K)
+        self.plane = None
+
+    # Transform_Cloud_LidarToCamera (DepthEstimator.cpp:156-217) + getImagePoints (camera_pinhole.h:84-97)
+    def set_cloud(self, cloud):
+        T, cam = self.T, self.cam
+        p = np.asarray(cloud, dtype=np.float32)[:, :3].astype(np.float64)
+        x, y, z = p[:, 0], p[:, 1], p[:, 2]
+        with np.errstate(all="ignore"):
+            xc = T[0, 3] + ((T[0, 0] * x + T[0, 1] * y) + T[0, 2] * z)
+            yc = T[1, 3] + ((T[1, 0] * x + T[1, 1] * y) + T[1, 2] * z)
+            zc = T[2, 3] + ((T[2, 0] * x + T[2, 1] * y) + T[2, 2] * z)
+            f, cu, cv = cam.focal_length, cam.principal_point_x, cam.principal_point_y
+            q0 = (f * xc + 0.0 * yc) + cu * zc
+            q1 = (0.0 * xc + f * yc) + cv * zc
+            q2 = (0.0 * xc + 0.0 * yc) + 1.0 * zc
+            u, v = q0 / q2, q1 / q2
+            in_range = (u >= 0.0) & (u <= float(cam.width)) & (v >= 0.0) & (v <= float(cam.height))
+            strict = (u > 0) & (u < cam.width) & (v > 0) & (v < cam.height)
+        self.cam_pts = np.stack([xc, yc, zc])
+        self.img_pts = np.stack([u, v])
+        self.in_range = in_range
+        self.point_index = np.nonzero(in_range & strict)[0].astype(np.int32)
+        self.img_vis = self.img_pts[:, self.point_index]
+        # InitializeLidarProjection (NeighborFinderPixel.cpp:29-58)
+        W, H = cam.width, cam.height
+        pm = np.full((H, W), -1, dtype=np.int32)
+        for i, raw in enumerate(self.point_index):
+            xi, yi = int(self.img_vis[0, i]), int(self.img_vis[1, i])
+            if pm[yi, xi] == -1 and self.cam_pts[2, raw] > 0:
+                pm[yi, xi] = i
+        self.pixel_map = pm
+        self.plane = None
+
+    def set_ground_plane(self, coeffs, inliers):
+        if coeffs is None:
+            self.plane = None
+            return
+        c = np.asarray(coeffs, dtype=np.float32)
+        n = c[:3].astype(np.float64)
+        self.plane = {"coeffs": c, "inliers": set(int(i) for i in np.asarray(inliers)),
+                      "prior_n": n / math.sqrt(float(n @ n)), "prior_off": float(c[3])}
+
+    # NeighborFinderPixel::getNeighbors (NeighborFinderPixel.cpp:60-95)
+    def neighbours(self, u, v, sx, sy):
+        P, W, H = self.P, self.cam.width, self.cam.height
+        hx = float(P.pixelarea_search_witdh) * 0.5 * float(np.float32(sx))
+        hy = float(P.pixelarea_search_height) * 0.5 * float(np.float32(sy))
+        left, right = max(u - hx, 0.0), min(u + hx, float(W - 1))
+        top, bottom = max(v - hy, 0.0), min(v + hy, float(H - 1))
+        idx = []
+        for i in range(int(top), int(bottom) + 1):
+            for j in range(int(left), int(right) + 1):
+                if self.pixel_map[i, j] != -1:
+                    idx.append(int(self.pixel_map[i, j]))
+        pts = [self.cam_pts[:, self.point_index[k]].copy() for k in idx]
+        return idx, pts
+
+    # PointHistogram::FilterPointsMinDistBlob (HistogramPointDepth.cpp:15-123)
+    @staticmethod
+    def histogram_filter(depths, bin_w, min_count):
+        max_dist = 0
+        for d in depths:
+            if d > max_dist:
+                max_dist = int(math.ceil(d))
+        bin_count = int(max_dist / bin_w + 1)
+        if bin_count <= 1:
+            return None
+        bins = [0] * bin_count
+        for d in depths:
+            val = min(d, 1e10)
+            bins[int(min(abs(val / bin_w), float(bin_count) - 1.0))] += 1
+        max_id, max_val, val = -1, -1, 0
+        for i in range(bin_count):
+            last = val
+            val = bins[i]
+            if val > max_val and val >= min_count:
+                max_val, max_id = val, i
+            elif val < max_val:
+                break
+            if last > 0 and val == 0:
+                return None
+        if max_id < 0:
+            return None
+        lo = max_id * bin_w - 0.0 * bin_w
+        hi = max_id * bin_w + 1.0 * bin_w
+        return [k for k, d in enumerate(depths) if lo <= d < hi]
+
+    # PlaneEstimationCalcMaxSpanningTriangle::CalculatePlaneCorners (:37-100), _distTreshold = 0
+    @staticmethod
+    def triangle(pts, thr=0.0):
+        n = len(pts)
+        if n < 3:
+            return None
+
+        def sq(a, b):
+            d = a - b
+            return d[0] * d[0] + (d[1] * d[1] + d[2] * d[2])
+
+        mi = mj = -1
+        md = -1.0
+        for i in range(n - 1):
+            for j in range(i + 1, n):
+                d = sq(pts[i], pts[j])
+                if d > md:
+                    md, mi, mj = d, i, j
+        if md <= thr:
+            return None
+        md2, mk = -1.0, -1
+        for k in range(n - 1):
+            if k == mi or k == mj:
+                continue
+            d1 = sq(pts[k], pts[mi])
+            if d1 <= thr:
+                continue
+            d2 = sq(pts[k], pts[mj])
+            if d2 <= thr:
+                continue
+            if d1 + d2 > md2:
+                md2, mk = d1 + d2, k
+        if mi == -1 or mj == -1 or mk == -1:
+            return None
+        return mi, mj, mk
+
+    def viewing_ray(self, u, v):
+        d = self.Kinv @ np.array([u, v, 1.0])
+        d = d / np.linalg.norm(d)
+        if d[2] < 0:
+            d = -d
+        return d
+
+    @staticmethod
+    def line_plane(n, offset, n0, n1):
+        direction = (n1 - n0) / np.linalg.norm(n1 - n0)
+        t = -(offset + float(n @ n0)) / float(n @ direction)
+        return n0 + direction * t
+
+    def thresholds(self, depth, pts):
+        P = self.P
+        if P.treshold_depth_enabled:
+            if depth < P.treshold_depth_min:
+                if P.treshold_depth_mode == 0:
+                    return 5, depth
+                depth = float(P.treshold_depth_min)
+            elif depth > P.treshold_depth_max:
+                if P.treshold_depth_mode == 0:
+                    return 4, depth
+                depth = float(P.treshold_depth_max)
+        if P.treshold_depth_local_enabled:
+            zs = [p[2] for p in pts]
+            mn, mx = min(zs), max(zs)
+            if P.treshold_depth_local_valuetype == 1:
+                r = (mx - mn) * P.treshold_depth_local_value
+                lo, hi = mn - r, mx + r
+            else:
+                lo, hi = mn - P.treshold_depth_local_value, mx + P.treshold_depth_local_value
+            if depth < lo:
+                if P.treshold_depth_local_mode == 0:
+                    return 7, depth
+                depth = lo
+            elif depth > hi:
+                if P.treshold_depth_local_mode == 0:
+                    return 6, depth
+                depth = hi
+        return 0, depth
+
+    # DepthEstimator::CalculateDepthSegmented (DepthEstimator.cpp:903-1037), triangle variant
+    def depth_segmented(self, u, v, seg, trace):
+        P = self.P
+        if not P.do_use_PCA and P.do_use_triangle_size_maximation:
+            tri = self.triangle(seg)
+            if tri is None:
+                return 9, -1.0
+        else:
+            if len(seg) < 3:
+                return 3, -1.0
+            tri = (0, 1, 2)
+        trace["corners"] = tri
+        c1, c2, c3 = seg[tri[0]], seg[tri[1]], seg[tri[2]]
+        if not P.do_use_PCA and P.do_check_triangleplanar_condition:
+            e1, e2, e3 = c2 - c1, c3 - c1, c3 - c2
+            e1, e2, e3 = e1 / np.linalg.norm(e1), e2 / np.linalg.norm(e2), e3 / np.linalg.norm(e3)
+            thr = P.triangleplanar_crossnorm_treshold
+            if not (np.linalg.norm(np.cross(e1, e2)) >= thr and np.linalg.norm(np.cross(e1, e3)) >= thr
+                    and np.linalg.norm(np.cross(e2, e3)) >= thr):
+                return 8, -1.0
+        ray = self.viewing_ray(u, v)
+        if P.do_use_PCA:
+            X = np.stack(seg, axis=1)
+            mean = X.mean(axis=1)
+            C = (X - mean[:, None]) @ (X - mean[:, None]).T
+            w, V = np.linalg.eigh(C)
+            planarity = np.float32((w[1] - w[0]) / w[2])
+            linearity = np.float32((w[2] - w[1]) / w[2])
+            if planarity < P.pca_treshold_2_1_rel_min:
+                return 14, -1.0
+            if linearity > P.pca_treshold_3_2_rel_max:
+                return 13, -1.0
+            if w[2] < P.pca_treshold_3_abs_min:
+                return 12, -1.0
+            n = V[:, 0] / np.linalg.norm(V[:, 0])
+            off = -float(n @ mean)
+        else:
+            v0, v1 = c3 - c1, c2 - c1
+            n = np.cross(v0, v1)
+            n = n / np.linalg.norm(n)
+            off = -float(c1 @ n)
+        if P.viewray_plane_orthoganality_treshold > 0:
+            if not abs(float((n / np.linalg.norm(n)) @ (ray / np.linalg.norm(ray)))) >= P.viewray_plane_orthoganality_treshold:
+                return 11, -1.0
+        ip = self.line_plane(n, off, np.zeros(3), ray)
+        depth = float(ip[2])
+        code, depth = self.thresholds(depth, seg)
+        if code:
+            return code, -1.0
+        if depth < 0 and P.do_use_cut_behind_camera:
+            return 10, -1.0
+        return 1, depth
+
+    # DepthEstimator::CalculateDepth(Vector2d, ...) (DepthEstimator.cpp:491-600)
+    def feature(self, u, v):
+        P = self.P
+        trace = {}
+        idx, nb = self.neighbours(u, v, 1.0, 1.0)
+        trace["nb_idx"] = idx
+        if len(nb) < np.uint32(P.radiusSearch_count_min):
+            return 2, -1.0, trace
+        result = (0, -1.0)
+        seg = None
+        if P.do_use_histogram_segmentation:
+            depths = [min(float(p[2]), 999.0) for p in nb]
+            keep = self.histogram_filter(depths, P.histogram_segmentation_bin_witdh,
+                                         P.histogram_segmentation_min_pointcount)
+            if keep is None:
+                result = (3, -1.0)
+            else:
+                seg = [nb[k] for k in keep]
+                trace["seg_pos"] = keep
+        else:
+            seg = nb
+            trace["seg_pos"] = list(range(len(nb)))
+        if result[0] != 3:
+            result = self.depth_segmented(u, v, seg, trace)
+            if result[0] == 1:
+                return result[0], result[1], trace
+        old = result[0]
+        if self.plane is not None and P.do_use_ransac_plane:
+            idx, nb = self.neighbours(u, v, 2.0, 1.5)
+            trace["road_idx"] = idx
+            if len(nb) < np.uint32(P.radiusSearch_count_min):
+                return 2, -1.0, trace
+            # CalculateDepthSegmentationPlane (:782-900)
+            seg, pos = [], []
+            c = self.plane["coeffs"]
+            for i, p in enumerate(nb):
+                raw = int(self.point_index[idx[i]])
+                pl = (self.Tinv[:, :3] @ p + self.Tinv[:, 3]).astype(np.float32)
+                d = abs(((c[0] * pl[0] + c[1] * pl[1]) + c[2] * pl[2]) + c[3])  # float32 scalars throughout
+                if float(d) > P.ransac_plane_point_distance_treshold:
+                    return old, -1.0, trace
+                if raw in self.plane["inliers"]:
+                    seg.append(p)
+                    pos.append(i)
+            trace["road_pos"] = pos
+            if len(seg) < 3:
+                return old, -1.0, trace
+            ray = self.viewing_ray(u, v)
+            if P.plane_estimator_use_triangle_maximation:
+                tri = self.triangle(seg)
+                if tri is None:
+                    return 2, -1.0, trace
+                xs, zs = [p[0] for p in seg], [p[2] for p in seg]
+                with np.errstate(all="ignore"):
+                    rel = np.float64(max(zs) - min(zs)) / np.float64(max(xs) - min(xs))
+                if not rel >= P.plane_estimator_z_x_min_relation:
+                    return 15, -1.0, trace
+                c1, c2, c3 = seg[tri[0]], seg[tri[1]], seg[tri[2]]
+                n = np.cross(c3 - c1, c2 - c1)
+                n = n / np.linalg.norm(n)
+                off = -float(c1 @ n)
+            else:
+                # PlaneEstimationMEstimator::EstimatePlane (:18-55)
+                pn, po = self.plane["prior_n"], self.plane["prior_off"]
+                with np.errstate(all="ignore"):
+                    w = np.array([1.0 / abs(float(pn @ p) + po) for p in seg])
+                    X = np.stack(seg, axis=1)
+                    center = (X * w[None, :]).sum(axis=1) / w.sum()
+                    M = (X - center[:, None]) * np.sqrt(w)[None, :]
+                if not np.all(np.isfinite(M)):
+                    return 16, float("nan"), trace
+                U, S, _ = np.linalg.svd(M, full_matrices=False)
+                n = U[:, -1] / np.linalg.norm(U[:, -1])
+                off = -float(n @ center)
+            ip = self.line_plane(n, off, ray, np.zeros(3))
+            depth = float(ip[2])
+            code, depth = self.thresholds(depth, seg)
+            if code:
+                return code, -1.0, trace
+            return 16, depth, trace
+        return result[0], result[1], trace
+
+    def calculate_depth(self, uv):
+        if self.P.set_all_depths_to_zero:
+            return np.full(len(uv), -1.0), np.ones(len(uv), dtype=np.int32), [{} for _ in uv]
+        out = [self.feature(float(a), float(b)) for a, b in uv]
+        return (np.array([o[1] for o in out]), np.array([o[0] for o in out], dtype=np.int32), [o[2] for o in out])

@@ -1,0 +1,71 @@
+"""world_size-2 gloo tests of the multi-GPU layout: calibration broadcast, sequence assignment, timing reduce."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from mono_lidar_depth_amd import capi, sharding, synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if rank == 0:
+            P = capi.params_c0().replace(treshold_depth_max=77, histogram_segmentation_bin_witdh=0.25)
+            cam = capi.MldCamera(synth.KITTI_F, synth.KITTI_CU, synth.KITTI_CV, synth.KITTI_W, synth.KITTI_H)
+            T = synth.T_CAM_LIDAR
+        else:
+            P = cam = T = None
+        P, cam, T = sharding.broadcast_calibration(P, cam, T)
+        seqs = sharding.assign_sequences(8, world)[rank]
+        slow = sharding.max_over_ranks(1.0 + rank)
+        total = sharding.sum_over_ranks(100.0 * (rank + 1))
+        q.put((rank, bytes(P), bytes(cam), T.tolist(), seqs, slow, total))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_and_sharding_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, p0, c0, t0, s0, slow0, tot0), (r1, p1, c1, t1, s1, slow1, tot1) = res
+    assert p0 == p1 and c0 == c1 and t0 == t1  # every rank holds rank 0's calibration
+    P = capi.MldParams.from_buffer_copy(p1)
+    assert P.treshold_depth_max == 77 and P.histogram_segmentation_bin_witdh == 0.25
+    assert np.array_equal(np.array(t1), synth.T_CAM_LIDAR)
+    assert s0 == [0, 2, 4, 6] and s1 == [1, 3, 5, 7]  # sequence s -> rank s mod world
+    assert slow0 == slow1 == 2.0 and tot0 == tot1 == 300.0
+
+
+def test_pack_roundtrip_and_identity_without_process_group():
+    P = capi.params_default()
+    cam = capi.MldCamera(600.0, 50.0, 50.0, 100, 100)
+    blob = sharding.pack_calibration(P, cam, synth.T_CAM_LIDAR)
+    assert blob.nbytes < 1024
+    P2, cam2, T2 = sharding.unpack_calibration(blob)
+    assert bytes(P2) == bytes(P) and bytes(cam2) == bytes(cam) and np.array_equal(T2, synth.T_CAM_LIDAR)
+    P3, cam3, T3 = sharding.broadcast_calibration(P, cam, synth.T_CAM_LIDAR)
+    assert P3 is P and cam3 is cam
+    assert sharding.max_over_ranks(3.5) == 3.5 and sharding.sum_over_ranks(2.0) == 2.0
+    assert sharding.assign_sequences(3, 8) == [[0], [1], [2], [], [], [], [], []]
