@@ -1,0 +1,42 @@
+"""The C++ shim class (reference method names over the C-ABI) driven the way tracklets_depth drives it."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from mono_lidar_depth_amd import capi, synth
+
+from helpers import assert_depth_parity, run_oracle
+
+ROOT = Path(__file__).resolve().parent.parent
+DEMO = ROOT / "mono_lidar_depth_amd" / "lib" / "mld_shim_demo"
+
+
+def test_shim_demo_is_built():
+    assert DEMO.exists(), "run __graft_entry__.build()"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_plane", [True, False])
+def test_cpp_shim_matches_oracle(tmp_path, with_plane):
+    cloud = synth.make_cloud(synth.HDL64_KITTI, seed=12, frame=1, stride_floats=8)  # pcl::PointXYZI layout
+    uv = synth.make_features(900, seed=12)
+    coeffs, inl = synth.make_ground_plane(cloud)
+    (tmp_path / "cloud.bin").write_bytes(cloud.tobytes())
+    (tmp_path / "uv.bin").write_bytes(uv.tobytes())
+    (tmp_path / "inl.bin").write_bytes(inl.tobytes())
+    out = tmp_path / "out.bin"
+    r = subprocess.run([str(DEMO), "-", str(tmp_path / "cloud.bin"), str(tmp_path / "uv.bin"),
+                        str(tmp_path / "inl.bin") if with_plane else "-", str(out)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "usage_error_ok 1" in r.stdout
+    raw = out.read_bytes()
+    F = uv.shape[0]
+    depth = np.frombuffer(raw[:8 * F], dtype=np.float64)
+    types = np.frombuffer(raw[8 * F:], dtype=np.int32)
+    P = capi.params_c0() if with_plane else capi.params_c0().replace(do_use_ransac_plane=0)
+    coeffs[3] = np.float32(1.73)
+    _, (d0, t0) = run_oracle(P, cloud, uv, (coeffs, inl) if with_plane else None)
+    assert_depth_parity(depth, types, d0, t0)
