@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -196,6 +197,10 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     c.pcaRelMax = P.pca_treshold_3_2_rel_max;
     c.pcaRelMin = P.pca_treshold_2_1_rel_min;
     ctx->lds_bytes = (size_t)cap * (3 * sizeof(double) + 2 * sizeof(int)) + (size_t)kRecFields * kWave * sizeof(double);
+    // MLD_FORCE_WAVE_PATH=1 disables the thread-per-feature fast path (tests exercise both code paths)
+    const char* force = std::getenv("MLD_FORCE_WAVE_PATH");
+    c.threadPath = (force && force[0] == '1') ? 0 : 1;
+    ctx->lds_bytes = std::max(ctx->lds_bytes, (size_t)kK1Max * kWave * sizeof(uint32_t));
 }
 
 int check_slot(mld_ctx* ctx, int slot) {
@@ -261,7 +266,8 @@ int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int strid
     if (!dev_ptr && n > 0) return fail(ctx, MLD_ERR_INVALID_ARG, "null cloud pointer");
     if (((size_t)dev_ptr & 3) != 0) return fail(ctx, MLD_ERR_INVALID_ARG, "cloud pointer must be 4-byte aligned");
     if (s.d.tag >= kMaxTag) {
-        HIP_TRY(ctx, hipMemsetAsync(s.d.map, 0, (size_t)ctx->cam.width * ctx->cam.height * sizeof(uint32_t),
+        HIP_TRY(ctx, hipMemsetAsync(s.d.map, 0,
+                                    ((size_t)ctx->cam.width * ctx->cam.height + kMapPadCells) * sizeof(uint32_t),
                                     ctx->stream));
         s.d.tag = 1;
     } else {
@@ -465,7 +471,7 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     ctx->h_descs.resize(max_frames);
     if ((e = hipMalloc((void**)&ctx->d_slots, sizeof(SlotDesc) * max_frames)) != hipSuccess)
         return hip_bail(e, "hipMalloc(slots)");
-    size_t cells = (size_t)camera->width * camera->height;
+    size_t cells = (size_t)camera->width * camera->height + kMapPadCells;
     for (Slot& s : ctx->slots) {
         if ((e = hipMalloc((void**)&s.d.map, cells * sizeof(uint32_t))) != hipSuccess) return hip_bail(e, "hipMalloc(map)");
         if ((e = hipMemsetAsync(s.d.map, 0, cells * sizeof(uint32_t), ctx->stream)) != hipSuccess)

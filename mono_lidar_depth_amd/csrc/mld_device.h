@@ -10,6 +10,7 @@ constexpr uint32_t kIdxBits = 24;               // pixel-map key: [tag:8 | (0xFF
 constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1u;
 constexpr int64_t kMaxPoints = (int64_t)kIdxMask;  // points per cloud representable in a key
 constexpr uint32_t kMaxTag = 255;
+constexpr int kMapPadCells = 16;  // the thread path reads rows with 16-byte loads that may overrun the last cell
 
 // Per-context constants, passed to every kernel by value (kernarg segment -> SGPRs / scalar loads).
 struct Calib {
@@ -36,6 +37,7 @@ struct Calib {
     int useRoad;   // do_use_ransac_plane
     int roadMode;  // 0 = M-estimator, 1 = max spanning triangle
     int usePCA;
+    int threadPath;  // 1: thread-per-feature fast path with wave-cooperative overflow; 0: wave path only
 };
 
 // Per-frame-slot descriptor (device-resident array, or passed by value for single-slot calls).

@@ -23,6 +23,12 @@
 
 namespace mld {
 
+// Pointers that arrive inside SlotDesc are generic to the compiler, which would make every access a flat_*
+// instruction.  They are always device-global memory: cast to address space 1 so global_load/store/atomic is emitted.
+#define GPTR(T, p) ((const T __attribute__((address_space(1)))*)(p))
+#define GPTRW(T, p) ((T __attribute__((address_space(1)))*)(p))
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
 // ------------------------------------------------------------------------------------------------
@@ -103,15 +109,14 @@ __device__ __forceinline__ V3 vcross(V3 a, V3 b) {
 __device__ __forceinline__ void load_point(const SlotDesc& s, long long i, double& x, double& y, double& z) {
     const unsigned char* p = s.cloud + (size_t)i * (size_t)s.stride;
     if ((((size_t)s.cloud) & 15) == 0) {
-        float4 q = *reinterpret_cast<const float4*>(p);
+        f32x4 q = *GPTR(f32x4, p);
         x = (double)q.x;
         y = (double)q.y;
         z = (double)q.z;
     } else {
-        const float* q = reinterpret_cast<const float*>(p);
-        x = (double)q[0];
-        y = (double)q[1];
-        z = (double)q[2];
+        x = (double)GPTR(float, p)[0];
+        y = (double)GPTR(float, p)[1];
+        z = (double)GPTR(float, p)[2];
     }
 }
 __device__ __forceinline__ V3 lidar_to_cam(const Calib& c, double x, double y, double z) {
@@ -165,7 +170,8 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
         if ((u > 0.0) && (u < Wd) && (v > 0.0) && (v < Hd)) {
             int xi = (int)u, yi = (int)v;  // truncation, NeighborFinderPixel.cpp:41-42
             uint32_t key = (s.tag << kIdxBits) | (kIdxMask - (uint32_t)i);
-            atomicMax(&s.map[(size_t)xi + (size_t)yi * (size_t)c.W], key);
+            __hip_atomic_fetch_max(GPTRW(uint32_t, s.map) + ((size_t)xi + (size_t)yi * (size_t)c.W), key,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -220,7 +226,7 @@ __device__ int gather_window(const Calib& c, const SlotDesc& s, double u, double
         if (cidx < ncell) {
             int row = (int)(((float)cidx + 0.5f) * rnx);
             int col = cidx - row * nx;
-            uint32_t key = s.map[(size_t)(x0 + col) + (size_t)(y0 + row) * (size_t)c.W];
+            uint32_t key = GPTR(uint32_t, s.map)[(size_t)(x0 + col) + (size_t)(y0 + row) * (size_t)c.W];
             has = (key >> kIdxBits) == s.tag;
             orig = (int)(kIdxMask - (key & kIdxMask));
         }
@@ -619,17 +625,94 @@ enum : int {
     ST_ROAD_TRI = 4     // record = 3 corners + minZ,maxZ           -> phase 4
 };
 
-__global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restrict__ slots, SlotDesc single,
-                                                         int use_single, Calib c, int n_slots, int per_slot) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    int slot, j;
-    decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
-    const SlotDesc s = use_single ? single : slots[slot];
-    const long long f0 = (long long)j * kWave;
-    if (f0 >= s.F) return;
-    const int lane = threadIdx.x;
-    const int nf = (int)((s.F - f0) < (long long)kWave ? (s.F - f0) : (long long)kWave);
+// Tail of CalculateDepthSegmented (DepthEstimator.cpp:928-1036), one feature per lane.
+//   r[0..8]: three corners (triangle) or mean + scatter xx,xy,xz,yy,yz,zz (PCA); r[9], r[10]: min / max z of the
+//   segmented points (TresholdDepthLocal).
+__device__ __forceinline__ void finish_main(const Calib& c, bool pca, double u, double v, const double r[kRecFields], int& out_type,
+                            double& out_depth) {
+    const bool orth = c.orthThr > 0;  // DepthEstimator.cpp:77-81
+    int type = MLD_Success;
+    double depth = -1.0;
+    V3 dir = viewing_ray(c, u, v);
+    V3 support = {0, 0, 0};
+    if (!pca) {
+        V3 c1 = {r[0], r[1], r[2]}, c2 = {r[3], r[4], r[5]}, c3 = {r[6], r[7], r[8]};
+        if (c.checkPlanar) {  // PlaneEstimationCheckPlanar.cpp:18-44
+            V3 e1 = vnormalized(vsub(c2, c1)), e2 = vnormalized(vsub(c3, c1)), e3 = vnormalized(vsub(c3, c2));
+            double l12 = vnorm(vcross(e1, e2)), l13 = vnorm(vcross(e1, e3)), l23 = vnorm(vcross(e2, e3));
+            if (!((l12 >= c.planarThr) && (l13 >= c.planarThr) && (l23 >= c.planarThr))) type = MLD_TriangleNotPlanar;
+        }
+        if (type == MLD_Success) {
+            Plane pl = plane_through(c1, c2, c3);
+            if (!intersect(c, orth, pl, support, dir, depth)) type = MLD_PlaneViewrayNotOrthogonal;
+        }
+    } else {
+        // Mono_LidarPipeline::PCA (PCA.cpp:11-62)
+        double ev[3];
+        V3 n0;
+        jacobi_eig3(&r[3], ev, n0);
+        n0 = vdivs(n0, vnorm(n0));
+        float planarity = (float)((ev[1] - ev[0]) / ev[2]);
+        float linearity = (float)((ev[2] - ev[1]) / ev[2]);
+        if ((double)planarity < c.pcaRelMin)
+            type = MLD_PcaIsCubic;
+        else if ((double)linearity > c.pcaRelMax)
+            type = MLD_PcaIsLine;
+        else if (ev[2] < c.pcaAbsMin)
+            type = MLD_PcaIsPoint;
+        if (type == MLD_Success) {
+            V3 mean = {r[0], r[1], r[2]};
+            Plane pl = {n0, -vdot(n0, mean)};
+            if (!intersect(c, orth, pl, support, dir, depth)) type = MLD_PlaneViewrayNotOrthogonal;
+        }
+    }
+    if (type == MLD_Success) {
+        int t = apply_thresholds(c, r[9], r[10], depth);
+        if (t) type = t;
+    }
+    if (type == MLD_Success && depth < 0 && c.cutBehind) type = MLD_CornerBehindCamera;
+    out_type = type;
+    out_depth = (type == MLD_Success) ? depth : -1.0;
+}
 
+// Tail of the road estimators (RoadDepthEstimatorMEstimator.cpp:28-74, RoadDepthEstimatorMaxSpanningTriangle.cpp:
+// 24-75), one feature per lane.  r[0..8]: weighted centre + weighted scatter (M-estimator) or three corners.
+__device__ __forceinline__ void finish_road(const Calib& c, bool triangle, double u, double v, const double r[kRecFields], int& out_type,
+                            double& out_depth) {
+    V3 dir = viewing_ray(c, u, v);
+    V3 support = {0, 0, 0};
+    Plane pl;
+    if (!triangle) {
+        // PlaneEstimationMEstimator::EstimatePlane (:18-55): direction of least weighted variance
+        V3 center = {r[0], r[1], r[2]};
+        double ev[3];
+        V3 n0;
+        jacobi_eig3(&r[3], ev, n0);
+        if (isnan(center.x) || isnan(center.y) || isnan(center.z)) {
+            double qn = __builtin_nan("");
+            n0 = {qn, qn, qn};
+        }
+        n0 = vnormalized(n0);
+        pl.n = n0;
+        pl.offset = -vdot(n0, center);
+    } else {
+        pl = plane_through({r[0], r[1], r[2]}, {r[3], r[4], r[5]}, {r[6], r[7], r[8]});
+    }
+    double depth = -1.0;
+    intersect(c, false, pl, dir, support, depth);  // n0 = direction, n1 = support (swapped, as the reference)
+    int type = MLD_SuccessRoad;
+    int t = apply_thresholds(c, r[9], r[10], depth);
+    if (t) type = t;
+    out_type = type;
+    out_depth = (type == MLD_SuccessRoad) ? depth : -1.0;
+}
+
+// Wave-cooperative path: processes the features whose bit is set in `mask` (wave-uniform), one at a time, with
+// all 64 lanes working on that feature's window / neighbour list.  Handles lists of any length (up to the
+// window size); used for the features the thread-per-feature path cannot hold (long lists).
+__device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, unsigned char* smem, const int lane,
+                                       const unsigned long long mask, const double myu, const double myv, int& mytype,
+                                       double& mydepth) {
     Lists L;
     L.x = reinterpret_cast<double*>(smem);
     L.y = L.x + c.cap;
@@ -637,19 +720,12 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
     L.idx = reinterpret_cast<int*>(L.z + c.cap);
     L.bin = L.idx + c.cap;
     double* rec = reinterpret_cast<double*>(L.bin + c.cap);
-
-    double myu = 0, myv = 0;
-    if (lane < nf) {
-        const double* q = s.uv + 2 * (f0 + lane);
-        myu = q[0];
-        myv = q[1];
-    }
+    const bool inmask = (mask >> lane) & 1ull;
     int mystate = ST_FINAL;
-    int mytype = MLD_Unspecified;
-    double mydepth = -1.0;
 
     // ---------------- phase 1 ----------------
-    for (int fi = 0; fi < nf; fi++) {
+    for (unsigned long long m1 = mask; m1; m1 &= m1 - 1) {
+        const int fi = __ffsll((long long)m1) - 1;
         const double u = readlane_f64(myu, fi), v = readlane_f64(myv, fi);
         int state = ST_FINAL, type = MLD_Unspecified;
         int k = gather_window(c, s, u, v, c.halfX1, c.halfY1, L, lane);
@@ -706,65 +782,23 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
         if (lane == fi) {
             mystate = state;
             mytype = type;
+            mydepth = -1.0;
         }
     }
 
     // ---------------- phase 2 (lane = feature) ----------------
-    const bool orth = c.orthThr > 0;  // DepthEstimator.cpp:77-81
     if (mystate == ST_TRIANGLE || mystate == ST_PCA) {
         double r[kRecFields];
 #pragma unroll
         for (int t = 0; t < kRecFields; t++) r[t] = load_rec(rec, lane, t);
-        int type = MLD_Success;
-        double depth = -1.0;
-        V3 dir = viewing_ray(c, myu, myv);
-        V3 support = {0, 0, 0};
-        if (mystate == ST_TRIANGLE) {
-            V3 c1 = {r[0], r[1], r[2]}, c2 = {r[3], r[4], r[5]}, c3 = {r[6], r[7], r[8]};
-            if (c.checkPlanar) {  // PlaneEstimationCheckPlanar.cpp:18-44
-                V3 e1 = vnormalized(vsub(c2, c1)), e2 = vnormalized(vsub(c3, c1)), e3 = vnormalized(vsub(c3, c2));
-                double l12 = vnorm(vcross(e1, e2)), l13 = vnorm(vcross(e1, e3)), l23 = vnorm(vcross(e2, e3));
-                if (!((l12 >= c.planarThr) && (l13 >= c.planarThr) && (l23 >= c.planarThr)))
-                    type = MLD_TriangleNotPlanar;
-            }
-            if (type == MLD_Success) {
-                Plane pl = plane_through(c1, c2, c3);
-                if (!intersect(c, orth, pl, support, dir, depth)) type = MLD_PlaneViewrayNotOrthogonal;
-            }
-        } else {
-            // Mono_LidarPipeline::PCA (PCA.cpp:11-62)
-            double ev[3];
-            V3 n0;
-            jacobi_eig3(&r[3], ev, n0);
-            n0 = vdivs(n0, vnorm(n0));
-            float planarity = (float)((ev[1] - ev[0]) / ev[2]);
-            float linearity = (float)((ev[2] - ev[1]) / ev[2]);
-            if ((double)planarity < c.pcaRelMin)
-                type = MLD_PcaIsCubic;
-            else if ((double)linearity > c.pcaRelMax)
-                type = MLD_PcaIsLine;
-            else if (ev[2] < c.pcaAbsMin)
-                type = MLD_PcaIsPoint;
-            if (type == MLD_Success) {
-                V3 mean = {r[0], r[1], r[2]};
-                Plane pl = {n0, -vdot(n0, mean)};
-                if (!intersect(c, orth, pl, support, dir, depth)) type = MLD_PlaneViewrayNotOrthogonal;
-            }
-        }
-        if (type == MLD_Success) {
-            int t = apply_thresholds(c, r[9], r[10], depth);
-            if (t) type = t;
-        }
-        if (type == MLD_Success && depth < 0 && c.cutBehind) type = MLD_CornerBehindCamera;
-        mytype = type;
-        mydepth = (type == MLD_Success) ? depth : -1.0;
+        finish_main(c, mystate == ST_PCA, myu, myv, r, mytype, mydepth);
         mystate = ST_FINAL;
     }
 
     // ---------------- phase 3: road fallback (DepthEstimator.cpp:578-597) ----------------
     // Candidates: everything that is not Success and did not already return at :509-510.
     const bool road_on = c.useRoad && s.has_plane;
-    bool cand = road_on && (lane < nf) && (mytype != MLD_Success) && (mytype != MLD_RadiusSearchInsufficientPoints);
+    bool cand = road_on && inmask && (mytype != MLD_Success) && (mytype != MLD_RadiusSearchInsufficientPoints);
     unsigned long long cm = __ballot(cand);
     while (cm) {
         const int fi = __ffsll((long long)cm) - 1;
@@ -796,7 +830,7 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
                     float xf = (float)xl, yf = (float)yl, zf = (float)zl;
                     float d = fabsf(s.coeffs[0] * xf + s.coeffs[1] * yf + s.coeffs[2] * zf + s.coeffs[3]);
                     far = (double)d > c.roadDistThr;
-                    inl = (s.inlier_mask[id >> 5] >> (id & 31)) & 1u;
+                    inl = (GPTR(uint32_t, s.inlier_mask)[id >> 5] >> (id & 31)) & 1u;
                 }
                 anyFar = anyFar || (__ballot(far) != 0ull);
                 unsigned long long m = __ballot(inl);
@@ -878,37 +912,469 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
         double r[kRecFields];
 #pragma unroll
         for (int t = 0; t < kRecFields; t++) r[t] = load_rec(rec, lane, t);
-        V3 dir = viewing_ray(c, myu, myv);
-        V3 support = {0, 0, 0};
-        Plane pl;
-        if (mystate == ST_ROAD_MEST) {
-            // PlaneEstimationMEstimator::EstimatePlane (:18-55): direction of least weighted variance
-            V3 center = {r[0], r[1], r[2]};
-            double ev[3];
-            V3 n0;
-            jacobi_eig3(&r[3], ev, n0);
-            if (isnan(center.x) || isnan(center.y) || isnan(center.z)) {
-                double qn = __builtin_nan("");
-                n0 = {qn, qn, qn};
-            }
-            n0 = vnormalized(n0);
-            pl.n = n0;
-            pl.offset = -vdot(n0, center);
-        } else {
-            pl = plane_through({r[0], r[1], r[2]}, {r[3], r[4], r[5]}, {r[6], r[7], r[8]});
+        finish_road(c, mystate == ST_ROAD_TRI, myu, myv, r, mytype, mydepth);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Thread-per-feature path (lane = feature).  With the ~2-10 neighbours a 64-beam cloud gives a 7x10 window, a
+// wave-per-feature design leaves most lanes idle; here every lane walks its own short list.  The only per-thread
+// storage is the neighbour INDEX list in LDS (transposed, bank-conflict free); points are re-read from the cloud
+// (L1/L2 hits) and re-transformed where needed.  All loops over list entries run in the reference's serial order,
+// so even the weighted sums of the road path match the CPU order.  Features whose lists exceed the capacities
+// are flagged and handled by wave_path().
+// ------------------------------------------------------------------------------------------------
+constexpr int kK1Max = 64;  // neighbour list capacity per feature (LDS: 64 entries x 64 lanes x 4 B = 16 KB per wave)
+constexpr int kK2Max = 16;  // longest list the per-thread O(n^2) triangle search accepts
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+#define LST(e) lst[(e) * kWave + lane]
+
+__device__ __forceinline__ V3 cam_point(const Calib& c, const SlotDesc& s, uint32_t orig) {
+    double x, y, z;
+    load_point(s, (long long)orig, x, y, z);
+    return lidar_to_cam(c, x, y, z);
+}
+__device__ __forceinline__ double cam_z(const Calib& c, const SlotDesc& s, uint32_t orig) {
+    double x, y, z;
+    load_point(s, (long long)orig, x, y, z);
+    return c.T[11] + ((c.T[8] * x + c.T[9] * y) + c.T[10] * z);
+}
+
+// Row-major window scan by one thread (NeighborFinderPixel.cpp:60-95): appends the original indices of the
+// occupied cells to the thread's LDS list.  Returns the count (may exceed kK1Max: overflow).
+__device__ int scan_window_thread(const Calib& c, const SlotDesc& s, double u, double v, double halfX, double halfY,
+                                  bool active, uint32_t* lst, int lane) {
+    int x0 = 0, y0 = 0, nx = 0, ny = 0;
+    if (active && isfinite(u) && isfinite(v)) {
+        double a;
+        a = u - halfX;
+        double left = (a < 0.) ? 0. : a;
+        a = u + halfX;
+        double right = ((double)(c.W - 1) < a) ? (double)(c.W - 1) : a;
+        a = v - halfY;
+        double top = (a < 0.) ? 0. : a;
+        a = v + halfY;
+        double bottom = ((double)(c.H - 1) < a) ? (double)(c.H - 1) : a;
+        x0 = (int)left;
+        y0 = (int)top;
+        int x1 = (int)right, y1 = (int)bottom;
+        nx = x1 - x0 + 1;
+        ny = y1 - y0 + 1;
+        if (nx <= 0 || ny <= 0 || x0 < 0 || y0 < 0 || x1 >= c.W || y1 >= c.H) {
+            nx = 0;
+            ny = 0;
         }
-        double depth = -1.0;
-        intersect(c, false, pl, dir, support, depth);  // n0 = direction, n1 = support (swapped, as the reference)
-        int type = MLD_SuccessRoad;
-        int t = apply_thresholds(c, r[9], r[10], depth);
-        if (t) type = t;
-        mytype = type;
-        mydepth = (type == MLD_SuccessRoad) ? depth : -1.0;
+    }
+    const int nymax = uniform(wave_max_i32(ny)), nxmax = uniform(wave_max_i32(nx));
+    int k = 0;
+    for (int r = 0; r < nymax; r++) {
+        const bool rowok = r < ny;
+        const auto* rowp = GPTR(uint32_t, s.map) + ((size_t)(y0 + (rowok ? r : 0)) * (size_t)c.W + (size_t)x0);
+        for (int c0 = 0; c0 < nxmax; c0 += 8) {
+            // two 16-byte loads cover 8 cells; the map allocation is padded so that reading past the window's
+            // last cell stays inside the buffer
+            u32x4_a4 ka = {0, 0, 0, 0}, kb = {0, 0, 0, 0};
+            if (rowok && c0 < nx) ka = *GPTR(u32x4_a4, rowp + c0);
+            if (rowok && c0 + 4 < nx) kb = *GPTR(u32x4_a4, rowp + c0 + 4);
+            uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                bool has = rowok && (c0 + i < nx) && ((key[i] >> kIdxBits) == s.tag);
+                if (has) {
+                    if (k < kK1Max) LST(k) = kIdxMask - (key[i] & kIdxMask);
+                    k++;
+                }
+            }
+        }
+    }
+    return k;
+}
+
+// Max-spanning triangle over the thread's list entries [0, n) (PlaneEstimationCalcMaxSpanningTriangle.cpp:37-100),
+// serial loops, n <= kK2Max.  The wave iterates to the longest list; shorter lanes idle.
+__device__ bool triangle_thread(const Calib& c, const SlotDesc& s, int n, bool want, const uint32_t* lst, int lane, V3& c1,
+                                V3& c2, V3& c3) {
+    bool act = want && n >= 3;
+    int i = 0, j = 1, bi = -1, bj = -1;
+    double best = -1.0;
+    V3 pi = {0, 0, 0};
+    bool fresh = true;
+    while (__any(act)) {
+        if (act) {
+            if (fresh) pi = cam_point(c, s, LST(i));
+            V3 pj = cam_point(c, s, LST(j));
+            double d = vsqnorm(vsub(pi, pj));
+            if (d > best) {
+                best = d;
+                bi = i;
+                bj = j;
+            }
+            j++;
+            fresh = false;
+            if (j >= n) {
+                i++;
+                j = i + 1;
+                fresh = true;
+                if (i >= n - 1) act = false;
+            }
+        }
+    }
+    bool ok = want && n >= 3 && !(best <= 0.0) && bi >= 0;
+    V3 pa = {0, 0, 0}, pb = {0, 0, 0};
+    if (ok) {
+        pa = cam_point(c, s, LST(bi));
+        pb = cam_point(c, s, LST(bj));
+    }
+    int bk = -1;
+    double best2 = -1.0;
+    V3 pkbest = {0, 0, 0};
+    const int lim = ok ? n - 1 : 0;  // last point never considered (:71)
+    const int limmax = uniform(wave_max_i32(lim));
+    for (int kx = 0; kx < limmax; kx++) {
+        if (kx < lim && kx != bi && kx != bj) {
+            V3 pk = cam_point(c, s, LST(kx));
+            double d1 = vsqnorm(vsub(pk, pa));
+            double d2 = vsqnorm(vsub(pk, pb));
+            if (!(d1 <= 0.0) && !(d2 <= 0.0)) {
+                double d = d1 + d2;
+                if (d > best2) {
+                    best2 = d;
+                    bk = kx;
+                    pkbest = pk;
+                }
+            }
+        }
+    }
+    ok = ok && bk >= 0;
+    c1 = pa;
+    c2 = pb;
+    c3 = pkbest;
+    return ok;
+}
+
+__global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restrict__ slots, SlotDesc single,
+                                                         int use_single, Calib c, int n_slots, int per_slot) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int slot, j;
+    decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
+    const SlotDesc s = use_single ? single : slots[slot];
+    const long long f0 = (long long)j * kWave;
+    if (f0 >= s.F) return;
+    const int lane = threadIdx.x;
+    const int nf = (int)((s.F - f0) < (long long)kWave ? (s.F - f0) : (long long)kWave);
+    const bool active = lane < nf;
+    uint32_t* lst = reinterpret_cast<uint32_t*>(smem);
+
+    double myu = 0, myv = 0;
+    if (active) {
+        const auto* q = GPTR(double, s.uv) + 2 * (f0 + lane);
+        myu = q[0];
+        myv = q[1];
+    }
+    int mytype = MLD_Unspecified;
+    double mydepth = -1.0;
+    bool overflow = false;
+
+    if (c.threadPath) {
+        // ---------------- main window (DepthEstimator.cpp:509-576) ----------------
+        int k = scan_window_thread(c, s, myu, myv, c.halfX1, c.halfY1, active, lst, lane);
+        overflow = k > kK1Max;
+        bool live = active && !overflow;  // still being computed by this path
+        if (live && (unsigned)k < c.countMin) {
+            mytype = MLD_RadiusSearchInsufficientPoints;
+            live = false;
+        }
+        int ks = live ? k : 0;
+        double minZ = 1.7976931348623157e308, maxZ = -1.7976931348623157e308;
+        if (c.useHist) {
+            // PointHistogram::FilterPointsMinDistBlob (HistogramPointDepth.cpp:15-123), per thread
+            const int kmax = uniform(wave_max_i32(ks));
+            int md = 0;
+            double dmin = 1.7976931348623157e308;
+            for (int e = 0; e < kmax; e++) {
+                if (e < ks) {
+                    double d = cam_z(c, s, LST(e));
+                    d = (999. < d) ? 999. : d;
+                    int ce = (int)ceil(d);
+                    md = max(md, ce);
+                    dmin = (d < dmin) ? d : dmin;
+                }
+            }
+            const int binCount = (int)((double)md / c.binW + 1.0);
+            bool hfail = binCount <= 1;
+            const double lim = (double)binCount - 1.;
+            int bmin = 0;
+            {
+                double value = (1e10 < dmin) ? 1e10 : dmin;
+                double q = fabs(value / c.binW);
+                bmin = (int)((lim < q) ? lim : q);  // bin index is monotone in d: the smallest d gives the first bin
+            }
+            for (int e = 0; e < kmax; e++) {
+                if (e < ks) {
+                    uint32_t id = LST(e);
+                    double d = cam_z(c, s, id);
+                    d = (999. < d) ? 999. : d;
+                    double value = (1e10 < d) ? 1e10 : d;
+                    double q = fabs(value / c.binW);
+                    int bi = (int)((lim < q) ? lim : q);
+                    int rel = bi - bmin;
+                    rel = rel > 255 ? 255 : rel;
+                    LST(e) = id | ((uint32_t)rel << kIdxBits);
+                }
+            }
+            // scan of the bins (HistogramPointDepth.cpp:70-85) from the first non-empty one
+            int binMaxRel = -1, binMaxVal = -1, binValue = 0, irel = 0;
+            bool run = live && !hfail && ks > 0;
+            while (__any(run)) {
+                if (run) {
+                    if (bmin + irel >= binCount) {
+                        run = false;
+                    } else {
+                        int last = binValue;
+                        int cnt = 0;
+                        for (int e = 0; e < ks; e++) cnt += ((LST(e) >> kIdxBits) == (uint32_t)irel) ? 1 : 0;
+                        binValue = cnt;
+                        if ((binValue > binMaxVal) && (binValue >= c.minCount)) {
+                            binMaxVal = binValue;
+                            binMaxRel = irel;
+                        } else if (binValue < binMaxVal) {
+                            run = false;
+                        }
+                        if (run && (last > 0) && (binValue == 0)) {
+                            hfail = true;
+                            run = false;
+                        }
+                        irel++;
+                        if (irel >= 255) run = false;  // cannot happen: at most ks+1 <= 65 bins are visited
+                    }
+                }
+            }
+            if (binMaxRel < 0) hfail = true;
+            const double lower = (double)(bmin + binMaxRel) * c.binW - 0.0 * c.binW;
+            const double higher = (double)(bmin + binMaxRel) * c.binW + 1.0 * c.binW;
+            int kk = 0;
+            for (int e = 0; e < kmax; e++) {
+                if (e < ks && !hfail) {
+                    uint32_t packed = LST(e);
+                    int rel = (int)(packed >> kIdxBits);
+                    uint32_t id = packed & kIdxMask;
+                    if (rel >= binMaxRel - 1 && rel <= binMaxRel + 1) {  // membership is by [lower, higher), not by bin
+                        double z = cam_z(c, s, id);
+                        double d = (999. < z) ? 999. : z;
+                        if ((d >= lower) && (d < higher)) {
+                            LST(kk) = id;
+                            kk++;
+                            if (z < minZ) minZ = z;
+                            if (z > maxZ) maxZ = z;
+                        }
+                    }
+                }
+            }
+            if (live && hfail) {
+                mytype = MLD_HistogramNoLocalMax;
+                live = false;
+            }
+            ks = live ? kk : 0;
+        } else {
+            const int kmax = uniform(wave_max_i32(ks));
+            for (int e = 0; e < kmax; e++) {
+                if (e < ks) {
+                    double z = cam_z(c, s, LST(e));
+                    if (z < minZ) minZ = z;
+                    if (z > maxZ) maxZ = z;
+                }
+            }
+        }
+
+        // ---- CalculateDepthSegmented (DepthEstimator.cpp:903-1037) ----
+        double r[kRecFields];
+#pragma unroll
+        for (int t = 0; t < kRecFields; t++) r[t] = 0.0;
+        bool pca = false;
+        if (!c.usePCA && c.useTriMax) {
+            if (live && ks > kK2Max) {
+                overflow = true;
+                live = false;
+            }
+            if (live && ks < 3) {
+                mytype = MLD_TriangleNotPlanarInsufficientPoints;
+                live = false;
+            }
+            V3 c1, c2, c3;
+            bool ok = triangle_thread(c, s, ks, live, lst, lane, c1, c2, c3);
+            if (live && !ok) {
+                mytype = MLD_TriangleNotPlanarInsufficientPoints;
+                live = false;
+            }
+            r[0] = c1.x; r[1] = c1.y; r[2] = c1.z;
+            r[3] = c2.x; r[4] = c2.y; r[5] = c2.z;
+            r[6] = c3.x; r[7] = c3.y; r[8] = c3.z;
+        } else {
+            if (live && ks < 3) {
+                mytype = MLD_HistogramNoLocalMax;  // :920-921
+                live = false;
+            }
+            if (c.usePCA) {
+                // Mono_LidarPipeline::PCA::CalculatePCA (PCA.cpp:45-62): mean, scatter, in index order
+                pca = true;
+                const int n = live ? ks : 0;
+                const int nmax = uniform(wave_max_i32(n));
+                double sx = 0, sy = 0, sz = 0;
+                for (int e = 0; e < nmax; e++)
+                    if (e < n) {
+                        V3 p = cam_point(c, s, LST(e));
+                        sx += p.x;
+                        sy += p.y;
+                        sz += p.z;
+                    }
+                const double mx = sx / (double)n, my = sy / (double)n, mz = sz / (double)n;
+                double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+                for (int e = 0; e < nmax; e++)
+                    if (e < n) {
+                        V3 p = cam_point(c, s, LST(e));
+                        double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
+                        c0 += dx * dx;
+                        c1 += dx * dy;
+                        c2 += dx * dz;
+                        c3 += dy * dy;
+                        c4 += dy * dz;
+                        c5 += dz * dz;
+                    }
+                r[0] = mx; r[1] = my; r[2] = mz;
+                r[3] = c0; r[4] = c1; r[5] = c2; r[6] = c3; r[7] = c4; r[8] = c5;
+            } else if (live) {
+                V3 p0 = cam_point(c, s, LST(0)), p1 = cam_point(c, s, LST(1)), p2 = cam_point(c, s, LST(2));
+                r[0] = p0.x; r[1] = p0.y; r[2] = p0.z;
+                r[3] = p1.x; r[4] = p1.y; r[5] = p1.z;
+                r[6] = p2.x; r[7] = p2.y; r[8] = p2.z;
+            }
+        }
+        r[9] = minZ;
+        r[10] = maxZ;
+        if (live) finish_main(c, pca, myu, myv, r, mytype, mydepth);
+
+        // ---------------- road fallback (DepthEstimator.cpp:578-597) ----------------
+        const bool road_on = c.useRoad && s.has_plane;
+        bool cand = road_on && active && !overflow && (mytype != MLD_Success) &&
+                    (mytype != MLD_RadiusSearchInsufficientPoints);
+        if (__any(cand)) {
+            const int resultOld = mytype;
+            int k2 = scan_window_thread(c, s, myu, myv, c.halfX2, c.halfY2, cand, lst, lane);
+            if (cand && k2 > kK1Max) {
+                overflow = true;
+                cand = false;
+            }
+            if (cand && (unsigned)k2 < c.countMin) {
+                mytype = MLD_RadiusSearchInsufficientPoints;
+                mydepth = -1.0;
+                cand = false;
+            }
+            // CalculateDepthSegmentationPlane (DepthEstimator.cpp:782-900) + first M-estimator pass, serial order
+            const int n2 = cand ? k2 : 0;
+            const int n2max = uniform(wave_max_i32(n2));
+            bool far = false;
+            int kk = 0;
+            double zmn = 1.7976931348623157e308, zmx = -1.7976931348623157e308;
+            double xmn = zmn, xmx = zmx;
+            double sw = 0, sx = 0, sy = 0, sz = 0;
+            const V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
+            for (int e = 0; e < n2max; e++) {
+                if (e < n2) {
+                    uint32_t id = LST(e);
+                    V3 p = cam_point(c, s, id);
+                    double xl = c.Tinv[3] + (c.Tinv[0] * p.x + (c.Tinv[1] * p.y + c.Tinv[2] * p.z));
+                    double yl = c.Tinv[7] + (c.Tinv[4] * p.x + (c.Tinv[5] * p.y + c.Tinv[6] * p.z));
+                    double zl = c.Tinv[11] + (c.Tinv[8] * p.x + (c.Tinv[9] * p.y + c.Tinv[10] * p.z));
+                    float xf = (float)xl, yf = (float)yl, zf = (float)zl;
+                    float d = fabsf(s.coeffs[0] * xf + s.coeffs[1] * yf + s.coeffs[2] * zf + s.coeffs[3]);
+                    far = far || ((double)d > c.roadDistThr);
+                    bool inl = (GPTR(uint32_t, s.inlier_mask)[id >> 5] >> (id & 31)) & 1u;
+                    if (inl) {
+                        LST(kk) = id;
+                        kk++;
+                        if (p.z < zmn) zmn = p.z;
+                        if (p.z > zmx) zmx = p.z;
+                        if (p.x < xmn) xmn = p.x;
+                        if (p.x > xmx) xmx = p.x;
+                        double w = 1 / fabs(vdot(pn, p) + s.prior_off);  // PlaneEstimationMEstimator.cpp:32
+                        sx += w * p.x;
+                        sy += w * p.y;
+                        sz += w * p.z;
+                        sw += w;
+                    }
+                }
+            }
+            if (cand && (far || kk < 3)) {
+                mytype = resultOld;  // :591
+                mydepth = -1.0;
+                cand = false;
+            }
+            double rr[kRecFields];
+#pragma unroll
+            for (int t = 0; t < kRecFields; t++) rr[t] = 0.0;
+            rr[9] = zmn;
+            rr[10] = zmx;
+            if (c.roadMode == 0) {
+                const double cx = sx / sw, cy = sy / sw, cz = sz / sw;
+                const int n3 = cand ? kk : 0;
+                const int n3max = uniform(wave_max_i32(n3));
+                double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+                for (int e = 0; e < n3max; e++) {
+                    if (e < n3) {
+                        V3 p = cam_point(c, s, LST(e));
+                        double w = 1 / fabs(vdot(pn, p) + s.prior_off);
+                        double dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
+                        c0 += w * dx * dx;
+                        c1 += w * dx * dy;
+                        c2 += w * dx * dz;
+                        c3 += w * dy * dy;
+                        c4 += w * dy * dz;
+                        c5 += w * dz * dz;
+                    }
+                }
+                rr[0] = cx; rr[1] = cy; rr[2] = cz;
+                rr[3] = c0; rr[4] = c1; rr[5] = c2; rr[6] = c3; rr[7] = c4; rr[8] = c5;
+                if (cand) finish_road(c, false, myu, myv, rr, mytype, mydepth);
+            } else {
+                // RoadDepthEstimatorMaxSpanningTriangle::CalculateDepth (:24-75)
+                if (cand && kk > kK2Max) {
+                    overflow = true;
+                    cand = false;
+                }
+                V3 c1, c2, c3;
+                bool ok = triangle_thread(c, s, kk, cand, lst, lane, c1, c2, c3);
+                if (cand && !ok) {
+                    mytype = MLD_RadiusSearchInsufficientPoints;
+                    mydepth = -1.0;
+                    cand = false;
+                }
+                if (cand) {
+                    double relation = (zmx - zmn) / (xmx - xmn);
+                    if (!(relation >= c.zxMinRel)) {
+                        mytype = MLD_InsufficientRoadPoints;
+                        mydepth = -1.0;
+                        cand = false;
+                    }
+                }
+                rr[0] = c1.x; rr[1] = c1.y; rr[2] = c1.z;
+                rr[3] = c2.x; rr[4] = c2.y; rr[5] = c2.z;
+                rr[6] = c3.x; rr[7] = c3.y; rr[8] = c3.z;
+                if (cand) finish_road(c, true, myu, myv, rr, mytype, mydepth);
+            }
+        }
+    } else {
+        overflow = active;
     }
 
-    if (lane < nf) {
-        s.depth[f0 + lane] = mydepth;
-        if (s.type) s.type[f0 + lane] = mytype;
+    // ---------------- long lists: wave-cooperative path ----------------
+    const unsigned long long om = __ballot(overflow && active);
+    if (om) wave_path(c, s, smem, lane, om, myu, myv, mytype, mydepth);
+
+    if (active) {
+        GPTRW(double, s.depth)[f0 + lane] = mydepth;
+        if (s.type) GPTRW(int32_t, s.type)[f0 + lane] = mytype;
     }
 }
 

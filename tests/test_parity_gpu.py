@@ -9,6 +9,17 @@ from helpers import assert_depth_parity, kitti_camera, make_estimator, make_orac
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["thread+wave", "wave-only"])
+def feature_kernel_path(request, monkeypatch):
+    """Every test runs twice: with the thread-per-feature fast path (long lists overflow to the wave-cooperative
+    path) and with the wave-cooperative path forced for all features (MLD_FORCE_WAVE_PATH is read by mld_create)."""
+    if request.param == "wave-only":
+        monkeypatch.setenv("MLD_FORCE_WAVE_PATH", "1")
+    else:
+        monkeypatch.delenv("MLD_FORCE_WAVE_PATH", raising=False)
+    yield request.param
+
+
 def _frame(scanner, seed, nfeat, frame=0, integer=False, stride=4):
     cloud = synth.make_cloud(scanner, seed=seed, frame=frame, stride_floats=stride)
     uv = synth.make_features(nfeat, seed=seed, integer=integer)
