@@ -196,11 +196,16 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     c.pcaAbsMin = P.pca_treshold_3_abs_min;
     c.pcaRelMax = P.pca_treshold_3_2_rel_max;
     c.pcaRelMin = P.pca_treshold_2_1_rel_min;
-    ctx->lds_bytes = (size_t)cap * (3 * sizeof(double) + 2 * sizeof(int)) + (size_t)kRecFields * kWave * sizeof(double);
+    ctx->lds_bytes = (size_t)cap * (3 * sizeof(double) + 2 * sizeof(int));
     // MLD_FORCE_WAVE_PATH=1 disables the thread-per-feature fast path (tests exercise both code paths)
     const char* force = std::getenv("MLD_FORCE_WAVE_PATH");
     c.threadPath = (force && force[0] == '1') ? 0 : 1;
-    ctx->lds_bytes = std::max(ctx->lds_bytes, (size_t)kK1Max * kWave * sizeof(uint32_t));
+    // list capacity of the thread path: 32 entries (8 KB of LDS per wave) keeps 16+ waves per CU resident;
+    // longer lists overflow to the wave-cooperative path.  MLD_K1MAX overrides (8..64) for experiments.
+    int k1max = 32;
+    if (const char* k = std::getenv("MLD_K1MAX")) k1max = std::atoi(k);
+    c.k1max = std::min(std::max(k1max, 8), kK1MaxLimit);
+    if (c.threadPath) ctx->lds_bytes = std::max(ctx->lds_bytes, (size_t)c.k1max * kWave * sizeof(uint32_t));
 }
 
 int check_slot(mld_ctx* ctx, int slot) {

@@ -37,6 +37,7 @@ struct Calib {
     int useRoad;   // do_use_ransac_plane
     int roadMode;  // 0 = M-estimator, 1 = max spanning triangle
     int usePCA;
+    int k1max;       // thread path: neighbour list capacity per feature (entries in LDS)
     int threadPath;  // 1: thread-per-feature fast path with wave-cooperative overflow; 0: wave path only
 };
 

@@ -710,6 +710,12 @@ __device__ __forceinline__ void finish_road(const Calib& c, bool triangle, doubl
 // Wave-cooperative path: processes the features whose bit is set in `mask` (wave-uniform), one at a time, with
 // all 64 lanes working on that feature's window / neighbour list.  Handles lists of any length (up to the
 // window size); used for the features the thread-per-feature path cannot hold (long lists).
+#define SREC(t, v)                   \
+    do {                             \
+        double v_ = (v);             \
+        if (lane == fi) myr[t] = v_; \
+    } while (0)
+
 __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, unsigned char* smem, const int lane,
                                        const unsigned long long mask, const double myu, const double myv, int& mytype,
                                        double& mydepth) {
@@ -719,7 +725,9 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
     L.z = L.y + c.cap;
     L.idx = reinterpret_cast<int*>(L.z + c.cap);
     L.bin = L.idx + c.cap;
-    double* rec = reinterpret_cast<double*>(L.bin + c.cap);
+    double myr[kRecFields];  // record of the feature this lane owns (values below are wave-uniform)
+#pragma unroll
+    for (int t = 0; t < kRecFields; t++) myr[t] = 0.0;
     const bool inmask = (mask >> lane) & 1ull;
     int mystate = ST_FINAL;
 
@@ -753,28 +761,28 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
                     if (c.usePCA) {
                         double ctr[3], cov[6];
                         moments(ks, L, lane, false, s, ctr, cov, true);
-                        if (lane == 0) {
-                            for (int t = 0; t < 3; t++) store_rec(rec, fi, t, ctr[t]);
-                            for (int t = 0; t < 6; t++) store_rec(rec, fi, 3 + t, cov[t]);
+                        {
+                            for (int t = 0; t < 3; t++) SREC(t, ctr[t]);
+                            for (int t = 0; t < 6; t++) SREC(3 + t, cov[t]);
                         }
                         state = ST_PCA;
                     } else {
-                        if (lane == 0) {
-                            store_rec(rec, fi, 0, L.x[ci]);
-                            store_rec(rec, fi, 1, L.y[ci]);
-                            store_rec(rec, fi, 2, L.z[ci]);
-                            store_rec(rec, fi, 3, L.x[cj]);
-                            store_rec(rec, fi, 4, L.y[cj]);
-                            store_rec(rec, fi, 5, L.z[cj]);
-                            store_rec(rec, fi, 6, L.x[ck]);
-                            store_rec(rec, fi, 7, L.y[ck]);
-                            store_rec(rec, fi, 8, L.z[ck]);
+                        {
+                            SREC(0, L.x[ci]);
+                            SREC(1, L.y[ci]);
+                            SREC(2, L.z[ci]);
+                            SREC(3, L.x[cj]);
+                            SREC(4, L.y[cj]);
+                            SREC(5, L.z[cj]);
+                            SREC(6, L.x[ck]);
+                            SREC(7, L.y[ck]);
+                            SREC(8, L.z[ck]);
                         }
                         state = ST_TRIANGLE;
                     }
-                    if (lane == 0) {
-                        store_rec(rec, fi, 9, mn);
-                        store_rec(rec, fi, 10, mx);
+                    {
+                        SREC(9, mn);
+                        SREC(10, mx);
                     }
                 }
             }
@@ -788,10 +796,7 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
 
     // ---------------- phase 2 (lane = feature) ----------------
     if (mystate == ST_TRIANGLE || mystate == ST_PCA) {
-        double r[kRecFields];
-#pragma unroll
-        for (int t = 0; t < kRecFields; t++) r[t] = load_rec(rec, lane, t);
-        finish_main(c, mystate == ST_PCA, myu, myv, r, mytype, mydepth);
+        finish_main(c, mystate == ST_PCA, myu, myv, myr, mytype, mydepth);
         mystate = ST_FINAL;
     }
 
@@ -852,9 +857,9 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
                 if (c.roadMode == 0) {
                     double ctr[3], cov[6];
                     moments(kk, L, lane, true, s, ctr, cov, false);
-                    if (lane == 0) {
-                        for (int t = 0; t < 3; t++) store_rec(rec, fi, t, ctr[t]);
-                        for (int t = 0; t < 6; t++) store_rec(rec, fi, 3 + t, cov[t]);
+                    {
+                        for (int t = 0; t < 3; t++) SREC(t, ctr[t]);
+                        for (int t = 0; t < 6; t++) SREC(3 + t, cov[t]);
                     }
                     state = ST_ROAD_MEST;
                 } else {
@@ -879,24 +884,24 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
                         if (!(relation >= c.zxMinRel)) {
                             type = MLD_InsufficientRoadPoints;
                         } else {
-                            if (lane == 0) {
-                                store_rec(rec, fi, 0, L.x[ci]);
-                                store_rec(rec, fi, 1, L.y[ci]);
-                                store_rec(rec, fi, 2, L.z[ci]);
-                                store_rec(rec, fi, 3, L.x[cj]);
-                                store_rec(rec, fi, 4, L.y[cj]);
-                                store_rec(rec, fi, 5, L.z[cj]);
-                                store_rec(rec, fi, 6, L.x[ck]);
-                                store_rec(rec, fi, 7, L.y[ck]);
-                                store_rec(rec, fi, 8, L.z[ck]);
+                            {
+                                SREC(0, L.x[ci]);
+                                SREC(1, L.y[ci]);
+                                SREC(2, L.z[ci]);
+                                SREC(3, L.x[cj]);
+                                SREC(4, L.y[cj]);
+                                SREC(5, L.z[cj]);
+                                SREC(6, L.x[ck]);
+                                SREC(7, L.y[ck]);
+                                SREC(8, L.z[ck]);
                             }
                             state = ST_ROAD_TRI;
                         }
                     }
                 }
-                if (state != ST_FINAL && lane == 0) {
-                    store_rec(rec, fi, 9, mn);
-                    store_rec(rec, fi, 10, mx);
+                if (state != ST_FINAL) {
+                    SREC(9, mn);
+                    SREC(10, mx);
                 }
             }
         }
@@ -909,10 +914,7 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
 
     // ---------------- phase 4 (lane = feature) ----------------
     if (mystate == ST_ROAD_MEST || mystate == ST_ROAD_TRI) {
-        double r[kRecFields];
-#pragma unroll
-        for (int t = 0; t < kRecFields; t++) r[t] = load_rec(rec, lane, t);
-        finish_road(c, mystate == ST_ROAD_TRI, myu, myv, r, mytype, mydepth);
+        finish_road(c, mystate == ST_ROAD_TRI, myu, myv, myr, mytype, mydepth);
     }
 }
 
@@ -924,7 +926,8 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
 // so even the weighted sums of the road path match the CPU order.  Features whose lists exceed the capacities
 // are flagged and handled by wave_path().
 // ------------------------------------------------------------------------------------------------
-constexpr int kK1Max = 64;  // neighbour list capacity per feature (LDS: 64 entries x 64 lanes x 4 B = 16 KB per wave)
+constexpr int kK1MaxLimit = 64;  // upper bound of Calib::k1max, the per-feature neighbour list capacity
+                                 // (LDS: k1max entries x 64 lanes x 4 B per wave; relative bins need k1max < 254)
 constexpr int kK2Max = 16;  // longest list the per-thread O(n^2) triangle search accepts
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -943,7 +946,7 @@ __device__ __forceinline__ double cam_z(const Calib& c, const SlotDesc& s, uint3
 }
 
 // Row-major window scan by one thread (NeighborFinderPixel.cpp:60-95): appends the original indices of the
-// occupied cells to the thread's LDS list.  Returns the count (may exceed kK1Max: overflow).
+// occupied cells to the thread's LDS list.  Returns the count (may exceed c.k1max: overflow).
 __device__ int scan_window_thread(const Calib& c, const SlotDesc& s, double u, double v, double halfX, double halfY,
                                   bool active, uint32_t* lst, int lane) {
     int x0 = 0, y0 = 0, nx = 0, ny = 0;
@@ -983,7 +986,7 @@ __device__ int scan_window_thread(const Calib& c, const SlotDesc& s, double u, d
             for (int i = 0; i < 8; i++) {
                 bool has = rowok && (c0 + i < nx) && ((key[i] >> kIdxBits) == s.tag);
                 if (has) {
-                    if (k < kK1Max) LST(k) = kIdxMask - (key[i] & kIdxMask);
+                    if (k < c.k1max) LST(k) = kIdxMask - (key[i] & kIdxMask);
                     k++;
                 }
             }
@@ -1080,7 +1083,7 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
     if (c.threadPath) {
         // ---------------- main window (DepthEstimator.cpp:509-576) ----------------
         int k = scan_window_thread(c, s, myu, myv, c.halfX1, c.halfY1, active, lst, lane);
-        overflow = k > kK1Max;
+        overflow = k > c.k1max;
         bool live = active && !overflow;  // still being computed by this path
         if (live && (unsigned)k < c.countMin) {
             mytype = MLD_RadiusSearchInsufficientPoints;
@@ -1262,7 +1265,7 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
         if (__any(cand)) {
             const int resultOld = mytype;
             int k2 = scan_window_thread(c, s, myu, myv, c.halfX2, c.halfY2, cand, lst, lane);
-            if (cand && k2 > kK1Max) {
+            if (cand && k2 > c.k1max) {
                 overflow = true;
                 cand = false;
             }
