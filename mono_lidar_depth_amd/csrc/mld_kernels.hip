@@ -687,7 +687,8 @@ __device__ __forceinline__ void finish_road(const Calib& c, bool triangle, doubl
         V3 center = {r[0], r[1], r[2]};
         double ev[3];
         V3 n0;
-        jacobi_eig3(&r[3], ev, n0);
+        jacobi_eig3(&r[3], ev, n0);  // (a closed-form eigen-solve cannot separate the two tiny eigenvalues of
+                                     //  nearly collinear road points; Jacobi keeps their relative accuracy)
         if (isnan(center.x) || isnan(center.y) || isnan(center.z)) {
             double qn = __builtin_nan("");
             n0 = {qn, qn, qn};
@@ -945,9 +946,56 @@ __device__ __forceinline__ double cam_z(const Calib& c, const SlotDesc& s, uint3
     return c.T[11] + ((c.T[8] * x + c.T[9] * y) + c.T[10] * z);
 }
 
+// Scans `nymax` window rows in groups of RG rows; a row is covered by NCH chunks of 8 cells (two 16-byte loads
+// each; NCH == 0: any width, chunk loop not unrolled).  The map allocation is padded so that reading past the
+// window's last cell stays inside the buffer.  Appends hits in row-major order.
+template <int RG, int NCH>
+__device__ __forceinline__ void scan_rows(const Calib& c, const SlotDesc& s,
+                                          const uint32_t __attribute__((address_space(1)))* base, int nx, int ny,
+                                          int nymax, int nxmax, uint32_t* lst, int lane, int& k) {
+    constexpr int NC = NCH > 0 ? NCH : 1;
+    const int nchunks = NCH > 0 ? NCH : (nxmax + 7) / 8;
+    for (int r0 = 0; r0 < nymax; r0 += RG) {
+        for (int cc = 0; cc < nchunks; cc += NC) {  // one iteration when NCH > 0
+            uint32_t key[RG][NC][8];
+#pragma unroll
+            for (int q = 0; q < RG; q++) {
+                const bool rowok = (r0 + q) < ny;
+                const auto* rowp = base + (size_t)(rowok ? (r0 + q) : 0) * (size_t)c.W;
+#pragma unroll
+                for (int h = 0; h < NC; h++) {
+                    const int c0 = (cc + h) * 8;
+                    u32x4_a4 ka = {0, 0, 0, 0}, kb = {0, 0, 0, 0};
+                    if (rowok && c0 < nx) ka = *GPTR(u32x4_a4, rowp + c0);
+                    if (rowok && c0 + 4 < nx) kb = *GPTR(u32x4_a4, rowp + c0 + 4);
+                    key[q][h][0] = ka.x; key[q][h][1] = ka.y; key[q][h][2] = ka.z; key[q][h][3] = ka.w;
+                    key[q][h][4] = kb.x; key[q][h][5] = kb.y; key[q][h][6] = kb.z; key[q][h][7] = kb.w;
+                }
+            }
+            // all chunks of the group's rows are in registers: consume row by row (row-major order)
+#pragma unroll
+            for (int q = 0; q < RG; q++) {
+#pragma unroll
+                for (int h = 0; h < NC; h++) {
+                    const int c0 = (cc + h) * 8;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        // cells beyond nx / rows beyond ny were not loaded (key 0 never matches a tag >= 1)
+                        const bool has = (c0 + i < nx) && ((key[q][h][i] >> kIdxBits) == s.tag);
+                        if (has) {
+                            if (k < c.k1max) LST(k) = kIdxMask - (key[q][h][i] & kIdxMask);
+                            k++;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Row-major window scan by one thread (NeighborFinderPixel.cpp:60-95): appends the original indices of the
 // occupied cells to the thread's LDS list.  Returns the count (may exceed c.k1max: overflow).
-__device__ int scan_window_thread(const Calib& c, const SlotDesc& s, double u, double v, double halfX, double halfY,
+__device__ __forceinline__ int scan_window_thread(const Calib& c, const SlotDesc& s, double u, double v, double halfX, double halfY,
                                   bool active, uint32_t* lst, int lane) {
     int x0 = 0, y0 = 0, nx = 0, ny = 0;
     if (active && isfinite(u) && isfinite(v)) {
@@ -971,33 +1019,22 @@ __device__ int scan_window_thread(const Calib& c, const SlotDesc& s, double u, d
         }
     }
     const int nymax = uniform(wave_max_i32(ny)), nxmax = uniform(wave_max_i32(nx));
+    const auto* base = GPTR(uint32_t, s.map) + ((size_t)y0 * (size_t)c.W + (size_t)x0);
     int k = 0;
-    for (int r = 0; r < nymax; r++) {
-        const bool rowok = r < ny;
-        const auto* rowp = GPTR(uint32_t, s.map) + ((size_t)(y0 + (rowok ? r : 0)) * (size_t)c.W + (size_t)x0);
-        for (int c0 = 0; c0 < nxmax; c0 += 8) {
-            // two 16-byte loads cover 8 cells; the map allocation is padded so that reading past the window's
-            // last cell stays inside the buffer
-            u32x4_a4 ka = {0, 0, 0, 0}, kb = {0, 0, 0, 0};
-            if (rowok && c0 < nx) ka = *GPTR(u32x4_a4, rowp + c0);
-            if (rowok && c0 + 4 < nx) kb = *GPTR(u32x4_a4, rowp + c0 + 4);
-            uint32_t key[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                bool has = rowok && (c0 + i < nx) && ((key[i] >> kIdxBits) == s.tag);
-                if (has) {
-                    if (k < c.k1max) LST(k) = kIdxMask - (key[i] & kIdxMask);
-                    k++;
-                }
-            }
-        }
-    }
+    // Rows are independent: the loads of a group of rows are issued before any of them is consumed, so that
+    // the map latency is paid once per group instead of once per row.
+    if (nxmax <= 8)
+        scan_rows<4, 1>(c, s, base, nx, ny, nymax, nxmax, lst, lane, k);
+    else if (nxmax <= 16)
+        scan_rows<2, 2>(c, s, base, nx, ny, nymax, nxmax, lst, lane, k);
+    else
+        scan_rows<1, 0>(c, s, base, nx, ny, nymax, nxmax, lst, lane, k);
     return k;
 }
 
 // Max-spanning triangle over the thread's list entries [0, n) (PlaneEstimationCalcMaxSpanningTriangle.cpp:37-100),
 // serial loops, n <= kK2Max.  The wave iterates to the longest list; shorter lanes idle.
-__device__ bool triangle_thread(const Calib& c, const SlotDesc& s, int n, bool want, const uint32_t* lst, int lane, V3& c1,
+__device__ __forceinline__ bool triangle_thread(const Calib& c, const SlotDesc& s, int n, bool want, const uint32_t* lst, int lane, V3& c1,
                                 V3& c2, V3& c3) {
     bool act = want && n >= 3;
     int i = 0, j = 1, bi = -1, bj = -1;
