@@ -930,6 +930,7 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
 constexpr int kK1MaxLimit = 64;  // upper bound of Calib::k1max, the per-feature neighbour list capacity
                                  // (LDS: k1max entries x 64 lanes x 4 B per wave; relative bins need k1max < 254)
 constexpr int kK2Max = 16;  // longest list the per-thread O(n^2) triangle search accepts
+constexpr int kTriSmall = 8;  // lists up to this length use the fully unrolled in-register triangle search
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -945,6 +946,34 @@ __device__ __forceinline__ double cam_z(const Calib& c, const SlotDesc& s, uint3
     load_point(s, (long long)orig, x, y, z);
     return c.T[11] + ((c.T[8] * x + c.T[9] * y) + c.T[10] * z);
 }
+
+// Raw float point of the cloud and its camera-frame image (same arithmetic as load_point + lidar_to_cam).  The list
+// loops below fetch several raw points before consuming any of them, so that the L2 latency is paid once per
+// group of entries instead of once per entry.
+struct RawP {
+    float x, y, z;
+};
+__device__ __forceinline__ RawP load_raw(const SlotDesc& s, uint32_t i) {
+    const unsigned char* p = s.cloud + (size_t)i * (size_t)s.stride;
+    RawP r;
+    if ((((size_t)s.cloud) & 15) == 0) {
+        f32x4 q = *GPTR(f32x4, p);
+        r.x = q.x;
+        r.y = q.y;
+        r.z = q.z;
+    } else {
+        r.x = GPTR(float, p)[0];
+        r.y = GPTR(float, p)[1];
+        r.z = GPTR(float, p)[2];
+    }
+    return r;
+}
+__device__ __forceinline__ double raw_z(const Calib& c, RawP r) {
+    return c.T[11] + ((c.T[8] * (double)r.x + c.T[9] * (double)r.y) + c.T[10] * (double)r.z);
+}
+__device__ __forceinline__ V3 raw_point(const Calib& c, RawP r) { return lidar_to_cam(c, (double)r.x, (double)r.y, (double)r.z); }
+// list entry e of this lane, or 0 (a valid point index whenever any list is non-empty) beyond the list end
+#define LST_ID(e, n) (((e) < (n)) ? (LST(min((e), c.k1max - 1)) & kIdxMask) : 0u)
 
 // Scans `nymax` window rows in groups of RG rows; a row is covered by NCH chunks of 8 cells (two 16-byte loads
 // each; NCH == 0: any width, chunk loop not unrolled).  The map allocation is padded so that reading past the
@@ -1030,6 +1059,65 @@ __device__ __forceinline__ int scan_window_thread(const Calib& c, const SlotDesc
     else
         scan_rows<1, 0>(c, s, base, nx, ny, nymax, nxmax, lst, lane, k);
     return k;
+}
+
+// Max-spanning triangle for lists of at most M entries, fully unrolled: all M points are fetched in one batch and
+// kept in registers, pairs are visited in the reference's (i,j) order with strict '>' (first maximal pair wins),
+// then the third corner over k < n-1.  One memory round trip instead of one per pair.
+template <int M>
+__device__ __forceinline__ bool triangle_small(const Calib& c, const SlotDesc& s, int n, bool want, const uint32_t* lst,
+                                               int lane, V3& c1, V3& c2, V3& c3) {
+    const int nn = want ? n : 0;
+    RawP rp[M];
+#pragma unroll
+    for (int q = 0; q < M; q++) rp[q] = load_raw(s, LST_ID(q, nn));
+    V3 P[M];
+#pragma unroll
+    for (int q = 0; q < M; q++) P[q] = raw_point(c, rp[q]);
+    double best = -1.0;
+    int bi = -1, bj = -1;
+#pragma unroll
+    for (int i = 0; i < M - 1; i++) {
+#pragma unroll
+        for (int j = i + 1; j < M; j++) {
+            const double d = vsqnorm(vsub(P[i], P[j]));
+            const bool upd = (j < nn) && (d > best);
+            best = upd ? d : best;
+            bi = upd ? i : bi;
+            bj = upd ? j : bj;
+        }
+    }
+    bool ok = (nn >= 3) && !(best <= 0.0) && (bi >= 0);
+    V3 pa = P[0], pb = P[0];
+#pragma unroll
+    for (int q = 1; q < M; q++) {
+        pa.x = (bi == q) ? P[q].x : pa.x;
+        pa.y = (bi == q) ? P[q].y : pa.y;
+        pa.z = (bi == q) ? P[q].z : pa.z;
+        pb.x = (bj == q) ? P[q].x : pb.x;
+        pb.y = (bj == q) ? P[q].y : pb.y;
+        pb.z = (bj == q) ? P[q].z : pb.z;
+    }
+    double best2 = -1.0;
+    int bk = -1;
+    V3 pk = P[0];
+#pragma unroll
+    for (int kx = 0; kx < M - 1; kx++) {  // last point never considered (:71)
+        const double d1 = vsqnorm(vsub(P[kx], pa));
+        const double d2 = vsqnorm(vsub(P[kx], pb));
+        const double d = d1 + d2;
+        const bool upd = ok && (kx < nn - 1) && (kx != bi) && (kx != bj) && !(d1 <= 0.0) && !(d2 <= 0.0) && (d > best2);
+        best2 = upd ? d : best2;
+        bk = upd ? kx : bk;
+        pk.x = upd ? P[kx].x : pk.x;
+        pk.y = upd ? P[kx].y : pk.y;
+        pk.z = upd ? P[kx].z : pk.z;
+    }
+    ok = ok && (bk >= 0);
+    c1 = pa;
+    c2 = pb;
+    c3 = pk;
+    return ok;
 }
 
 // Max-spanning triangle over the thread's list entries [0, n) (PlaneEstimationCalcMaxSpanningTriangle.cpp:37-100),
@@ -1133,13 +1221,18 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
             const int kmax = uniform(wave_max_i32(ks));
             int md = 0;
             double dmin = 1.7976931348623157e308;
-            for (int e = 0; e < kmax; e++) {
-                if (e < ks) {
-                    double d = cam_z(c, s, LST(e));
+            for (int e0 = 0; e0 < kmax; e0 += 4) {
+                RawP rp[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ks));
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    double d = raw_z(c, rp[q]);
                     d = (999. < d) ? 999. : d;
                     int ce = (int)ceil(d);
-                    md = max(md, ce);
-                    dmin = (d < dmin) ? d : dmin;
+                    const bool ok = e0 + q < ks;
+                    md = ok ? max(md, ce) : md;
+                    dmin = (ok && d < dmin) ? d : dmin;
                 }
             }
             const int binCount = (int)((double)md / c.binW + 1.0);
@@ -1151,17 +1244,24 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
                 double q = fabs(value / c.binW);
                 bmin = (int)((lim < q) ? lim : q);  // bin index is monotone in d: the smallest d gives the first bin
             }
-            for (int e = 0; e < kmax; e++) {
-                if (e < ks) {
-                    uint32_t id = LST(e);
-                    double d = cam_z(c, s, id);
+            for (int e0 = 0; e0 < kmax; e0 += 4) {
+                RawP rp[4];
+                uint32_t ids[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    ids[q] = LST_ID(e0 + q, ks);
+                    rp[q] = load_raw(s, ids[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    double d = raw_z(c, rp[q]);
                     d = (999. < d) ? 999. : d;
                     double value = (1e10 < d) ? 1e10 : d;
-                    double q = fabs(value / c.binW);
-                    int bi = (int)((lim < q) ? lim : q);
+                    double qq = fabs(value / c.binW);
+                    int bi = (int)((lim < qq) ? lim : qq);
                     int rel = bi - bmin;
                     rel = rel > 255 ? 255 : rel;
-                    LST(e) = id | ((uint32_t)rel << kIdxBits);
+                    if (e0 + q < ks) LST(e0 + q) = ids[q] | ((uint32_t)rel << kIdxBits);
                 }
             }
             // scan of the bins (HistogramPointDepth.cpp:70-85) from the first non-empty one
@@ -1195,20 +1295,28 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
             const double lower = (double)(bmin + binMaxRel) * c.binW - 0.0 * c.binW;
             const double higher = (double)(bmin + binMaxRel) * c.binW + 1.0 * c.binW;
             int kk = 0;
-            for (int e = 0; e < kmax; e++) {
-                if (e < ks && !hfail) {
-                    uint32_t packed = LST(e);
-                    int rel = (int)(packed >> kIdxBits);
-                    uint32_t id = packed & kIdxMask;
-                    if (rel >= binMaxRel - 1 && rel <= binMaxRel + 1) {  // membership is by [lower, higher), not by bin
-                        double z = cam_z(c, s, id);
-                        double d = (999. < z) ? 999. : z;
-                        if ((d >= lower) && (d < higher)) {
-                            LST(kk) = id;
-                            kk++;
-                            if (z < minZ) minZ = z;
-                            if (z > maxZ) maxZ = z;
-                        }
+            for (int e0 = 0; e0 < kmax; e0 += 4) {
+                RawP rp[4];
+                uint32_t packed[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    packed[q] = (e0 + q < ks) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
+                    rp[q] = load_raw(s, packed[q] & kIdxMask);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int rel = (int)(packed[q] >> kIdxBits);
+                    const uint32_t id = packed[q] & kIdxMask;
+                    const double z = raw_z(c, rp[q]);
+                    const double d = (999. < z) ? 999. : z;
+                    // membership is by [lower, higher), not by bin; only the neighbouring bins can qualify
+                    const bool keep = (e0 + q < ks) && !hfail && (rel >= binMaxRel - 1) && (rel <= binMaxRel + 1) &&
+                                      (d >= lower) && (d < higher);
+                    if (keep) {
+                        LST(kk) = id;  // kk <= e0 + q: entries not yet read are never overwritten
+                        kk++;
+                        if (z < minZ) minZ = z;
+                        if (z > maxZ) maxZ = z;
                     }
                 }
             }
@@ -1219,11 +1327,17 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
             ks = live ? kk : 0;
         } else {
             const int kmax = uniform(wave_max_i32(ks));
-            for (int e = 0; e < kmax; e++) {
-                if (e < ks) {
-                    double z = cam_z(c, s, LST(e));
-                    if (z < minZ) minZ = z;
-                    if (z > maxZ) maxZ = z;
+            for (int e0 = 0; e0 < kmax; e0 += 4) {
+                RawP rp[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ks));
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const double z = raw_z(c, rp[q]);
+                    if (e0 + q < ks) {
+                        if (z < minZ) minZ = z;
+                        if (z > maxZ) maxZ = z;
+                    }
                 }
             }
         }
@@ -1243,7 +1357,17 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
                 live = false;
             }
             V3 c1, c2, c3;
-            bool ok = triangle_thread(c, s, ks, live, lst, lane, c1, c2, c3);
+            bool ok = triangle_small<kTriSmall>(c, s, ks, live && ks <= kTriSmall, lst, lane, c1, c2, c3);
+            if (__any(live && ks > kTriSmall)) {  // rare: longer segmented lists take the generic serial loops
+                V3 d1, d2, d3;
+                bool ok2 = triangle_thread(c, s, ks, live && ks > kTriSmall, lst, lane, d1, d2, d3);
+                if (ks > kTriSmall) {
+                    ok = ok2;
+                    c1 = d1;
+                    c2 = d2;
+                    c3 = d3;
+                }
+            }
             if (live && !ok) {
                 mytype = MLD_TriangleNotPlanarInsufficientPoints;
                 live = false;
@@ -1320,17 +1444,27 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
             double xmn = zmn, xmx = zmx;
             double sw = 0, sx = 0, sy = 0, sz = 0;
             const V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
-            for (int e = 0; e < n2max; e++) {
-                if (e < n2) {
-                    uint32_t id = LST(e);
-                    V3 p = cam_point(c, s, id);
+            for (int e0 = 0; e0 < n2max; e0 += 4) {
+                RawP rp[4];
+                uint32_t ids[4], mw[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    ids[q] = LST_ID(e0 + q, n2);
+                    rp[q] = load_raw(s, ids[q]);
+                    mw[q] = GPTR(uint32_t, s.inlier_mask)[ids[q] >> 5];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                  if (e0 + q < n2) {
+                    const uint32_t id = ids[q];
+                    V3 p = raw_point(c, rp[q]);
                     double xl = c.Tinv[3] + (c.Tinv[0] * p.x + (c.Tinv[1] * p.y + c.Tinv[2] * p.z));
                     double yl = c.Tinv[7] + (c.Tinv[4] * p.x + (c.Tinv[5] * p.y + c.Tinv[6] * p.z));
                     double zl = c.Tinv[11] + (c.Tinv[8] * p.x + (c.Tinv[9] * p.y + c.Tinv[10] * p.z));
                     float xf = (float)xl, yf = (float)yl, zf = (float)zl;
                     float d = fabsf(s.coeffs[0] * xf + s.coeffs[1] * yf + s.coeffs[2] * zf + s.coeffs[3]);
                     far = far || ((double)d > c.roadDistThr);
-                    bool inl = (GPTR(uint32_t, s.inlier_mask)[id >> 5] >> (id & 31)) & 1u;
+                    bool inl = (mw[q] >> (id & 31)) & 1u;
                     if (inl) {
                         LST(kk) = id;
                         kk++;
@@ -1344,6 +1478,7 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
                         sz += w * p.z;
                         sw += w;
                     }
+                  }
                 }
             }
             if (cand && (far || kk < 3)) {
@@ -1361,9 +1496,14 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
                 const int n3 = cand ? kk : 0;
                 const int n3max = uniform(wave_max_i32(n3));
                 double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
-                for (int e = 0; e < n3max; e++) {
-                    if (e < n3) {
-                        V3 p = cam_point(c, s, LST(e));
+                for (int e0 = 0; e0 < n3max; e0 += 4) {
+                    RawP rp[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) rp[q] = load_raw(s, LST_ID(e0 + q, n3));
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                      if (e0 + q < n3) {
+                        V3 p = raw_point(c, rp[q]);
                         double w = 1 / fabs(vdot(pn, p) + s.prior_off);
                         double dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
                         c0 += w * dx * dx;
@@ -1372,6 +1512,7 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
                         c3 += w * dy * dy;
                         c4 += w * dy * dz;
                         c5 += w * dz * dz;
+                      }
                     }
                 }
                 rr[0] = cx; rr[1] = cy; rr[2] = cz;
@@ -1384,7 +1525,17 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
                     cand = false;
                 }
                 V3 c1, c2, c3;
-                bool ok = triangle_thread(c, s, kk, cand, lst, lane, c1, c2, c3);
+                bool ok = triangle_small<kTriSmall>(c, s, kk, cand && kk <= kTriSmall, lst, lane, c1, c2, c3);
+                if (__any(cand && kk > kTriSmall)) {
+                    V3 d1, d2, d3;
+                    bool ok2 = triangle_thread(c, s, kk, cand && kk > kTriSmall, lst, lane, d1, d2, d3);
+                    if (kk > kTriSmall) {
+                        ok = ok2;
+                        c1 = d1;
+                        c2 = d2;
+                        c3 = d3;
+                    }
+                }
                 if (cand && !ok) {
                     mytype = MLD_RadiusSearchInsufficientPoints;
                     mydepth = -1.0;
