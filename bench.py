@@ -34,6 +34,8 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-step", type=int, default=256, help="frame slots processed per step")
+    ap.add_argument("--slots", type=int, default=0,
+                    help="frame slots of the context (0 = frames-per-step); a step runs frames-per-step/slots launch sets")
     ap.add_argument("--unique-frames", type=int, default=16, help="distinct synthetic clouds generated per rank")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -91,6 +93,19 @@ def cpu_baseline(P, cam_struct, T, clouds, planes, uvs, seconds):
     }
 
 
+def pmc_traffic(kernel, frames_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    profiles/summarize.py: FETCH_SIZE/WRITE_SIZE in separate --pmc runs, gfx950 correction applied); None when no
+    profile of the same launch size is on record.  bench.py itself never runs under the profiler."""
+    try:
+        t = json.loads((ROOT / "profiles" / "traffic.json").read_text())
+        if int(t.get("frames_per_launch", -1)) != int(frames_per_launch):
+            return None
+        return float(t[kernel]["hbm_bytes_per_launch"])
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def main():
     args = parse_args()
     import torch
@@ -142,10 +157,19 @@ def main():
     coeffs = np.stack([planes_h[b % U][0] for b in range(B)])
     torch.cuda.synchronize()
 
-    est = DepthEstimator(device=local_rank, max_frames=B)
+    S = args.slots if args.slots > 0 else B
+    assert B % S == 0, "--frames-per-step must be a multiple of --slots"
+    est = DepthEstimator(device=local_rank, max_frames=S)
     est.InitConfig(P)
     est.Initialize(cam, T)
-    batch = est.prepareBatch(t_clouds, t_uvs, t_depth, t_type, coeffs, t_masks, stride_bytes=16)
+    # a step walks the B resident frames in sub-batches of S frame slots (the slots' pixel maps are reused, so
+    # their footprint — S x 1.86 MB — can stay cache-resident while the clouds stream through once)
+    batches = [est.prepareBatch(t_clouds[i:i + S], t_uvs[i:i + S], t_depth[i:i + S], t_type[i:i + S],
+                                coeffs[i:i + S], t_masks[i:i + S], stride_bytes=16) for i in range(0, B, S)]
+
+    def run_step():
+        for b in batches:
+            est.runBatch(b)
 
     def barrier():
         if world > 1:
@@ -153,7 +177,7 @@ def main():
 
     # ---- warm-up, then exactly K timed steps ---------------------------------------------------------------
     for _ in range(args.warmup):
-        est.runBatch(batch)
+        run_step()
     est.synchronize()
     timing = not args.no_kernel_timing
     if timing:
@@ -163,7 +187,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        est.runBatch(batch)
+        run_step()
     est.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -181,17 +205,18 @@ def main():
         return
 
     # ---- statistics for the algorithmic byte count (sampled slots, outside the timed region) -------------
-    stat_slots = list(range(0, B, max(1, B // max(1, args.stat_slots))))[:max(1, args.stat_slots)]
+    stat_slots = list(range(0, S, max(1, S // max(1, args.stat_slots))))[:max(1, args.stat_slots)]
     stats = []
     type_hist = np.zeros(capi.MLD_RESULT_TYPE_COUNT, dtype=np.int64)
     for b in range(B):
         type_hist += est.resultHistogram(t_type[b])
     for b in stat_slots:
+        fr = B - S + b  # the slots hold the last sub-batch of the step
         fb = traffic.frame_bytes(P, cam.width, cam.height, N, est.getVisibleCount(b), est.getPixelMap(b),
-                                 uvs_h[b], t_type[b].cpu().numpy())
+                                 uvs_h[fr], t_type[fr].cpu().numpy())
         stats.append(fb)
-    proj_bytes = float(np.mean([s["project_bytes"] for s in stats])) * B
-    feat_bytes = float(np.mean([s["feature_bytes"] for s in stats])) * B
+    proj_bytes = float(np.mean([s["project_bytes"] for s in stats])) * S  # per launch: S frames
+    feat_bytes = float(np.mean([s["feature_bytes"] for s in stats])) * S
     dominant = "k_feature_depth" if k_feat_ms >= k_proj_ms else "k_project_scatter"
     dom_ms = max(k_feat_ms, k_proj_ms)
     dom_bytes = feat_bytes if dominant == "k_feature_depth" else proj_bytes
@@ -202,7 +227,7 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "traffic": None,  # HBM bytes from rocprofv3 --pmc are recorded in profiles/ (separate passes)
+        "traffic": pmc_traffic(dominant, S),
         "kernel": dominant,
         "kernel_ms": dom_ms,
         "algorithmic_bytes_per_launch": dom_bytes,
@@ -212,7 +237,7 @@ def main():
             "k_feature_depth": {"avg_ms": k_feat_ms, "launches": n_feat, "algorithmic_bytes_per_launch": feat_bytes,
                                 "GBps": (feat_bytes / (k_feat_ms * 1e-3)) / 1e9 if k_feat_ms > 0 else 0.0},
         },
-        "whole_step_GBps": ((proj_bytes + feat_bytes) * args.steps / elapsed) / 1e9,
+        "whole_step_GBps": ((proj_bytes + feat_bytes) * (B // S) * args.steps / elapsed) / 1e9,
     }
 
     cpu = None
@@ -236,8 +261,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": (f"BASELINE config 2: 64x2048 cloud ({N} points) x {F} features/frame, C0 parameters, "
-                         f"{B} device-resident frames per step per GPU, plane-as-input"),
+                         f"{B} device-resident frames per step per GPU in launch sets of {S}, plane-as-input"),
             "frames_per_step": B,
+            "frame_slots_per_launch": S,
             "features_per_frame": F,
             "points_per_frame": N,
             "sequences": world,

@@ -9,7 +9,15 @@ import pandas as pd
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 src = f"gpurun_out/prof_{tag}"
-stats = glob.glob(f"{src}/trace/*/*kernel_stats.csv")[0]
+import os
+
+
+def newest(pattern):
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1] if fs else None
+
+
+stats = newest(f"{src}/trace/*/*kernel_stats.csv")
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 lines = [f"# rocprofv3 summary — {tag}", "",
          "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 "
@@ -34,10 +42,10 @@ lines += ["## PMC (per launch, mean over launches)", "",
           "| kernel | counter | value |", "|---|---|---|"]
 rows = {}
 for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    fs = glob.glob(f"{src}/{d}/*/*_counter_collection.csv")
-    if not fs:
+    f_ = newest(f"{src}/{d}/*/*_counter_collection.csv")
+    if not f_:
         continue
-    df = pd.read_csv(fs[0])
+    df = pd.read_csv(f_)
     df = df[df.Kernel_Name.str.contains("k_feature_depth|k_project_scatter")]
     df["k"] = df.Kernel_Name.str.extract(r"(k_\w+)")
     g = df.groupby(["k", "Counter_Name"]).Counter_Value.mean()
@@ -45,12 +53,20 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
         rows[(k, c)] = v
         lines.append(f"| `{k}` | {c} | {v:,.1f} |")
 lines += ["", "## derived", ""]
+traffic = {}
 for k in ("k_project_scatter", "k_feature_depth"):
     if (k, "FETCH_SIZE") in rows and (k, "WRITE_SIZE") in rows:
         f, w = rows[(k, "FETCH_SIZE")] * 1024, rows[(k, "WRITE_SIZE")] * 1024
         fc = 2 * f if k == "k_project_scatter" else f
         avg = float(ks[ks.Name.str.contains(k)].AverageNs.iloc[0]) * 1e-9
+        traffic[k] = {"fetch_bytes_corrected": fc, "write_bytes": w, "hbm_bytes_per_launch": fc + w, "launch_s": avg}
         lines.append(f"* `{k}`: HBM traffic per launch = {fc / 1e6:,.1f} MB read (corrected) + {w / 1e6:,.1f} MB "
                      f"written = {(fc + w) / 1e6:,.1f} MB -> {(fc + w) / avg / 1e12:.2f} TB/s over the {avg * 1e6:.1f} us launch")
+try:
+    traffic["frames_per_launch"] = b["config"].get("frame_slots_per_launch", b["config"]["frames_per_step"])
+    traffic["source"] = f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
+except Exception as e:  # noqa: BLE001
+    print("traffic.json not written:", e)
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
