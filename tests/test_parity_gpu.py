@@ -222,3 +222,35 @@ def test_batched_slots_match_single_slot():
     for b in range(B):
         _, (d0, t0) = run_oracle(P, clouds[b], uvs[b], planes[b])
         assert_depth_parity(t_depth[b].cpu().numpy(), t_type[b].cpu().numpy(), d0, t0)
+
+
+def test_config5_dense_cloud_integer_features():
+    """BASELINE config 5: 128x4096 cloud (524 288 points), 10 000 integer-pixel features (tracklet-style)."""
+    P = capi.params_c0()
+    cloud, uv, plane = _frame(synth.DENSE128, 77, 10000, integer=True)
+    est = make_estimator(P)
+    depth, types = est.CalculateDepth(cloud, uv, GroundPlane(*plane))
+    _, (d0, t0) = run_oracle(P, cloud, uv, plane, n_threads=8)
+    assert_depth_parity(depth, types, d0, t0)
+    assert (types == 1).sum() > 500
+
+
+def test_full_size_properties_config2():
+    """Size-independent properties at full size: idempotence (same cloud twice), permutation of the feature
+    order permutes the outputs, and a feature's result does not depend on the other features in the call."""
+    P = capi.params_c0()
+    cloud, uv, plane = _frame(synth.HDL64, 88, 2000)
+    est = make_estimator(P)
+    gp = GroundPlane(*plane)
+    d1, t1 = est.CalculateDepth(cloud, uv, gp)
+    d2, t2 = est.CalculateDepth(cloud, uv, gp)
+    assert np.array_equal(d1, d2, equal_nan=True) and np.array_equal(t1, t2)
+    perm = np.random.default_rng(0).permutation(len(uv))
+    d3, t3 = est.CalculateDepth(uv[perm])
+    assert np.array_equal(d3, d1[perm], equal_nan=True) and np.array_equal(t3, t1[perm])
+    d4, t4 = est.CalculateDepth(uv[:137])
+    assert np.array_equal(d4, d1[:137], equal_nan=True) and np.array_equal(t4, t1[:137])
+    # successes lie inside the global window and inside the local z-range tolerance by construction
+    ok = t1 == 1
+    assert (d1[ok] >= 0).all() and (d1[ok] <= 100).all()
+    assert ((t1 != 1) & (t1 != 16) == (d1 == -1)).all()
