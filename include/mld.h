@@ -193,6 +193,32 @@ int mld_calculate_depths_device(mld_ctx* ctx, int n_slots, const double* const* 
                                 double* const* depth_out_dev, int32_t* const* type_out_dev);
 
 /*
+ * Tracklet gather / scatter either side of the path — TrackletDepthModule::process
+ * (tracklets_depth/src/tracklet_depth_module.cpp:23-61 ExractNewTrackletFrames, :63-117 CalculateFeatureDepths*,
+ * :119-169 SaveFeatureDepths).  For n_tracks tracks:
+ *   u_new/v_new : newest feature of every track            (feature_points.at(0), float32 as in the message)
+ *   u_old/v_old : previous feature (feature_points.at(1)); read only where is_new[i] != 0
+ *   is_new      : the track id is not yet in the tracklet map (a new tracklet contributes TWO features)
+ * Features are truncated to integer pixels as the reference's std::pair<int,int> does.  The current frame's
+ * features are evaluated on `slot_cur`, the previous features of NEW tracks on `slot_last` — the previous frame's
+ * slot, whose projection and pixel map are still resident (no re-projection); slot_last = -1: no previous cloud,
+ * those depths are -1 (:93-96).  Both slots must have their cloud (and ground plane) set.
+ *   d_cur_out  : n_tracks float32 depths of the newest features            (FeaturePoint.d)
+ *   d_last_out : n_tracks float32; written only where is_new[i] != 0
+ *   type_*_out : optional int32 result types, same indexing
+ *   n_new_host : optional; receives the number of new tracks (synchronises)
+ * The `_device` form takes device pointers and is asynchronous on the context's stream.
+ */
+int mld_tracklets_depth_device(mld_ctx* ctx, int slot_cur, int slot_last, const float* u_new, const float* v_new,
+                               const float* u_old, const float* v_old, const uint8_t* is_new, int64_t n_tracks,
+                               float* d_cur_out, float* d_last_out, int32_t* type_cur_out, int32_t* type_last_out,
+                               int64_t* n_new_host);
+int mld_tracklets_depth(mld_ctx* ctx, int slot_cur, int slot_last, const float* u_new, const float* v_new,
+                        const float* u_old, const float* v_old, const uint8_t* is_new, int64_t n_tracks,
+                        float* d_cur_out, float* d_last_out, int32_t* type_cur_out, int32_t* type_last_out,
+                        int64_t* n_new_host);
+
+/*
  * Debug / parity getters (host buffers; each synchronises).
  *   mld_get_visible_count           -> _points_cs_image_visible.cols()         (DepthEstimator.cpp:192)
  *   mld_get_visible_image_points    -> getPointsCloudImageCs, 2 x Nvis col-major (:392-394)

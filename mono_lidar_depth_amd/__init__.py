@@ -8,5 +8,7 @@ from .capi import MldCamera, MldParams, params_c0, params_default, params_from_f
 from .depth_estimator import (CameraPinhole, DepthEstimator, DepthEstimatorError, ExceptionPclInvalid,
                               GroundPlane)
 
-__all__ = ["MldCamera", "MldParams", "params_c0", "params_default", "params_from_file", "RESULT_TYPE_NAMES",
+from .tracklets import TrackletDepthModule
+
+__all__ = ["TrackletDepthModule", "MldCamera", "MldParams", "params_c0", "params_default", "params_from_file", "RESULT_TYPE_NAMES",
            "CameraPinhole", "DepthEstimator", "DepthEstimatorError", "ExceptionPclInvalid", "GroundPlane"]

@@ -121,6 +121,10 @@ _SIGNATURES = [
     ("mld_calculate_depth_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("mld_calculate_depths_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64),
                                               _P(C.c_void_p), _P(C.c_void_p)]),
+    ("mld_tracklets_depth_device", C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int64] +
+     [C.c_void_p] * 4 + [_P(C.c_int64)]),
+    ("mld_tracklets_depth", C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int64] +
+     [C.c_void_p] * 4 + [_P(C.c_int64)]),
     ("mld_get_visible_count", C.c_int, [C.c_void_p, C.c_int, _P(C.c_int64)]),
     ("mld_get_visible_image_points", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     ("mld_get_point_index", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),

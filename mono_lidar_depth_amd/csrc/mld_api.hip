@@ -70,6 +70,19 @@ struct mld_ctx {
     std::vector<SlotDesc> h_descs;
     size_t lds_bytes = 0;
     std::string err;
+    // tracklet gather/scatter scratch (device)
+    double* trk_uv_cur = nullptr;
+    double* trk_uv_last = nullptr;
+    double* trk_depth_cur = nullptr;
+    double* trk_depth_last = nullptr;
+    int32_t* trk_type_cur = nullptr;
+    int32_t* trk_type_last = nullptr;
+    int32_t* trk_rank = nullptr;
+    long long* trk_n_new = nullptr;
+    size_t trk_cap = 0;
+    // staging for the host-pointer tracklet entry point
+    unsigned char* trk_stage = nullptr;
+    size_t trk_stage_cap = 0;
     bool timing = false;
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
@@ -510,6 +523,10 @@ void mld_destroy(mld_ctx* ctx) {
             if (p) (void)hipFree(p);
     }
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    void* trk[] = {ctx->trk_uv_cur, ctx->trk_uv_last, ctx->trk_depth_cur, ctx->trk_depth_last, ctx->trk_type_cur,
+                   ctx->trk_type_last, ctx->trk_rank, ctx->trk_n_new, ctx->trk_stage};
+    for (void* p : trk)
+        if (p) (void)hipFree(p);
     for (TimedLaunch& t : ctx->timed) {
         (void)hipEventDestroy(t.e0);
         (void)hipEventDestroy(t.e1);
@@ -710,6 +727,124 @@ int mld_calculate_depths_device(mld_ctx* ctx, int n_slots, const double* const* 
     }
     if ((rc = upload_descs(ctx, n_slots))) return rc;
     return launch_features(ctx, n_slots, max_F, false, 0);
+}
+
+// ---------------------------------------------------------------------------- tracklets
+static int ensure_tracklet_scratch(mld_ctx* ctx, size_t n) {
+    if (n <= ctx->trk_cap && ctx->trk_uv_cur) return MLD_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    void* olds[] = {ctx->trk_uv_cur, ctx->trk_uv_last, ctx->trk_depth_cur, ctx->trk_depth_last, ctx->trk_type_cur,
+                    ctx->trk_type_last, ctx->trk_rank};
+    for (void* p : olds)
+        if (p) HIP_TRY(ctx, hipFree(p));
+    size_t m = n < 1 ? 1 : n;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->trk_uv_cur, m * 2 * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->trk_uv_last, m * 2 * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->trk_depth_cur, m * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->trk_depth_last, m * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->trk_type_cur, m * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->trk_type_last, m * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->trk_rank, m * sizeof(int32_t)));
+    if (!ctx->trk_n_new) HIP_TRY(ctx, hipMalloc((void**)&ctx->trk_n_new, sizeof(long long)));
+    ctx->trk_cap = m;
+    return MLD_OK;
+}
+
+int mld_tracklets_depth_device(mld_ctx* ctx, int slot_cur, int slot_last, const float* u_new, const float* v_new,
+                               const float* u_old, const float* v_old, const uint8_t* is_new, int64_t n_tracks,
+                               float* d_cur_out, float* d_last_out, int32_t* type_cur_out, int32_t* type_last_out,
+                               int64_t* n_new_host) {
+    int rc = check_slot(ctx, slot_cur);
+    if (rc) return rc;
+    if (slot_last >= 0 && (rc = check_slot(ctx, slot_last))) return rc;
+    if (slot_last == slot_cur) return fail(ctx, MLD_ERR_INVALID_ARG, "slot_last must differ from slot_cur");
+    if ((rc = bind_device(ctx))) return rc;
+    if (n_tracks < 0) return fail(ctx, MLD_ERR_INVALID_ARG, "negative track count");
+    if (n_tracks > 0 && (!u_new || !v_new || !u_old || !v_old || !is_new || !d_cur_out || !d_last_out))
+        return fail(ctx, MLD_ERR_INVALID_ARG, "null tracklet array");
+    if ((rc = precheck_calc(ctx, ctx->slots[slot_cur], n_tracks))) return rc;
+    if (slot_last >= 0 && (rc = precheck_calc(ctx, ctx->slots[slot_last], n_tracks))) return rc;
+    if ((rc = ensure_tracklet_scratch(ctx, (size_t)n_tracks))) return rc;
+    if (n_tracks == 0) {
+        if (n_new_host) *n_new_host = 0;
+        return MLD_OK;
+    }
+    hipLaunchKernelGGL(k_tracklet_gather, dim3(1), dim3(kTrkBlock), 0, ctx->stream, u_new, v_new, u_old, v_old, is_new,
+                       (long long)n_tracks, ctx->trk_uv_cur, ctx->trk_uv_last, ctx->trk_rank, ctx->trk_n_new);
+    HIP_TRY(ctx, hipGetLastError());
+    if ((rc = calc_one(ctx, slot_cur, ctx->trk_uv_cur, n_tracks, ctx->trk_depth_cur, ctx->trk_type_cur))) return rc;
+    if (slot_last >= 0) {
+        Slot& sl = ctx->slots[slot_last];
+        sl.d.F_dev = ctx->trk_n_new;  // the number of new tracks is only known on the device
+        rc = calc_one(ctx, slot_last, ctx->trk_uv_last, n_tracks, ctx->trk_depth_last, ctx->trk_type_last);
+        sl.d.F_dev = nullptr;
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_tracklet_scatter, dim3((unsigned)((n_tracks + 255) / 256)), dim3(256), 0, ctx->stream,
+                       ctx->trk_depth_cur, ctx->trk_type_cur, ctx->trk_depth_last, ctx->trk_type_last, ctx->trk_rank,
+                       (long long)n_tracks, slot_last >= 0 ? 1 : 0, d_cur_out, d_last_out, type_cur_out, type_last_out);
+    HIP_TRY(ctx, hipGetLastError());
+    if (n_new_host) {
+        long long nn = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&nn, ctx->trk_n_new, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        *n_new_host = (int64_t)nn;
+    }
+    return MLD_OK;
+}
+
+int mld_tracklets_depth(mld_ctx* ctx, int slot_cur, int slot_last, const float* u_new, const float* v_new,
+                        const float* u_old, const float* v_old, const uint8_t* is_new, int64_t n_tracks,
+                        float* d_cur_out, float* d_last_out, int32_t* type_cur_out, int32_t* type_last_out,
+                        int64_t* n_new_host) {
+    int rc = check_slot(ctx, slot_cur);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    if (n_tracks < 0) return fail(ctx, MLD_ERR_INVALID_ARG, "negative track count");
+    if (n_tracks > 0 && (!u_new || !v_new || !u_old || !v_old || !is_new || !d_cur_out || !d_last_out))
+        return fail(ctx, MLD_ERR_INVALID_ARG, "null tracklet array");
+    const size_t n = (size_t)n_tracks;
+    // staging layout: 4 float inputs | 2 float outputs | 2 int32 outputs | is_new bytes
+    const size_t bytes = n * (4 * 4 + 2 * 4 + 2 * 4 + 1) + 64;
+    if ((rc = grow(ctx, ctx->trk_stage, ctx->trk_stage_cap, bytes))) return rc;
+    float* du0 = reinterpret_cast<float*>(ctx->trk_stage);
+    float *dv0 = du0 + n, *du1 = dv0 + n, *dv1 = du1 + n, *dd0 = dv1 + n, *dd1 = dd0 + n;
+    int32_t* dt0 = reinterpret_cast<int32_t*>(dd1 + n);
+    int32_t* dt1 = dt0 + n;
+    uint8_t* dnew = reinterpret_cast<uint8_t*>(dt1 + n);
+    if (n) {
+        HIP_TRY(ctx, hipMemcpyAsync(du0, u_new, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dv0, v_new, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(du1, u_old, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dv1, v_old, n * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dnew, is_new, n, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(dd1, 0, n * 4, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(dt1, 0, n * 4, ctx->stream));
+    }
+    rc = mld_tracklets_depth_device(ctx, slot_cur, slot_last, du0, dv0, du1, dv1, dnew, n_tracks, dd0, dd1, dt0, dt1,
+                                    nullptr);
+    if (rc) return rc;
+    if (n) {
+        HIP_TRY(ctx, hipMemcpyAsync(d_cur_out, dd0, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (type_cur_out) HIP_TRY(ctx, hipMemcpyAsync(type_cur_out, dt0, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        // d_last / type_last are defined for new tracks only: copy through a host temporary and merge
+        std::vector<float> tmp(n);
+        std::vector<int32_t> tmpt(n);
+        HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), dd1, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(tmpt.data(), dt1, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        int64_t nn = 0;
+        for (size_t i = 0; i < n; i++)
+            if (is_new[i]) {
+                d_last_out[i] = tmp[i];
+                if (type_last_out) type_last_out[i] = tmpt[i];
+                nn++;
+            }
+        if (n_new_host) *n_new_host = nn;
+    } else if (n_new_host) {
+        *n_new_host = 0;
+    }
+    return MLD_OK;
 }
 
 // ---------------------------------------------------------------------------- getters

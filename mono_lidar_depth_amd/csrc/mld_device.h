@@ -49,6 +49,7 @@ struct SlotDesc {
     double* depth;                // F
     int32_t* type;                // F or nullptr
     const uint32_t* inlier_mask;  // bit i = original point i is a ground-plane inlier; nullptr = no plane
+    const long long* F_dev;       // optional device-side feature count (<= F); used when the count is produced on the GPU
     long long n;                  // points
     long long F;                  // features
     double prior_n[3];            // M-estimator prior (normalised lidar-frame normal, DepthEstimator.cpp:286-292)

@@ -1189,9 +1189,14 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
     decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
     const SlotDesc s = use_single ? single : slots[slot];
     const long long f0 = (long long)j * kWave;
-    if (f0 >= s.F) return;
+    long long Fn = s.F;
+    if (s.F_dev) {
+        const long long fd = *GPTR(long long, s.F_dev);
+        Fn = fd < Fn ? fd : Fn;
+    }
+    if (f0 >= Fn) return;
     const int lane = threadIdx.x;
-    const int nf = (int)((s.F - f0) < (long long)kWave ? (s.F - f0) : (long long)kWave);
+    const int nf = (int)((Fn - f0) < (long long)kWave ? (Fn - f0) : (long long)kWave);
     const bool active = lane < nf;
     uint32_t* lst = reinterpret_cast<uint32_t*>(smem);
 
@@ -1584,6 +1589,76 @@ __global__ void k_build_mask(const int32_t* __restrict__ idx, long long n_inl, l
     if (i < n_inl) {
         int id = idx[i];
         if (id >= 0 && (long long)id < n_points) atomicOr(&mask[id >> 5], 1u << (id & 31));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tracklet gather / scatter either side of the path (tracklets_depth/src/tracklet_depth_module.cpp:23-169)
+// ------------------------------------------------------------------------------------------------
+constexpr int kTrkBlock = 1024;
+
+// ExractNewTrackletFrames + CalculateFeatureDepths{Cur,Last}Frame feature marshalling (:23-117):
+//   uv_cur[i]  = (int)newest feature of track i                       (every track, track order)
+//   uv_last[r] = (int)previous feature of the r-th NEW track          (new tracks only, track order)
+// The float -> std::pair<int,int> conversion of the reference truncates toward zero (TempTrackletFrame.h:7-8).
+// One block; the order-preserving ranks of the new tracks come from a chunked ballot scan.
+__global__ __launch_bounds__(kTrkBlock) void k_tracklet_gather(const float* __restrict__ u_new,
+                                                             const float* __restrict__ v_new,
+                                                             const float* __restrict__ u_old,
+                                                             const float* __restrict__ v_old,
+                                                             const uint8_t* __restrict__ is_new, long long n,
+                                                             double* uv_cur, double* uv_last, int32_t* rank,
+                                                             long long* n_new_out) {
+    __shared__ int wsum[kTrkBlock / kWave];
+    __shared__ int base_s;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    const int w = threadIdx.x / kWave;
+    for (long long c0 = 0; c0 < n; c0 += kTrkBlock) {
+        const long long i = c0 + threadIdx.x;
+        const bool in = i < n;
+        const bool nw = in && is_new[i] != 0;
+        const unsigned long long m = __ballot(nw);
+        if ((threadIdx.x & (kWave - 1)) == 0) wsum[w] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int q = 0; q < w; q++) off += wsum[q];
+        const int r = off + prefix_count(m);
+        if (in) {
+            uv_cur[2 * i] = (double)(int)u_new[i];
+            uv_cur[2 * i + 1] = (double)(int)v_new[i];
+            rank[i] = nw ? r : -1;
+            if (nw) {
+                uv_last[2 * (long long)r] = (double)(int)u_old[i];
+                uv_last[2 * (long long)r + 1] = (double)(int)v_old[i];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int t = 0;
+            for (int q = 0; q < kTrkBlock / kWave; q++) t += wsum[q];
+            base_s += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_new_out = base_s;
+}
+
+// SaveFeatureDepths / convert_tracklets_to_matches_msg (:119-169, :209-259): depths back to the tracks as float32
+// FeaturePoint.d (matches_msg_depth_ros/msg/FeaturePoint.msg:3-5).  d_last is written for new tracks only; without
+// a previous cloud their previous-frame depth is -1 (:93-96).
+__global__ void k_tracklet_scatter(const double* __restrict__ depth_cur, const int32_t* __restrict__ type_cur,
+                                   const double* __restrict__ depth_last, const int32_t* __restrict__ type_last,
+                                   const int32_t* __restrict__ rank, long long n, int have_last, float* d_cur_out,
+                                   float* d_last_out, int32_t* type_cur_out, int32_t* type_last_out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    d_cur_out[i] = (float)depth_cur[i];
+    if (type_cur_out) type_cur_out[i] = type_cur[i];
+    const int r = rank[i];
+    if (r >= 0) {
+        d_last_out[i] = have_last ? (float)depth_last[r] : -1.0f;
+        if (type_last_out) type_last_out[i] = have_last ? type_last[r] : (int32_t)MLD_Unspecified;
     }
 }
 

@@ -1,0 +1,89 @@
+"""Python mirror of tracklets_depth::TrackletDepthModule around the DepthEstimator boundary.
+
+Reference: tracklets_depth/src/tracklet_depth_module.cpp — process :261-396, ExractNewTrackletFrames :23-61,
+CalculateFeatureDepthsCurFrame :63-82, CalculateFeatureDepthsLastFrame :84-117, SaveFeatureDepths :119-169,
+TidyUpTracklets :171-193.  The ROS message plumbing is out of scope; tracks arrive as arrays.
+
+What runs on the GPU: the feature gather (newest feature of every track, previous feature of NEW tracks, truncated
+to integer pixels), both CalculateDepth calls and the float32 scatter — one C-ABI call, `mld_tracklets_depth*`.
+The previous frame is NOT re-projected as the reference does (:115 -> setInputCloud): its frame slot (cloud, pixel
+map, ground plane) is kept and the two slots ping-pong.  The tracklet map itself (ids seen so far, per-track
+history) is host bookkeeping, kept here in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import capi
+from .depth_estimator import CameraPinhole, DepthEstimator, GroundPlane, _is_torch_cuda
+
+
+class TrackletDepthModule:
+    def __init__(self, parameters, camera: CameraPinhole, transform_lidar_to_cam, device: int = 0,
+                 keep_history: bool = True):
+        self._est = DepthEstimator(device=device, max_frames=2)
+        self._est.InitConfig(parameters)
+        self._est.Initialize(camera, transform_lidar_to_cam)
+        self._slot_cur = 0
+        self._have_last = False  # _cloud_last_frame != nullptr
+        self._keep_history = keep_history
+        # _trackletMap: id -> list of (u, v, depth), newest first (feature_tracking::Tracklet::push_front)
+        self._tracklet_map: Dict[int, List[Tuple[int, int, float]]] = {}
+
+    @property
+    def estimator(self) -> DepthEstimator:
+        return self._est
+
+    def known_ids(self):
+        return self._tracklet_map.keys()
+
+    def process(self, cloud, ids, u_new, v_new, u_old, v_old, ground_plane: Optional[GroundPlane]):
+        """One frame (tracklet_depth_module.cpp:261-396).
+
+        ids: track ids; u_new/v_new: newest feature of every track (feature_points[0]); u_old/v_old: previous
+        feature (feature_points[1]; only read for tracks that are new to the module).  Returns
+        (d_cur, d_last, is_new): float32 depths of the newest features, float32 depths of the previous features
+        (NaN where the track is not new) and the new-track mask.
+        """
+        est, lib = self._est, self._est._lib
+        ids = np.asarray(ids, dtype=np.int64)
+        n = int(ids.size)
+        known = self._tracklet_map
+        is_new = np.fromiter((int(i) not in known for i in ids), dtype=np.uint8, count=n)  # :31
+        slot_cur = self._slot_cur
+        slot_last = (1 - slot_cur) if self._have_last else -1
+        est.setInputCloud(cloud, ground_plane, slot=slot_cur)  # the only projection of this frame
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (u_new, v_new, u_old, v_old)]
+        d_cur = np.empty(n, dtype=np.float32)
+        d_last = np.full(n, np.nan, dtype=np.float32)
+        t_cur = np.empty(n, dtype=np.int32)
+        t_last = np.zeros(n, dtype=np.int32)
+        n_new = C.c_int64(0)
+        est._check(lib.mld_tracklets_depth(est._ctx, slot_cur, slot_last, *[a.ctypes.data for a in arrs],
+                                           is_new.ctypes.data, n, d_cur.ctypes.data, d_last.ctypes.data,
+                                           t_cur.ctypes.data, t_last.ctypes.data, C.byref(n_new)))
+        self.last_types = (t_cur, t_last)
+        # SaveFeatureDepths (:119-169) + TidyUpTracklets (:171-193)
+        updated = {}
+        ui0, vi0 = arrs[0].astype(np.int32), arrs[1].astype(np.int32)
+        ui1, vi1 = arrs[2].astype(np.int32), arrs[3].astype(np.int32)
+        for i in range(n):
+            tid = int(ids[i])
+            hist = known.get(tid)
+            if hist is None:
+                hist = [(int(ui1[i]), int(vi1[i]), float(d_last[i]))]
+            elif not self._keep_history:
+                hist = []
+            hist.insert(0, (int(ui0[i]), int(vi0[i]), float(d_cur[i])))
+            updated[tid] = hist
+        self._tracklet_map = updated  # tracks without an update this frame are dropped
+        # remember cloud / plane: the current slot becomes the previous one (:348, :357)
+        self._have_last = True
+        self._slot_cur = 1 - slot_cur
+        return d_cur, d_last, is_new.astype(bool)
+
+    def tracklet(self, track_id: int):
+        return list(self._tracklet_map[track_id])

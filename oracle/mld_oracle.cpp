@@ -915,6 +915,44 @@ int orc_trace_feature(orc_frame* h, double u, double v, orc_feature_trace* tr, i
     return MLD_OK;
 }
 
+// TrackletDepthModule::process, the feature marshalling either side of the path
+// (tracklets_depth/src/tracklet_depth_module.cpp): ExractNewTrackletFrames :23-61 (a new track contributes its
+// newest AND its previous feature; std::pair<int,int> truncates the float coordinates), CalculateFeatureDepths
+// CurFrame :63-82 / LastFrame :84-117 (no previous cloud -> -1), SaveFeatureDepths :119-169 (float32 depths).
+int orc_tracklets_depth(orc_frame* cur, orc_frame* last, const float* u_new, const float* v_new, const float* u_old,
+                        const float* v_old, const uint8_t* is_new, int64_t n, float* d_cur, float* d_last,
+                        int32_t* t_cur, int32_t* t_last, int n_threads) {
+    if (!cur || !cur->fr.cloud_set) return MLD_ERR_NOT_INITIALIZED;
+    std::vector<double> uv_cur(2 * n), uv_last;
+    std::vector<int64_t> owner;
+    for (int64_t i = 0; i < n; i++) {
+        uv_cur[2 * i] = static_cast<double>(static_cast<int>(u_new[i]));
+        uv_cur[2 * i + 1] = static_cast<double>(static_cast<int>(v_new[i]));
+        if (is_new[i]) {
+            uv_last.push_back(static_cast<double>(static_cast<int>(u_old[i])));
+            uv_last.push_back(static_cast<double>(static_cast<int>(v_old[i])));
+            owner.push_back(i);
+        }
+    }
+    std::vector<double> dc(n), dl(owner.size(), -1.0);
+    std::vector<int32_t> tc(n), tl(owner.size(), 0);
+    int rc = orc_calculate_depth(cur, uv_cur.data(), n, dc.data(), tc.data(), n_threads);
+    if (rc) return rc;
+    if (last && last->fr.cloud_set && !owner.empty()) {
+        rc = orc_calculate_depth(last, uv_last.data(), static_cast<int64_t>(owner.size()), dl.data(), tl.data(), n_threads);
+        if (rc) return rc;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        d_cur[i] = static_cast<float>(dc[i]);
+        if (t_cur) t_cur[i] = tc[i];
+    }
+    for (size_t r = 0; r < owner.size(); r++) {
+        d_last[owner[r]] = static_cast<float>(dl[r]);
+        if (t_last) t_last[owner[r]] = tl[r];
+    }
+    return MLD_OK;
+}
+
 // ---- component entry points (known-answer tests, micro-vectors) --------------------------------
 
 // PointHistogram::FilterPointsMinDistBlob: returns 1/0; keep[] = positions kept.

@@ -54,6 +54,7 @@ def load() -> C.CDLL:
         getattr(lib, name).restype = None
     lib.orc_trace_feature.argtypes = [C.c_void_p, C.c_double, C.c_double, P(OrcTrace), C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int32]
+    lib.orc_tracklets_depth.argtypes = [C.c_void_p, C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 4 + [C.c_int]
     lib.orc_filter_points_min_dist_blob.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p,
                                                     P(C.c_int32), P(C.c_double), P(C.c_double)]
     lib.orc_get_nearest_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -186,6 +187,22 @@ class OracleDepthEstimator:
         out = np.empty(3)
         self.lib.orc_viewing_ray(self.h, u, v, out.ctypes.data)
         return out
+
+
+def tracklets_depth(cur: OracleDepthEstimator, last, u_new, v_new, u_old, v_old, is_new, n_threads: int = 1):
+    """TrackletDepthModule::process feature marshalling on the CPU (see orc_tracklets_depth)."""
+    arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (u_new, v_new, u_old, v_old)]
+    isn = np.ascontiguousarray(is_new, dtype=np.uint8)
+    n = isn.size
+    d_cur = np.full(n, np.nan, dtype=np.float32)
+    d_last = np.full(n, np.nan, dtype=np.float32)
+    t_cur = np.zeros(n, dtype=np.int32)
+    t_last = np.zeros(n, dtype=np.int32)
+    rc = load().orc_tracklets_depth(cur.h, last.h if last is not None else None, *[a.ctypes.data for a in arrs],
+                                    isn.ctypes.data, n, d_cur.ctypes.data, d_last.ctypes.data, t_cur.ctypes.data,
+                                    t_last.ctypes.data, n_threads)
+    assert rc == 0, rc
+    return d_cur, d_last, t_cur, t_last
 
 
 # ---- component functions -------------------------------------------------------------------------

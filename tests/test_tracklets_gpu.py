@@ -1,0 +1,68 @@
+"""BASELINE config 5 through the tracklet API: 128x4096 cloud, 10 000 tracks (10 % new per frame), three frames.
+
+The GPU module keeps the previous frame's slot (no re-projection); the oracle restates TrackletDepthModule's
+marshalling on the CPU with the previous cloud re-projected as the reference does.  Results must be identical.
+"""
+import numpy as np
+import pytest
+
+from mono_lidar_depth_amd import GroundPlane, TrackletDepthModule, capi, synth
+from oracle import oracle
+
+from helpers import kitti_camera, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _tracks(rng, ids_prev, n_tracks, new_frac, W, H):
+    n_new = int(n_tracks * new_frac) if ids_prev is not None else n_tracks
+    keep = n_tracks - n_new
+    start = (ids_prev.max() + 1) if ids_prev is not None else 0
+    ids = np.concatenate([rng.choice(ids_prev, keep, replace=False) if keep else np.zeros(0, np.int64),
+                          np.arange(start, start + n_new)]).astype(np.int64)
+    rng.shuffle(ids)
+    u0 = rng.uniform(-2, W + 2, n_tracks).astype(np.float32)
+    v0 = rng.uniform(100, H + 2, n_tracks).astype(np.float32)
+    u1 = (u0 + rng.normal(0, 3, n_tracks)).astype(np.float32)
+    v1 = (v0 + rng.normal(0, 2, n_tracks)).astype(np.float32)
+    return ids, u0, v0, u1, v1
+
+
+@pytest.mark.parametrize("scanner,n_tracks", [(synth.DENSE128, 10000), (synth.VLP16, 3000)])
+def test_tracklet_module_sequence(scanner, n_tracks):
+    P = capi.params_c0()
+    cam = kitti_camera()
+    mod = TrackletDepthModule(P, cam, synth.T_CAM_LIDAR)
+    rng = np.random.default_rng(3)
+    ids_prev = None
+    ref_last = None
+    known = set()
+    for frame in range(3):
+        cloud = synth.make_cloud(scanner, seed=14, frame=frame * 2)
+        coeffs, inl = synth.make_ground_plane(cloud)
+        ids, u0, v0, u1, v1 = _tracks(rng, ids_prev, n_tracks, 0.10, cam.width, cam.height)
+        d_cur, d_last, is_new = mod.process(cloud, ids, u0, v0, u1, v1, GroundPlane(coeffs, inl))
+
+        ref_cur = make_oracle(P)
+        ref_cur.set_cloud(cloud)
+        ref_cur.set_ground_plane(coeffs, inl)
+        exp_new = np.array([int(i) not in known for i in ids])
+        assert np.array_equal(is_new, exp_new)
+        e_cur, e_last, et_cur, et_last = oracle.tracklets_depth(ref_cur, ref_last, u0, v0, u1, v1, exp_new, n_threads=8)
+        t_cur, t_last = mod.last_types
+        assert np.array_equal(t_cur, et_cur)
+        assert np.allclose(d_cur, e_cur, rtol=0, atol=1e-4, equal_nan=True)
+        assert np.array_equal(t_last[is_new], et_last[is_new])
+        assert np.allclose(d_last[is_new], e_last[is_new], rtol=0, atol=1e-4, equal_nan=True)
+        assert np.isnan(d_last[~is_new]).all()
+        if frame == 0:
+            assert (d_last[is_new] == -1).all()  # no previous cloud (:93-96)
+        else:
+            assert is_new.sum() == int(n_tracks * 0.10)
+        # bookkeeping: only the tracks of this frame survive (TidyUpTracklets), new ones hold two features
+        known = set(int(i) for i in ids)
+        assert set(mod.known_ids()) == known
+        i_new = int(np.nonzero(is_new)[0][0])
+        h = mod.tracklet(int(ids[i_new]))
+        assert len(h) == 2 and h[0][:2] == (int(u0[i_new]), int(v0[i_new])) and h[1][:2] == (int(u1[i_new]), int(v1[i_new]))
+        ids_prev, ref_last = ids, ref_cur
