@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLD_ABI_VERSION 1
+#define MLD_ABI_VERSION 2
 
 typedef enum mld_status {
     MLD_OK = 0,
@@ -82,8 +82,8 @@ typedef struct mld_camera {
 
 /*
  * The fields of DepthEstimatorParameters (DepthEstimatorParameters.h:7-173) that steer the hot
- * path, same names (including the reference's spelling).  Fields the path never reads (kd-tree,
- * region growing, RANSAC-estimation and debug knobs) are not mirrored.
+ * path and the per-frame ground-plane estimator, same names (including the reference's spelling).
+ * Fields the path never reads (kd-tree, region growing, debug knobs) are not mirrored.
  * Layout: all doubles first, then int32s — no implicit padding except the tail.
  */
 typedef struct mld_params {
@@ -93,6 +93,11 @@ typedef struct mld_params {
     double pca_treshold_3_2_rel_max;             /* :103 */
     double pca_treshold_2_1_rel_min;             /* :104 */
     double ransac_plane_point_distance_treshold; /* :122 */
+    double ransac_plane_distance_treshold;       /* :114  RANSAC inlier distance (ground-plane estimation) */
+    double ransac_plane_min_z;                   /* :115 */
+    double ransac_plane_max_z;                   /* :116 */
+    double ransac_plane_refinement_treshold;     /* :119 */
+    double ransac_plane_probability;             /* :124 */
     double plane_estimator_z_x_min_relation;     /* :141 */
     double triangleplanar_crossnorm_treshold;    /* :154 */
     double viewray_plane_orthoganality_treshold; /* :155 */
@@ -119,6 +124,8 @@ typedef struct mld_params {
     int32_t do_use_triangle_size_maximation;     /* :152 */
     int32_t do_check_triangleplanar_condition;   /* :153 */
     int32_t set_all_depths_to_zero;              /* :156 */
+    int32_t ransac_plane_max_iterations;         /* :117 */
+    int32_t ransac_plane_use_refinement;         /* :118 */
     int32_t reserved_;
 } mld_params;
 
@@ -172,6 +179,16 @@ int mld_set_ground_plane(mld_ctx* ctx, int slot, const float coeffs[4], const in
                          int64_t n_inliers);
 int mld_set_ground_plane_device(mld_ctx* ctx, int slot, const float coeffs[4], const int32_t* inlier_idx_dev,
                                 int64_t n_inliers);
+/*
+ * RansacPlane::CalculateInliersPlane on the GPU (monolidar_fusion/src/RansacPlane.cpp:41-140) — what setInputCloud
+ * runs when the GroundPlane handed in is not segmented yet (DepthEstimator.cpp:275-283).  Estimates the plane of
+ * the slot's cloud (parameters ransac_plane_*), installs it as the slot's ground plane and returns the
+ * coefficients and the inlier count.  `seed` makes the random draws reproducible (the reference is time-seeded).
+ * Synchronises.  MLD_ERR_CLOUD_TOO_SMALL: fewer than 3 usable points / no model (ExceptionPclInvalid).
+ */
+int mld_estimate_ground_plane(mld_ctx* ctx, int slot, uint32_t seed, float coeffs_out[4], int64_t* n_inliers_out);
+/* The slot's current inlier set as ascending original indices (GroundPlane::getInlinersIndex). */
+int mld_get_ground_plane_inliers(mld_ctx* ctx, int slot, int32_t* index_out, int64_t capacity, int64_t* n_out);
 /* Same, with the inlier set already as a device bitmask (bit i of word i/32 = point i is an inlier). */
 int mld_set_ground_plane_mask_device(mld_ctx* ctx, int slot, const float coeffs[4], const uint32_t* mask_dev);
 /* Slots [0, n_slots): coeffs is n_slots x 4 (host), mask_dev a host array of device bitmask pointers. */

@@ -5,10 +5,10 @@ method names), depth_estimator.py (Python mirror used by tests and bench), synth
 sharding.py (sequence -> GPU assignment and the calibration broadcast).
 """
 from .capi import MldCamera, MldParams, params_c0, params_default, params_from_file, RESULT_TYPE_NAMES
-from .depth_estimator import (CameraPinhole, DepthEstimator, DepthEstimatorError, ExceptionPclInvalid,
-                              GroundPlane)
+from .depth_estimator import (NO_PLANE, CameraPinhole, DepthEstimator, DepthEstimatorError, ExceptionPclInvalid,
+                              GroundPlane, RansacPlane)
 
 from .tracklets import TrackletDepthModule
 
 __all__ = ["TrackletDepthModule", "MldCamera", "MldParams", "params_c0", "params_default", "params_from_file", "RESULT_TYPE_NAMES",
-           "CameraPinhole", "DepthEstimator", "DepthEstimatorError", "ExceptionPclInvalid", "GroundPlane"]
+           "NO_PLANE", "RansacPlane", "CameraPinhole", "DepthEstimator", "DepthEstimatorError", "ExceptionPclInvalid", "GroundPlane"]

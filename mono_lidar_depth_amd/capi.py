@@ -53,6 +53,11 @@ class MldParams(C.Structure):
         ("pca_treshold_3_2_rel_max", C.c_double),
         ("pca_treshold_2_1_rel_min", C.c_double),
         ("ransac_plane_point_distance_treshold", C.c_double),
+        ("ransac_plane_distance_treshold", C.c_double),
+        ("ransac_plane_min_z", C.c_double),
+        ("ransac_plane_max_z", C.c_double),
+        ("ransac_plane_refinement_treshold", C.c_double),
+        ("ransac_plane_probability", C.c_double),
         ("plane_estimator_z_x_min_relation", C.c_double),
         ("triangleplanar_crossnorm_treshold", C.c_double),
         ("viewray_plane_orthoganality_treshold", C.c_double),
@@ -79,6 +84,8 @@ class MldParams(C.Structure):
         ("do_use_triangle_size_maximation", C.c_int32),
         ("do_check_triangleplanar_condition", C.c_int32),
         ("set_all_depths_to_zero", C.c_int32),
+        ("ransac_plane_max_iterations", C.c_int32),
+        ("ransac_plane_use_refinement", C.c_int32),
         ("reserved_", C.c_int32),
     ]
 
@@ -115,6 +122,8 @@ _SIGNATURES = [
     ("mld_set_clouds_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64), C.c_int]),
     ("mld_set_ground_plane", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p, C.c_int64]),
     ("mld_set_ground_plane_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p, C.c_int64]),
+    ("mld_estimate_ground_plane", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, _P(C.c_float), _P(C.c_int64)]),
+    ("mld_get_ground_plane_inliers", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     ("mld_set_ground_plane_mask_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p]),
     ("mld_set_ground_planes_mask_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), _P(C.c_void_p)]),
     ("mld_calculate_depth", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

@@ -15,6 +15,7 @@
 #include "../../include/mld.h"
 #include "mld_device.h"
 #include "mld_kernels.hip"
+#include "mld_ransac.hip"
 
 using namespace mld;
 
@@ -70,6 +71,19 @@ struct mld_ctx {
     std::vector<SlotDesc> h_descs;
     size_t lds_bytes = 0;
     std::string err;
+    // ground-plane estimation scratch (device)
+    int32_t* rs_flags = nullptr;
+    int32_t* rs_cand = nullptr;
+    int32_t* rs_block = nullptr;
+    size_t rs_cap = 0;
+    int32_t* rs_M = nullptr;
+    int32_t* rs_S = nullptr;
+    int32_t* rs_sample = nullptr;
+    float* rs_sp = nullptr;
+    int32_t* rs_counts = nullptr;
+    size_t rs_counts_cap = 0;
+    int32_t* rs_inl = nullptr;
+    ransac::Result* rs_res = nullptr;
     // tracklet gather/scatter scratch (device)
     double* trk_uv_cur = nullptr;
     double* trk_uv_last = nullptr;
@@ -523,6 +537,10 @@ void mld_destroy(mld_ctx* ctx) {
             if (p) (void)hipFree(p);
     }
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    void* rsp[] = {ctx->rs_flags, ctx->rs_cand, ctx->rs_block, ctx->rs_M, ctx->rs_S, ctx->rs_sample, ctx->rs_sp,
+                   ctx->rs_counts, ctx->rs_inl, ctx->rs_res};
+    for (void* p : rsp)
+        if (p) (void)hipFree(p);
     void* trk[] = {ctx->trk_uv_cur, ctx->trk_uv_last, ctx->trk_depth_cur, ctx->trk_depth_last, ctx->trk_type_cur,
                    ctx->trk_type_last, ctx->trk_rank, ctx->trk_n_new, ctx->trk_stage};
     for (void* p : trk)
@@ -614,6 +632,100 @@ int mld_set_ground_plane(mld_ctx* ctx, int slot, const float coeffs[4], const in
         HIP_TRY(ctx, hipMemcpyAsync(s.inl_buf, inlier_idx_host, (size_t)n_inliers * sizeof(int32_t),
                                     hipMemcpyHostToDevice, ctx->stream));
     return build_mask_from_indices(ctx, s, s.inl_buf, n_inliers);
+}
+
+int mld_estimate_ground_plane(mld_ctx* ctx, int slot, uint32_t seed, float coeffs_out[4], int64_t* n_inliers_out) {
+    using namespace ransac;
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    if (!s.cloud_set) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "ground plane estimation before the slot's cloud");
+    const mld_params& P = ctx->P;
+    const long long n = s.d.n;
+    if (n < 3) return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");  // :44-50
+    const int n_draws = P.ransac_plane_max_iterations + 1;
+    if (n_draws < 1) return fail(ctx, MLD_ERR_INVALID_ARG, "ransac_plane_max_iterations must be >= 0");
+    // scratch
+    if (!ctx->rs_res) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_M, sizeof(int32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_S, sizeof(int32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_sample, kSample * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_sp, kSample * 3 * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_inl, kSample * sizeof(int32_t)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_res, sizeof(Result)));
+    }
+    if ((size_t)n_draws > ctx->rs_counts_cap) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->rs_counts) HIP_TRY(ctx, hipFree(ctx->rs_counts));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_counts, (size_t)n_draws * sizeof(int32_t)));
+        ctx->rs_counts_cap = (size_t)n_draws;
+    }
+    const bool pass = P.ransac_plane_min_z > -1001.;  // RansacPlane.cpp:57
+    if (pass) {
+        if ((size_t)n > ctx->rs_cap) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            void* olds[] = {ctx->rs_flags, ctx->rs_cand, ctx->rs_block};
+            for (void* p : olds)
+                if (p) HIP_TRY(ctx, hipFree(p));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_flags, (size_t)n * sizeof(int32_t)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_cand, (size_t)n * sizeof(int32_t)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_block, ((size_t)n / kScanBlock + 1) * sizeof(int32_t)));
+            ctx->rs_cap = (size_t)n;
+        }
+        const int nb = (int)((n + kScanBlock - 1) / kScanBlock);
+        hipLaunchKernelGGL(k_rs_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, s.d.cloud, n,
+                           s.d.stride, (float)P.ransac_plane_min_z, (float)P.ransac_plane_max_z, ctx->rs_flags);
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(kScanBlock), 0, ctx->stream, ctx->rs_flags, n, ctx->rs_block);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, ctx->stream, ctx->rs_block, nb, ctx->rs_M);
+        hipLaunchKernelGGL(k_rs_compact, dim3(nb), dim3(kScanBlock), 0, ctx->stream, ctx->rs_flags, n, ctx->rs_block,
+                           ctx->rs_cand);
+    }
+    hipLaunchKernelGGL(k_rs_sample, dim3((kSample + 255) / 256), dim3(256), 0, ctx->stream, s.d.cloud, s.d.stride,
+                       pass ? ctx->rs_cand : (int32_t*)nullptr, ctx->rs_M, n, seed, ctx->rs_sample, ctx->rs_sp, ctx->rs_S);
+    hipLaunchKernelGGL(k_rs_hypotheses, dim3((unsigned)n_draws), dim3(kWave), 0, ctx->stream, ctx->rs_sp, ctx->rs_S, seed,
+                       n_draws, P.ransac_plane_distance_treshold, ctx->rs_counts);
+    hipLaunchKernelGGL(k_rs_select, dim3(1), dim3(64), 0, ctx->stream, ctx->rs_counts, ctx->rs_sp, ctx->rs_S, seed,
+                       n_draws, P.ransac_plane_max_iterations, P.ransac_plane_probability, ctx->rs_res);
+    const size_t words = (size_t)((n + 31) / 32);
+    if ((rc = grow(ctx, s.mask_buf, s.mask_words, words))) return rc;
+    HIP_TRY(ctx, hipMemsetAsync(s.mask_buf, 0, words * sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(k_rs_refine, dim3(1), dim3(kPartials), 0, ctx->stream, ctx->rs_sp, ctx->rs_sample,
+                       P.ransac_plane_distance_treshold, P.ransac_plane_refinement_treshold,
+                       P.ransac_plane_use_refinement, ctx->rs_inl, s.mask_buf, ctx->rs_res);
+    HIP_TRY(ctx, hipGetLastError());
+    Result res;
+    HIP_TRY(ctx, hipMemcpyAsync(&res, ctx->rs_res, sizeof(Result), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (res.status != 0) return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");
+    rc = set_plane_common(ctx, s, res.coeffs);
+    if (rc) return rc;
+    s.d.inlier_mask = s.mask_buf;
+    if (coeffs_out)
+        for (int t = 0; t < 4; t++) coeffs_out[t] = res.coeffs[t];
+    if (n_inliers_out) *n_inliers_out = res.n_inliers;
+    return MLD_OK;
+}
+
+int mld_get_ground_plane_inliers(mld_ctx* ctx, int slot, int32_t* index_out, int64_t capacity, int64_t* n_out) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    if (!s.cloud_set || !s.d.has_plane || !s.d.inlier_mask) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "no ground plane set");
+    const size_t words = (size_t)((s.d.n + 31) / 32);
+    std::vector<uint32_t> m(words);
+    HIP_TRY(ctx, hipMemcpyAsync(m.data(), s.d.inlier_mask, words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t k = 0;
+    for (long long i = 0; i < s.d.n; i++)
+        if ((m[(size_t)i >> 5] >> (i & 31)) & 1u) {
+            if (index_out && k < capacity) index_out[k] = (int32_t)i;
+            k++;
+        }
+    if (n_out) *n_out = k;
+    if (index_out && k > capacity) return fail(ctx, MLD_ERR_CAPACITY, "output buffer too small");
+    return MLD_OK;
 }
 
 int mld_set_ground_plane_mask_device(mld_ctx* ctx, int slot, const float coeffs[4], const uint32_t* mask_dev) {

@@ -37,6 +37,13 @@ void mld_params_default(mld_params* p) {
     p->pca_treshold_2_1_rel_min = 0.5;
     p->do_use_ransac_plane = 1;
     p->ransac_plane_point_distance_treshold = 0.2;
+    p->ransac_plane_distance_treshold = 0.2;
+    p->ransac_plane_min_z = -10000;
+    p->ransac_plane_max_z = 10000;
+    p->ransac_plane_max_iterations = 10000;
+    p->ransac_plane_use_refinement = 1;
+    p->ransac_plane_refinement_treshold = 10.2;
+    p->ransac_plane_probability = 0.999;
     p->plane_estimator_use_triangle_maximation = 0;
     p->plane_estimator_z_x_min_relation = 0;
     p->plane_estimator_use_leastsquares = 0;
@@ -60,6 +67,9 @@ void mld_params_c0(mld_params* p) {
     p->histogram_segmentation_min_pointcount = 3;
     p->pca_treshold_2_1_rel_min = 1.5;
     p->viewray_plane_orthoganality_treshold = 0.03;
+    p->ransac_plane_distance_treshold = 0.3;
+    // ransac_plane_min_z / max_z are absent from the yaml: fromFile reads them as 0 (see mld_params_from_file);
+    // C0 keeps the header defaults so that the z pass-through stays off as in DepthEstimator.cpp:282
 }
 
 namespace {
@@ -95,6 +105,13 @@ const Field kFields[] = {
     FD(pca_treshold_2_1_rel_min),
     FI(do_use_ransac_plane),
     FD(ransac_plane_point_distance_treshold),
+    FD(ransac_plane_distance_treshold),
+    FD(ransac_plane_min_z),
+    FD(ransac_plane_max_z),
+    FI(ransac_plane_max_iterations),
+    FI(ransac_plane_use_refinement),
+    FD(ransac_plane_refinement_treshold),
+    FD(ransac_plane_probability),
     FI(plane_estimator_use_triangle_maximation),
     FD(plane_estimator_z_x_min_relation),
     FI(plane_estimator_use_leastsquares),
@@ -116,7 +133,8 @@ bool is_bool_field(const char* key) {
                                   "do_use_ransac_plane", "plane_estimator_use_triangle_maximation",
                                   "plane_estimator_use_leastsquares", "plane_estimator_use_mestimator",
                                   "do_use_cut_behind_camera", "do_use_triangle_size_maximation",
-                                  "do_check_triangleplanar_condition", "set_all_depths_to_zero"};
+                                  "do_check_triangleplanar_condition", "set_all_depths_to_zero",
+                                  "ransac_plane_use_refinement"};
     for (const char* k : kBool)
         if (std::strcmp(k, key) == 0) return true;
     return false;

@@ -1,0 +1,325 @@
+// Per-frame ground plane on the GPU: RansacPlane::CalculateInliersPlane (monolidar_fusion/src/RansacPlane.cpp:41-140).
+//
+// SURVEY.md §8(f)-1, a "next" row: the plane used to be an input only.  The pipeline of the reference is kept —
+// optional z pass-through (:57-64), sub-sample to 6000 points (:66-74), perpendicular-plane RANSAC around the z axis
+// with PCL's adaptive iteration bound (:94-108), least-squares refinement and re-selection within
+// ransac_plane_refinement_treshold of the UNREFINED model (:117-126), inlier lookup keyed by original index
+// (:128-133, here the bitmask the feature kernel reads).  PARITY UNPINNED against PCL: the reference's RandomSample
+// is time-seeded, i.e. not reproducible; draws here come from a counter-based hash (bit-identical to the CPU
+// restatement used by the tests), so all hypotheses are independent and evaluated in parallel, and PCL's
+// sequential stopping rule is applied afterwards to the per-draw inlier counts.
+#include "mld_device.h"
+
+namespace mld {
+namespace ransac {
+
+constexpr int kSample = 6000;  // RansacPlane.cpp:32
+constexpr int kPartials = 256;
+
+__host__ __device__ inline uint32_t mix(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t h = a * 0x9E3779B1u;
+    h ^= b + 0x85EBCA6Bu + (h << 6) + (h >> 2);
+    h ^= c * 0xC2B2AE35u + (h << 6) + (h >> 2);
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+struct Model {
+    float c[4];
+    int degenerate;
+    int valid;
+};
+
+// sac_model_plane computeModelCoefficients + sac_model_perpendicular_plane isModelValid, float arithmetic
+__device__ inline Model plane_from(const float* p0, const float* p1, const float* p2) {
+    Model m;
+    float a0 = p1[0] - p0[0], a1 = p1[1] - p0[1], a2 = p1[2] - p0[2];
+    float b0 = p2[0] - p0[0], b1 = p2[1] - p0[1], b2 = p2[2] - p0[2];
+    float r0 = a0 / b0, r1 = a1 / b1, r2 = a2 / b2;
+    m.degenerate = ((r0 == r1) && (r2 == r1)) ? 1 : 0;
+    float n0 = a1 * b2 - a2 * b1, n1 = a2 * b0 - a0 * b2, n2 = a0 * b1 - a1 * b0;
+    float nn = sqrtf(n0 * n0 + n1 * n1 + n2 * n2);
+    n0 /= nn;
+    n1 /= nn;
+    n2 /= nn;
+    m.c[0] = n0;
+    m.c[1] = n1;
+    m.c[2] = n2;
+    m.c[3] = -1.0f * (n0 * p0[0] + n1 * p0[1] + n2 * p0[2]);
+    if (!(nn > 0.0f) || !isfinite(nn)) m.degenerate = 1;
+    m.valid = (!m.degenerate && (fabs((double)n2) >= 0.984807753012208)) ? 1 : 0;  // cos(pi/18): 10 degrees
+    return m;
+}
+__device__ inline float plane_dist(const float c[4], const float* p) {
+    return fabsf(c[0] * p[0] + c[1] * p[1] + c[2] * p[2] + c[3]);
+}
+__device__ inline Model draw_model(const float* sp, int S, uint32_t seed, int d) {
+    uint32_t a = mix(seed, (uint32_t)d, 1u) % (uint32_t)S;
+    uint32_t b = mix(seed, (uint32_t)d, 2u) % (uint32_t)S;
+    uint32_t c = mix(seed, (uint32_t)d, 3u) % (uint32_t)S;
+    if (b == a) b = (b + 1) % (uint32_t)S;
+    while (c == a || c == b) c = (c + 1) % (uint32_t)S;
+    return plane_from(sp + 3 * a, sp + 3 * b, sp + 3 * c);
+}
+
+// pcl::PassThrough on z with float limits (:57-64): flag = finite && lo <= z <= hi
+__global__ void k_rs_flags(const unsigned char* cloud, long long n, int stride, float lo, float hi, int32_t* flags) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = reinterpret_cast<const float*>(cloud + (size_t)i * stride);
+    float x = p[0], y = p[1], z = p[2];
+    flags[i] = (isfinite(x) && isfinite(y) && isfinite(z) && !(z < lo) && !(z > hi)) ? 1 : 0;
+}
+// order-preserving compaction of the flagged indices (block offsets from k_scan_block_sums / k_scan_sums)
+__global__ __launch_bounds__(1024) void k_rs_compact(const int32_t* __restrict__ flags, long long n,
+                                                     const int32_t* __restrict__ block_off, int32_t* cand) {
+    __shared__ int wsum[1024 / kWave];
+    long long i = (long long)blockIdx.x * 1024 + threadIdx.x;
+    int v = (i < n) ? flags[i] : 0;
+    unsigned long long m = __ballot(v != 0);
+    int within = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    int w = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) wsum[w] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < w; q++) woff += wsum[q];
+    if (v) cand[block_off[blockIdx.x] + woff + within] = (int32_t)i;
+}
+
+// Stratified sub-sample (restatement of pcl::RandomSample, :66-74): sample[j] = cand[floor((j + u_j) M / 6000)].
+// M is read from device memory when the candidates come from the pass-through.  Also gathers the xyz of the
+// sample into a compact array and publishes S.
+__global__ void k_rs_sample(const unsigned char* cloud, int stride, const int32_t* cand, const int32_t* M_dev,
+                            long long M_host, uint32_t seed, int32_t* sample_idx, float* sp, int32_t* S_out) {
+    const long long M = cand ? (long long)*M_dev : M_host;
+    const int S = M > kSample ? kSample : (int)M;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) *S_out = S;
+    if (j >= S) return;
+    long long pos = j;
+    if (M > kSample) {
+        double u = (double)mix(seed, (uint32_t)j, 0x5A17u) * (1.0 / 4294967296.0);
+        pos = (long long)(((double)j + u) * (double)M / (double)kSample);
+        if (pos > M - 1) pos = M - 1;
+    }
+    int32_t idx = cand ? cand[pos] : (int32_t)pos;
+    sample_idx[j] = idx;
+    const float* p = reinterpret_cast<const float*>(cloud + (size_t)idx * stride);
+    sp[3 * j] = p[0];
+    sp[3 * j + 1] = p[1];
+    sp[3 * j + 2] = p[2];
+}
+
+// One wavefront per draw: inlier count of the hypothesis (countWithinDistance), -1 for a skipped (degenerate) draw.
+__global__ __launch_bounds__(kWave) void k_rs_hypotheses(const float* __restrict__ sp, const int32_t* S_dev, uint32_t seed,
+                                                        int n_draws, double thr, int32_t* counts) {
+    const int d = blockIdx.x;
+    if (d >= n_draws) return;
+    const int S = *S_dev;
+    if (S < 3) {
+        if (threadIdx.x == 0) counts[d] = -1;
+        return;
+    }
+    const Model m = draw_model(sp, S, seed, d);
+    int cnt = 0;
+    if (m.valid) {
+        for (int j = threadIdx.x; j < S; j += kWave)
+            if ((double)plane_dist(m.c, sp + 3 * j) < thr) cnt++;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (threadIdx.x == 0) counts[d] = m.degenerate ? -1 : cnt;
+}
+
+struct Result {
+    float coeffs[4];     // final (refined) coefficients
+    float ransac[4];     // RANSAC model (unrefined)
+    int32_t status;      // 0 ok, 1 no model / too few points
+    int32_t best_draw;
+    int32_t best_count;
+    int32_t n_inliers;   // final inlier count (bits set in the mask)
+    int32_t iterations;
+    int32_t S;
+};
+
+// PCL's sequential RANSAC loop (ransac.hpp computeModel) replayed over the per-draw counts: adaptive bound
+// k = log(1-p)/log(1-w^3), skipped draws do not count as iterations, stop at iterations >= k or > max_iterations.
+__global__ void k_rs_select(const int32_t* __restrict__ counts, const float* __restrict__ sp, const int32_t* S_dev,
+                            uint32_t seed, int n_draws, int max_it, double probability, Result* res) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int S = *S_dev;
+    res->S = S;
+    res->status = 1;
+    res->best_draw = -1;
+    res->n_inliers = 0;
+    if (S < 3) return;
+    int iterations = 0, best = -2147483647, best_draw = -1;
+    double k = 1.0;
+    const double log_probability = log(1.0 - probability);
+    const double one_over = 1.0 / (double)S;
+    for (int d = 0; d < n_draws && (double)iterations < k; d++) {
+        int cnt = counts[d];
+        if (cnt < 0) continue;  // skipped
+        if (cnt > best) {
+            best = cnt;
+            best_draw = d;
+            double w = (double)best * one_over;
+            double p_no = 1.0 - w * w * w;
+            p_no = fmax(2.220446049250313e-16, p_no);
+            p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
+            k = log_probability / log(p_no);
+        }
+        ++iterations;
+        if (iterations > max_it) break;
+    }
+    res->iterations = iterations;
+    res->best_draw = best_draw;
+    res->best_count = best;
+    if (best_draw < 0) return;
+    Model m = draw_model(sp, S, seed, best_draw);
+    for (int t = 0; t < 4; t++) {
+        res->ransac[t] = m.c[t];
+        res->coeffs[t] = m.c[t];
+    }
+    res->status = 0;
+}
+
+// Symmetric 3x3 Jacobi (double), smallest eigenvector; a = xx,xy,xz,yy,yz,zz
+__device__ inline void rs_smallest_eigvec(const double s[6], double n0[3]) {
+    double a[3][3] = {{s[0], s[1], s[2]}, {s[1], s[3], s[4]}, {s[2], s[4], s[5]}};
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (!(off > 1e-300) || off <= 1e-32 * diag) break;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                double apq = a[p][q];
+                if (apq == 0.0) continue;
+                double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < 3; k++) {
+                    double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = cs * akp - sn * akq;
+                    a[k][q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < 3; k++) {
+                    double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = cs * apk - sn * aqk;
+                    a[q][k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < 3; k++) {
+                    double vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = cs * vkp - sn * vkq;
+                    v[k][q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    // index of the smallest diagonal entry, ties resolved like a stable ascending sort of (d0,d1,d2)
+    int i0 = 0;
+    double d0 = a[0][0];
+    if (a[1][1] < d0) {
+        d0 = a[1][1];
+        i0 = 1;
+    }
+    if (a[2][2] < d0) i0 = 2;
+    n0[0] = v[0][i0];
+    n0[1] = v[1][i0];
+    n0[2] = v[2][i0];
+}
+
+// Refinement (:117-126) and the final inlier bitmask (:128-133).  One block of 256 threads.
+//   optimizeModelCoefficients: float sums over the RANSAC inliers; thread p owns inliers p, p+256, ... (in list
+//   order), partials combined in index order — the same association as the CPU restatement.
+__global__ __launch_bounds__(kPartials) void k_rs_refine(const float* __restrict__ sp, const int32_t* __restrict__ sample_idx,
+                                                        double thr, double refine_thr, int use_refinement,
+                                                        int32_t* inl_pos /* scratch, kSample */, uint32_t* mask,
+                                                        Result* res) {
+    __shared__ float acc[kPartials][9];
+    __shared__ int wsum[kPartials / kWave];
+    __shared__ int base_s, total_s;
+    if (res->status != 0) return;
+    const int S = res->S;
+    float rm[4] = {res->ransac[0], res->ransac[1], res->ransac[2], res->ransac[3]};
+    const bool valid = fabs((double)rm[2]) >= 0.984807753012208;
+    const int tid = threadIdx.x, w = tid / kWave;
+    if (tid == 0) {
+        base_s = 0;
+        total_s = 0;
+    }
+    __syncthreads();
+    // ordered list of the RANSAC inliers (positions in the sample)
+    for (int c0 = 0; c0 < S; c0 += kPartials) {
+        const int j = c0 + tid;
+        const bool in = (j < S) && valid && ((double)plane_dist(rm, sp + 3 * j) < thr);
+        const unsigned long long m = __ballot(in);
+        if ((tid & (kWave - 1)) == 0) wsum[w] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int q = 0; q < w; q++) off += wsum[q];
+        if (in) inl_pos[off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = j;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int q = 0; q < kPartials / kWave; q++) t += wsum[q];
+            base_s += t;
+        }
+        __syncthreads();
+    }
+    const int ni = base_s;
+    if (use_refinement && ni > 3) {
+        float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = tid; q < ni; q += kPartials) {
+            const float* v = sp + 3 * inl_pos[q];
+            a[0] += v[0] * v[0];
+            a[1] += v[0] * v[1];
+            a[2] += v[0] * v[2];
+            a[3] += v[1] * v[1];
+            a[4] += v[1] * v[2];
+            a[5] += v[2] * v[2];
+            a[6] += v[0];
+            a[7] += v[1];
+            a[8] += v[2];
+        }
+        for (int t = 0; t < 9; t++) acc[tid][t] = a[t];
+        __syncthreads();
+        if (tid == 0) {
+            float s9[9];
+            for (int t = 0; t < 9; t++) {
+                float sum = 0.0f;
+                for (int p = 0; p < kPartials; p++) sum += acc[p][t];
+                s9[t] = sum / (float)ni;
+            }
+            float cov[6] = {s9[0] - s9[6] * s9[6], s9[1] - s9[6] * s9[7], s9[2] - s9[6] * s9[8],
+                            s9[3] - s9[7] * s9[7], s9[4] - s9[7] * s9[8], s9[5] - s9[8] * s9[8]};
+            double sd[6] = {cov[0], cov[1], cov[2], cov[3], cov[4], cov[5]}, n0[3];
+            rs_smallest_eigvec(sd, n0);
+            float e0 = (float)n0[0], e1 = (float)n0[1], e2 = (float)n0[2];
+            res->coeffs[0] = e0;
+            res->coeffs[1] = e1;
+            res->coeffs[2] = e2;
+            res->coeffs[3] = -1.0f * (e0 * s9[6] + e1 * s9[7] + e2 * s9[8]);
+        }
+    }
+    // final inlier set: RANSAC inliers, or (with refinement) the sample points within refine_thr of the UNREFINED model
+    const double sel_thr = use_refinement ? refine_thr : thr;
+    int cnt = 0;
+    for (int j = tid; j < S; j += kPartials) {
+        if (valid && ((double)plane_dist(rm, sp + 3 * j) < sel_thr)) {
+            const int32_t id = sample_idx[j];
+            atomicOr(&mask[id >> 5], 1u << (id & 31));
+            cnt++;
+        }
+    }
+    atomicAdd(&total_s, cnt);
+    __syncthreads();
+    if (tid == 0) res->n_inliers = total_s;
+}
+
+}  // namespace ransac
+}  // namespace mld

@@ -68,6 +68,36 @@ class GroundPlane:
         return self.inliers
 
 
+class RansacPlane(GroundPlane):
+    """RansacPlane(parameters) (RansacPlane.h:129-170): not segmented until setInputCloud estimates it on the GPU
+    (DepthEstimator.cpp:275-283 -> RansacPlane::CalculateInliersPlane, RansacPlane.cpp:41-140).  `seed` fixes the
+    random draws (the reference's pcl::RandomSample is time-seeded)."""
+
+    def __init__(self, seed: int = 0):
+        self.coeffs = None
+        self.inliers = None
+        self.seed = int(seed)
+        self._segmented = False
+        self._owner = None
+
+    def getInlinersIndex(self):
+        if self.inliers is None and self._owner is not None:
+            est, slot = self._owner
+            self.inliers = est.getGroundPlaneInliers(slot)
+        return self.inliers
+
+
+class _NoPlane:
+    """`ransacPlane == nullptr` of the feature-only CalculateDepth overloads: the road fallback is skipped
+    (DepthEstimator.cpp:580)."""
+
+    def __repr__(self):
+        return "NO_PLANE"
+
+
+NO_PLANE = _NoPlane()
+
+
 def _is_torch_cuda(x) -> bool:
     return hasattr(x, "is_cuda") and bool(x.is_cuda)
 
@@ -190,7 +220,10 @@ class DepthEstimator:
                       plane_given: bool = True):
         """setInputCloud(cloud, groundPlane) — DepthEstimator.cpp:220-312.
 
-        `groundPlane=None` with `plane_given=True` means "ransacPlane == nullptr" (road fallback skipped).
+        groundPlane: a segmented GroundPlane (consumed as is), a RansacPlane (estimated here if not yet
+        segmented), None (a RansacPlane is created and estimated, as the reference does for a null pointer,
+        :275-278) or NO_PLANE (no plane at all: the road fallback is skipped, the `ransacPlane == nullptr` case of
+        the feature-only overloads).  Without do_use_ransac_plane the argument is ignored.
         """
         self._require_init("setInputCloud")
         ptr, n, stride, keep = self._cloud_view(cloud)
@@ -202,10 +235,19 @@ class DepthEstimator:
         if plane_given:
             self.setGroundPlane(groundPlane, slot)
 
-    def setGroundPlane(self, groundPlane: Optional[GroundPlane], slot: int = 0):
-        """The ground-plane hook of setInputCloud (DepthEstimator.cpp:273-292) with the plane as input."""
-        if groundPlane is None:
+    def setGroundPlane(self, groundPlane, slot: int = 0):
+        """The ground-plane hook of setInputCloud (DepthEstimator.cpp:273-292)."""
+        if groundPlane is NO_PLANE or not self._parameters.do_use_ransac_plane:
             self._check(self._lib.mld_set_ground_plane(self._ctx, slot, None, None, 0))
+            return
+        if groundPlane is None:
+            groundPlane = RansacPlane()
+        if isinstance(groundPlane, RansacPlane) and not groundPlane.isSegmented():
+            coeffs, _ = self.estimateGroundPlane(slot, groundPlane.seed)
+            groundPlane.coeffs = coeffs
+            groundPlane.inliers = None
+            groundPlane._segmented = True
+            groundPlane._owner = (self, slot)
             return
         coeffs = (C.c_float * 4)(*[float(x) for x in groundPlane.coeffs])
         inl = groundPlane.inliers
@@ -253,6 +295,22 @@ class DepthEstimator:
         self._check(lib.mld_set_ground_planes_mask_device(ctx, n, b["coeffs"].ctypes.data_as(C.POINTER(C.c_float)),
                                                           b["mask_ptrs"]))
         self._check(lib.mld_calculate_depths_device(ctx, n, b["uv_ptrs"], b["F"], b["depth_ptrs"], b["type_ptrs"]))
+
+    def estimateGroundPlane(self, slot: int = 0, seed: int = 0):
+        """RansacPlane::CalculateInliersPlane on the GPU for the slot's cloud; installs the plane.
+        Returns (coefficients float32[4], inlier count)."""
+        coeffs = (C.c_float * 4)()
+        n_inl = C.c_int64(0)
+        self._check(self._lib.mld_estimate_ground_plane(self._ctx, slot, int(seed) & 0xFFFFFFFF, coeffs, C.byref(n_inl)))
+        return np.array(list(coeffs), dtype=np.float32), int(n_inl.value)
+
+    def getGroundPlaneInliers(self, slot: int = 0) -> np.ndarray:
+        """GroundPlane::getInlinersIndex for the slot's current plane (ascending original indices)."""
+        n = C.c_int64(0)
+        self._check(self._lib.mld_get_ground_plane_inliers(self._ctx, slot, None, 0, C.byref(n)))
+        out = np.empty(int(n.value), dtype=np.int32)
+        self._check(self._lib.mld_get_ground_plane_inliers(self._ctx, slot, out.ctypes.data, out.size, C.byref(n)))
+        return out
 
     def setInputClouds(self, clouds: Sequence, stride_bytes: int = 16):
         """Batched setInputCloud: torch CUDA clouds for slots 0..len-1 in one launch."""

@@ -128,6 +128,22 @@ protected:
     std::vector<int> _inliersIndex;
 };
 
+// RansacPlane (RansacPlane.h:129-170): a GroundPlane that DepthEstimator::setInputCloud estimates on the GPU while it
+// is not segmented (RansacPlane::CalculateInliersPlane, RansacPlane.cpp:41-140 -> mld_estimate_ground_plane).
+// `seed` fixes the random draws (the reference's pcl::RandomSample is time-seeded).
+class RansacPlane : public GroundPlane {
+public:
+    using Ptr = std::shared_ptr<RansacPlane>;
+    RansacPlane() = default;
+    explicit RansacPlane(const std::shared_ptr<DepthEstimatorParameters>& /*parameters*/, uint32_t seed_ = 0) : seed(seed_) {}
+    void assign(const std::array<float, 4>& coeffs, std::vector<int> inliers) {
+        _modelCoeffs = coeffs;
+        _inliersIndex = std::move(inliers);
+        is_segmented_ = true;
+    }
+    uint32_t seed = 0;
+};
+
 class DepthEstimator {
 public:
     using Point = PointXYZI;
@@ -190,9 +206,23 @@ public:
         _numPoints = (int64_t)cloud->points.size();
         _isInitializedPointCloud = true;
         if (_parameters->do_use_ransac_plane) {
-            if (groundPlane == nullptr) groundPlane = std::make_shared<GroundPlane>();      // DepthEstimator.cpp:275-278
-            if (!groundPlane->isSegmented())                                                 // :281-283
-                groundPlane->CalculateInliersPlane(cloud, -10000., 10000.);
+            if (groundPlane == nullptr) groundPlane = std::make_shared<RansacPlane>(_parameters);  // DepthEstimator.cpp:275-278
+            if (!groundPlane->isSegmented()) {                                               // :281-283
+                // RansacPlane::CalculateInliersPlane on the GPU, on the cloud that was just uploaded
+                auto* rp = dynamic_cast<RansacPlane*>(groundPlane.get());
+                if (!rp) {
+                    groundPlane->CalculateInliersPlane(cloud, _parameters->ransac_plane_min_z, _parameters->ransac_plane_max_z);
+                } else {
+                    float coeffs[4];
+                    int64_t n_inl = 0;
+                    check(mld_estimate_ground_plane(_ctx, 0, rp->seed, coeffs, &n_inl));
+                    std::vector<int> inl((size_t)n_inl);
+                    static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
+                    check(mld_get_ground_plane_inliers(_ctx, 0, reinterpret_cast<int32_t*>(inl.data()), n_inl, &n_inl));
+                    rp->assign({coeffs[0], coeffs[1], coeffs[2], coeffs[3]}, std::move(inl));
+                    return;  // the estimator already installed the plane on the device
+                }
+            }
             const auto& c = groundPlane->getModelCoeffs();
             const auto& inl = groundPlane->getInlinersIndex();
             check(mld_set_ground_plane(_ctx, 0, c.data(), inl.data(), (int64_t)inl.size()));

@@ -953,6 +953,212 @@ int orc_tracklets_depth(orc_frame* cur, orc_frame* last, const float* u_new, con
     return MLD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// RansacPlane::CalculateInliersPlane (monolidar_fusion/src/RansacPlane.cpp:41-140), restated.
+//
+// PARITY UNPINNED: the arithmetic lives in un-vendored PCL (RandomSample is time-seeded upstream, so the
+// reference is not even run-to-run reproducible).  What is kept: the pipeline (z pass-through only if
+// min_z > -1001 :57-64, sub-sample to 6000 :66-74, perpendicular-plane RANSAC with axis z / 10 degrees
+// :94-108 incl. the adaptive iteration bound k = log(1-p)/log(1-w^3), optional least-squares refinement and the
+// re-selection within `ransac_plane_refinement_treshold` of the UNREFINED model :117-126), float arithmetic as in
+// PCL's plane model.  What is ours (shared bit-for-bit with the HIP implementation): the random draws come from a
+// counter-based hash, the 6000-point sub-sample is stratified instead of Knuth's algorithm S, the refinement's
+// float sums use 256 interleaved partial sums, the smallest eigenvector comes from a double Jacobi solve.
+// Checked against the reference's own test RansacPlane.CalculateInlersPlane (coefficients within 0.2).
+// ------------------------------------------------------------------------------------------------
+namespace ransac {
+constexpr int kSample = 6000;  // RansacPlane.cpp:32 _numberRandomSamplePoints
+constexpr int kPartials = 256;
+
+inline uint32_t mix(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t h = a * 0x9E3779B1u;
+    h ^= b + 0x85EBCA6Bu + (h << 6) + (h >> 2);
+    h ^= c * 0xC2B2AE35u + (h << 6) + (h >> 2);
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+struct Model {
+    float c[4];
+    bool degenerate;  // collinear sample: computeModelCoefficients fails, the draw is skipped
+    bool valid;       // normal within eps_angle of the z axis (isModelValid)
+};
+
+inline Model plane_from(const float* p0, const float* p1, const float* p2) {
+    Model m{};
+    float a0 = p1[0] - p0[0], a1 = p1[1] - p0[1], a2 = p1[2] - p0[2];
+    float b0 = p2[0] - p0[0], b1 = p2[1] - p0[1], b2 = p2[2] - p0[2];
+    float r0 = a0 / b0, r1 = a1 / b1, r2 = a2 / b2;  // sac_model_plane: collinearity test on the ratios
+    m.degenerate = (r0 == r1) && (r2 == r1);
+    float n0 = a1 * b2 - a2 * b1, n1 = a2 * b0 - a0 * b2, n2 = a0 * b1 - a1 * b0;
+    float nn = std::sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+    n0 /= nn;
+    n1 /= nn;
+    n2 /= nn;
+    m.c[0] = n0;
+    m.c[1] = n1;
+    m.c[2] = n2;
+    m.c[3] = -1.0f * (n0 * p0[0] + n1 * p0[1] + n2 * p0[2]);
+    if (!(nn > 0.0f) || !std::isfinite(nn)) m.degenerate = true;
+    m.valid = !m.degenerate && (std::fabs(static_cast<double>(n2)) >= 0.984807753012208);  // cos(pi/18)
+    return m;
+}
+inline float plane_dist(const float c[4], const float* p) { return std::fabs(c[0] * p[0] + c[1] * p[1] + c[2] * p[2] + c[3]); }
+}  // namespace ransac
+
+int orc_estimate_ground_plane(orc_frame* h, const void* pts_v, int64_t n, int stride, uint32_t seed, float coeffs_out[4],
+                              int64_t* n_inliers_out) {
+    using namespace ransac;
+    if (!h || !h->fr.cloud_set) return MLD_ERR_NOT_INITIALIZED;
+    const mld_params& P = h->fr.P;
+    const uint8_t* pts = static_cast<const uint8_t*>(pts_v);
+    if (n < 3) return MLD_ERR_CLOUD_TOO_SMALL;  // RansacPlane.cpp:44-50
+    auto pt = [&](int64_t i) { return reinterpret_cast<const float*>(pts + i * stride); };
+    // :57-64 PassThrough on z (float limits), only if min_z > -1001
+    std::vector<int32_t> cand;
+    const bool pass = P.ransac_plane_min_z > -1001.;
+    if (pass) {
+        const float lo = static_cast<float>(P.ransac_plane_min_z), hi = static_cast<float>(P.ransac_plane_max_z);
+        for (int64_t i = 0; i < n; i++) {
+            const float* p = pt(i);
+            if (std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]) && !(p[2] < lo) && !(p[2] > hi))
+                cand.push_back(static_cast<int32_t>(i));
+        }
+    }
+    const int64_t M = pass ? static_cast<int64_t>(cand.size()) : n;
+    // :66-74 RandomSample to 6000 (stratified restatement; ascending like Algorithm S)
+    std::vector<int32_t> sample;
+    if (M > kSample) {
+        sample.resize(kSample);
+        for (int j = 0; j < kSample; j++) {
+            double u = static_cast<double>(mix(seed, static_cast<uint32_t>(j), 0x5A17u)) * (1.0 / 4294967296.0);
+            int64_t pos = static_cast<int64_t>((static_cast<double>(j) + u) * static_cast<double>(M) / static_cast<double>(kSample));
+            if (pos > M - 1) pos = M - 1;
+            sample[j] = pass ? cand[pos] : static_cast<int32_t>(pos);
+        }
+    } else {
+        sample.resize(M);
+        for (int64_t j = 0; j < M; j++) sample[j] = pass ? cand[j] : static_cast<int32_t>(j);
+    }
+    const int S = static_cast<int>(sample.size());
+    if (S < 3) return MLD_ERR_CLOUD_TOO_SMALL;
+    std::vector<float> sp(3 * static_cast<size_t>(S));
+    for (int j = 0; j < S; j++) {
+        const float* p = pt(sample[j]);
+        sp[3 * j] = p[0];
+        sp[3 * j + 1] = p[1];
+        sp[3 * j + 2] = p[2];
+    }
+    // :102-108 RandomSampleConsensus
+    const double thr = P.ransac_plane_distance_treshold;
+    const int max_it = P.ransac_plane_max_iterations;
+    auto draw = [&](int d) {
+        uint32_t a = mix(seed, static_cast<uint32_t>(d), 1u) % static_cast<uint32_t>(S);
+        uint32_t b = mix(seed, static_cast<uint32_t>(d), 2u) % static_cast<uint32_t>(S);
+        uint32_t c = mix(seed, static_cast<uint32_t>(d), 3u) % static_cast<uint32_t>(S);
+        if (b == a) b = (b + 1) % static_cast<uint32_t>(S);
+        while (c == a || c == b) c = (c + 1) % static_cast<uint32_t>(S);
+        return plane_from(&sp[3 * a], &sp[3 * b], &sp[3 * c]);
+    };
+    auto count_inliers = [&](const Model& m) {
+        if (!m.valid) return 0;
+        int cnt = 0;
+        for (int j = 0; j < S; j++)
+            if (static_cast<double>(plane_dist(m.c, &sp[3 * j])) < thr) cnt++;
+        return cnt;
+    };
+    int iterations = 0, best = -2147483647, best_draw = -1;
+    double k = 1.0;
+    const double log_probability = std::log(1.0 - P.ransac_plane_probability);
+    const double one_over = 1.0 / static_cast<double>(S);
+    const int max_draws = max_it + 1;  // one hypothesis per draw; skipped (degenerate) draws are not re-drawn
+    for (int d = 0; d < max_draws && iterations < k; d++) {
+        Model m = draw(d);
+        if (m.degenerate) continue;  // ++skipped_count
+        int cnt = count_inliers(m);
+        if (cnt > best) {
+            best = cnt;
+            best_draw = d;
+            double w = static_cast<double>(best) * one_over;
+            double p_no = 1.0 - w * w * w;
+            p_no = std::max(std::numeric_limits<double>::epsilon(), p_no);
+            p_no = std::min(1.0 - std::numeric_limits<double>::epsilon(), p_no);
+            k = log_probability / std::log(p_no);
+        }
+        ++iterations;
+        if (iterations > max_it) break;
+    }
+    if (best_draw < 0) return MLD_ERR_CLOUD_TOO_SMALL;
+    Model bm = draw(best_draw);
+    float coeffs[4] = {bm.c[0], bm.c[1], bm.c[2], bm.c[3]};
+    std::vector<int32_t> inl;  // positions in the sample
+    if (bm.valid)
+        for (int j = 0; j < S; j++)
+            if (static_cast<double>(plane_dist(bm.c, &sp[3 * j])) < thr) inl.push_back(j);
+    // :117-126 refinement
+    if (P.ransac_plane_use_refinement) {
+        if (inl.size() > 3) {
+            // computeMeanAndCovarianceMatrix, float accumulators; partial p takes the inliers q = p, p+256, ...
+            float acc[kPartials][9];
+            for (int p = 0; p < kPartials; p++) {
+                for (int t = 0; t < 9; t++) acc[p][t] = 0.0f;
+                for (size_t q = p; q < inl.size(); q += kPartials) {
+                    const float* v = &sp[3 * inl[q]];
+                    acc[p][0] += v[0] * v[0];
+                    acc[p][1] += v[0] * v[1];
+                    acc[p][2] += v[0] * v[2];
+                    acc[p][3] += v[1] * v[1];
+                    acc[p][4] += v[1] * v[2];
+                    acc[p][5] += v[2] * v[2];
+                    acc[p][6] += v[0];
+                    acc[p][7] += v[1];
+                    acc[p][8] += v[2];
+                }
+            }
+            float a[9];
+            for (int t = 0; t < 9; t++) {
+                a[t] = 0.0f;
+                for (int p = 0; p < kPartials; p++) a[t] += acc[p][t];
+                a[t] /= static_cast<float>(inl.size());
+            }
+            float cov[6] = {a[0] - a[6] * a[6], a[1] - a[6] * a[7], a[2] - a[6] * a[8],
+                            a[3] - a[7] * a[7], a[4] - a[7] * a[8], a[5] - a[8] * a[8]};
+            double m9[9] = {cov[0], cov[1], cov[2], cov[1], cov[3], cov[4], cov[2], cov[4], cov[5]};
+            double ev[3], evec[9];
+            jacobi_eig3(m9, ev, evec);
+            float e0 = static_cast<float>(evec[0]), e1 = static_cast<float>(evec[3]), e2 = static_cast<float>(evec[6]);
+            coeffs[0] = e0;
+            coeffs[1] = e1;
+            coeffs[2] = e2;
+            coeffs[3] = -1.0f * (e0 * a[6] + e1 * a[7] + e2 * a[8]);
+        }
+        // selectWithinDistance(UNREFINED model, refinement threshold)
+        inl.clear();
+        if (bm.valid)
+            for (int j = 0; j < S; j++)
+                if (static_cast<double>(plane_dist(bm.c, &sp[3 * j])) < P.ransac_plane_refinement_treshold) inl.push_back(j);
+    }
+    std::vector<int32_t> inlier_idx(inl.size());
+    for (size_t q = 0; q < inl.size(); q++) inlier_idx[q] = sample[inl[q]];
+    for (int t = 0; t < 4; t++) coeffs_out[t] = coeffs[t];
+    if (n_inliers_out) *n_inliers_out = static_cast<int64_t>(inlier_idx.size());
+    return orc_set_ground_plane(h, coeffs, inlier_idx.data(), static_cast<int64_t>(inlier_idx.size()));
+}
+
+int64_t orc_get_plane_inliers(const orc_frame* h, int32_t* out, int64_t cap) {
+    int64_t k = 0;
+    for (int64_t i = 0; i < h->fr.n; i++)
+        if (h->fr.has_plane && h->fr.inlier[i]) {
+            if (k < cap) out[k] = static_cast<int32_t>(i);
+            k++;
+        }
+    return k;
+}
+
 // ---- component entry points (known-answer tests, micro-vectors) --------------------------------
 
 // PointHistogram::FilterPointsMinDistBlob: returns 1/0; keep[] = positions kept.

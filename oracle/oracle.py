@@ -54,6 +54,9 @@ def load() -> C.CDLL:
         getattr(lib, name).restype = None
     lib.orc_trace_feature.argtypes = [C.c_void_p, C.c_double, C.c_double, P(OrcTrace), C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int32]
+    lib.orc_estimate_ground_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint32, P(C.c_float), P(C.c_int64)]
+    lib.orc_get_plane_inliers.restype = C.c_int64
+    lib.orc_get_plane_inliers.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.orc_tracklets_depth.argtypes = [C.c_void_p, C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 4 + [C.c_int]
     lib.orc_filter_points_min_dist_blob.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p,
                                                     P(C.c_int32), P(C.c_double), P(C.c_double)]
@@ -113,6 +116,19 @@ class OracleDepthEstimator:
             inl = np.ascontiguousarray(inliers, dtype=np.int32)
             rc = self.lib.orc_set_ground_plane(self.h, c, inl.ctypes.data, inl.size)
         assert rc == 0, rc
+
+    def estimate_ground_plane(self, seed: int = 0):
+        """RansacPlane::CalculateInliersPlane restated (see orc_estimate_ground_plane); sets the frame's plane."""
+        arr = self._keep
+        coeffs = (C.c_float * 4)()
+        n_inl = C.c_int64(0)
+        rc = self.lib.orc_estimate_ground_plane(self.h, arr.ctypes.data, arr.shape[0], arr.shape[1] * 4, seed, coeffs,
+                                                C.byref(n_inl))
+        if rc != 0:
+            raise RuntimeError(f"orc_estimate_ground_plane: status {rc}")
+        inl = np.empty(n_inl.value, dtype=np.int32)
+        k = self.lib.orc_get_plane_inliers(self.h, inl.ctypes.data, inl.size)  # unique, ascending
+        return np.array(list(coeffs), dtype=np.float32), inl[:k].copy()
 
     def calculate_depth(self, uv, n_threads: int = 1):
         uv = _f64(uv)

@@ -12,6 +12,7 @@ Cases (small camera 320x96, f=180; 32x512 cloud; features chosen so that every l
   no_thresholds thresholds off, cut-behind-camera on                            -> type 10 (intersection behind the camera)
   find_by_pixel the reference's NeigborFinder.findByPixel layout (100x100, f=600, window 3x5, 50 points)
 """
+import json
 import sys
 from pathlib import Path
 
@@ -55,7 +56,10 @@ def run_case(name, P, cam, T, cloud, plane, candidates, per_type=6, max_features
         off = np.cumsum([0] + [len(l) for l in lists]).astype(np.int32)
         return flat, off
 
-    out = {"params": np.frombuffer(bytes(P), dtype=np.uint8), "camera": np.frombuffer(bytes(cam), dtype=np.uint8),
+    # parameters / camera as name -> value (robust against struct layout changes of the C-ABI)
+    pj = json.dumps({n: getattr(P, n) for n, _ in capi.MldParams._fields_})
+    cj = json.dumps({n: getattr(cam, n) for n, _ in capi.MldCamera._fields_})
+    out = {"params_json": np.array(pj), "camera_json": np.array(cj),
            "T": np.asarray(T, dtype=np.float64), "uv": uv,
            "depth": d0, "type": t0,  # depths as produced by the C++ oracle (agreeing with NumPy to 1e-9)
            "point_index": npo.point_index, "pixel_map": npo.pixel_map}

@@ -20,12 +20,12 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, f"libmld_hip.so lacks: {missing}"
     assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
-    assert lib.mld_abi_version() == 1
+    assert lib.mld_abi_version() == 2
 
 
 def test_struct_layout_matches_header():
-    # doubles first, then int32s: 9*8 + 24*4 = 168 bytes; camera 3*8 + 2*4 = 32
-    assert C.sizeof(capi.MldParams) == 168
+    # doubles first, then int32s: 14*8 + 26*4 = 216 bytes; camera 3*8 + 2*4 = 32
+    assert C.sizeof(capi.MldParams) == 216
     assert C.sizeof(capi.MldCamera) == 32
     header = (ROOT / "include" / "mld.h").read_text()
     body = header[header.index("typedef struct mld_params {"):header.index("} mld_params;")]
@@ -61,11 +61,16 @@ def test_params_from_file(tmp_path):
                  "plane_estimator_use_mestimator: 1\nplane_estimator_z_x_min_relation: 0\n"
                  "do_use_cut_behind_camera: 1\ndo_use_triangle_size_maximation: 1\n"
                  "do_check_triangleplanar_condition: 1\ntriangleplanar_crossnorm_treshold: 0.1\n"
-                 "viewray_plane_orthoganality_treshold: 0.03\nunknown_key: 7\n")
+                 "viewray_plane_orthoganality_treshold: 0.03\nunknown_key: 7\nransac_plane_distance_treshold: 0.3\n"
+                 "ransac_plane_max_iterations: 10000\nransac_plane_probability: 0.999\nransac_plane_use_refinement: 1\n"
+                 "ransac_plane_refinement_treshold: 10.2\n")
     p = capi.params_from_file(str(y))
     c0 = capi.params_c0()
     for name, _ in capi.MldParams._fields_:
+        if name in ("ransac_plane_min_z", "ransac_plane_max_z"):
+            continue  # absent from the yaml: the loader reads 0 (cv::FileStorage), C0 keeps the header defaults
         assert getattr(p, name) == getattr(c0, name), name
+    assert p.ransac_plane_min_z == 0 and p.ransac_plane_max_z == 0
     assert p.set_all_depths_to_zero == 0  # key absent in the yaml -> 0
     y2 = tmp_path / "q.yaml"
     y2.write_text("do_use_ransac_plane: 5\ntreshold_depth_max: 79.6\n")

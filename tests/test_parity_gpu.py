@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from mono_lidar_depth_amd import GroundPlane, capi, synth
+from mono_lidar_depth_amd import NO_PLANE, GroundPlane, capi, synth
 
 from helpers import assert_depth_parity, kitti_camera, make_estimator, make_oracle, run_oracle
 
@@ -85,7 +85,7 @@ def test_tag_wraparound():
     uv = synth.make_features(256, seed=9)
     for it in range(300):
         cl = clouds[it % 4]
-        est.setInputCloud(cl, None)
+        est.setInputCloud(cl, NO_PLANE)
     cl = clouds[299 % 4]
     depth, types = est.CalculateDepth(uv)
     _, (d0, t0) = run_oracle(P, cl, uv, None)
@@ -145,7 +145,7 @@ def test_parameter_modes(name):
     P = capi.params_c0().replace(**kw)
     cloud, uv, plane = _frame(synth.HDL64_KITTI, 31, 1200)
     est = make_estimator(P)
-    gp = GroundPlane(*plane) if with_plane else None
+    gp = GroundPlane(*plane) if with_plane else NO_PLANE
     depth, types = est.CalculateDepth(cloud, uv, gp)
     _, (d0, t0) = run_oracle(P, cloud, uv, plane if with_plane else None)
     exact = name not in ("pca",)
@@ -169,7 +169,7 @@ def test_edge_features_and_empty_inputs():
     assert d.shape == (0,) and t.shape == (0,)
     # empty cloud and all-NaN cloud: every feature is RadiusSearchInsufficientPoints
     for cl in (np.zeros((0, 4), np.float32), np.full((100, 4), np.nan, np.float32)):
-        d, t = est.CalculateDepth(cl, uv[:20], None)
+        d, t = est.CalculateDepth(cl, uv[:20], NO_PLANE)
         assert (t == 2).all() and (d == -1).all()
 
 
