@@ -68,6 +68,8 @@ struct mld_ctx {
     bool own_stream = true;
     std::vector<Slot> slots;
     SlotDesc* d_slots = nullptr;
+    uint32_t* bitmaps = nullptr;  // occupancy bitmaps of all slots, contiguous
+    size_t bitmap_words = 0;      // per slot
     std::vector<SlotDesc> h_descs;
     size_t lds_bytes = 0;
     std::string err;
@@ -189,6 +191,7 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     c.cv = ctx->cam.principal_point_y;
     c.W = ctx->cam.width;
     c.H = ctx->cam.height;
+    c.bmStride = (ctx->cam.width + 31) / 32 + 2;
     // NeighborFinderPixel.cpp:67-68, scales (1,1) and (2.0f,1.5f) (DepthEstimator.cpp:509,585)
     c.halfX1 = (double)P.pixelarea_search_witdh * 0.5 * (double)1.0f;
     c.halfY1 = (double)P.pixelarea_search_height * 0.5 * (double)1.0f;
@@ -292,11 +295,12 @@ struct ScopedTimer {
 };
 
 // New cloud for a slot: bump the map tag (zero-fill on wrap), forget the previous plane / debug data.
-int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int stride) {
+int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int stride, bool clear_bitmap = true) {
     if (n < 0 || n > kMaxPoints) return fail(ctx, MLD_ERR_CAPACITY, "cloud larger than 16 777 215 points");
     if (stride != 16 && stride != 32) return fail(ctx, MLD_ERR_INVALID_ARG, "stride_bytes must be 16 or 32");
     if (!dev_ptr && n > 0) return fail(ctx, MLD_ERR_INVALID_ARG, "null cloud pointer");
     if (((size_t)dev_ptr & 3) != 0) return fail(ctx, MLD_ERR_INVALID_ARG, "cloud pointer must be 4-byte aligned");
+    if (clear_bitmap) HIP_TRY(ctx, hipMemsetAsync(s.d.bitmap, 0, ctx->bitmap_words * sizeof(uint32_t), ctx->stream));
     if (s.d.tag >= kMaxTag) {
         HIP_TRY(ctx, hipMemsetAsync(s.d.map, 0,
                                     ((size_t)ctx->cam.width * ctx->cam.height + kMapPadCells) * sizeof(uint32_t),
@@ -504,6 +508,10 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if ((e = hipMalloc((void**)&ctx->d_slots, sizeof(SlotDesc) * max_frames)) != hipSuccess)
         return hip_bail(e, "hipMalloc(slots)");
     size_t cells = (size_t)camera->width * camera->height + kMapPadCells;
+    ctx->bitmap_words = (size_t)ctx->calib.bmStride * (size_t)camera->height + 2;
+    if ((e = hipMalloc((void**)&ctx->bitmaps, ctx->bitmap_words * sizeof(uint32_t) * (size_t)max_frames)) != hipSuccess)
+        return hip_bail(e, "hipMalloc(bitmaps)");
+    for (size_t si = 0; si < ctx->slots.size(); si++) ctx->slots[si].d.bitmap = ctx->bitmaps + si * ctx->bitmap_words;
     for (Slot& s : ctx->slots) {
         if ((e = hipMalloc((void**)&s.d.map, cells * sizeof(uint32_t))) != hipSuccess) return hip_bail(e, "hipMalloc(map)");
         if ((e = hipMemsetAsync(s.d.map, 0, cells * sizeof(uint32_t), ctx->stream)) != hipSuccess)
@@ -537,6 +545,7 @@ void mld_destroy(mld_ctx* ctx) {
             if (p) (void)hipFree(p);
     }
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    if (ctx->bitmaps) (void)hipFree(ctx->bitmaps);
     void* rsp[] = {ctx->rs_flags, ctx->rs_cand, ctx->rs_block, ctx->rs_M, ctx->rs_S, ctx->rs_sample, ctx->rs_sp,
                    ctx->rs_counts, ctx->rs_inl, ctx->rs_res};
     for (void* p : rsp)
@@ -595,8 +604,10 @@ int mld_set_clouds_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev,
     int rc = bind_device(ctx);
     if (rc) return rc;
     int64_t max_n = 0;
+    // the slots' occupancy bitmaps are contiguous: one fill for the whole batch
+    HIP_TRY(ctx, hipMemsetAsync(ctx->bitmaps, 0, ctx->bitmap_words * sizeof(uint32_t) * (size_t)n_slots, ctx->stream));
     for (int i = 0; i < n_slots; i++) {
-        if ((rc = begin_cloud(ctx, ctx->slots[i], pts_dev[i], n[i], stride_bytes))) return rc;
+        if ((rc = begin_cloud(ctx, ctx->slots[i], pts_dev[i], n[i], stride_bytes, false))) return rc;
         max_n = std::max(max_n, n[i]);
     }
     if ((rc = upload_descs(ctx, n_slots))) return rc;

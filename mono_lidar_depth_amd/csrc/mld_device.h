@@ -37,6 +37,7 @@ struct Calib {
     int useRoad;   // do_use_ransac_plane
     int roadMode;  // 0 = M-estimator, 1 = max spanning triangle
     int usePCA;
+    int bmStride;    // words per row of the occupancy bitmap: ceil(W/32) + 2 (8-byte reads never overrun a row)
     int k1max;       // thread path: neighbour list capacity per feature (entries in LDS)
     int threadPath;  // 1: thread-per-feature fast path with wave-cooperative overflow; 0: wave path only
 };
@@ -45,6 +46,7 @@ struct Calib {
 struct SlotDesc {
     const unsigned char* cloud;   // float32 records, `stride` bytes apart (x,y,z first)
     uint32_t* map;                // W*H keys
+    uint32_t* bitmap;             // occupancy bits of the map, bmStride words per image row (cleared per cloud)
     const double* uv;             // 2 x F column-major
     double* depth;                // F
     int32_t* type;                // F or nullptr

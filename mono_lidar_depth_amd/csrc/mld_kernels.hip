@@ -147,7 +147,6 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
     decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
     const SlotDesc s = use_single ? single : slots[slot];
     const long long base = (long long)j * (kProjThreads * kProjPerThread) + threadIdx.x;
-    if (base >= s.n) return;
     double px[kProjPerThread], py[kProjPerThread], pz[kProjPerThread];
 #pragma unroll
     for (int r = 0; r < kProjPerThread; r++) {
@@ -158,6 +157,13 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
         if (i < s.n) load_point(s, i, px[r], py[r], pz[r]);
     }
     const double Wd = (double)c.W, Hd = (double)c.H;
+    int bmw[kProjPerThread];       // occupancy-bitmap word of the point (or a unique negative value)
+    uint32_t bmb[kProjPerThread];  // its bit
+#pragma unroll
+    for (int r = 0; r < kProjPerThread; r++) {
+        bmw[r] = -1 - (int)threadIdx.x;
+        bmb[r] = 0u;
+    }
 #pragma unroll
     for (int r = 0; r < kProjPerThread; r++) {
         long long i = base + (long long)r * kProjThreads;
@@ -172,7 +178,29 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
             uint32_t key = (s.tag << kIdxBits) | (kIdxMask - (uint32_t)i);
             __hip_atomic_fetch_max(GPTRW(uint32_t, s.map) + ((size_t)xi + (size_t)yi * (size_t)c.W), key,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bmw[r] = yi * c.bmStride + (xi >> 5);
+            bmb[r] = 1u << (xi & 31);
         }
+    }
+    // Occupancy bits (lets the feature kernel skip the mostly empty key rows).  Consecutive lanes hold consecutive
+    // points of a scan ring, i.e. neighbouring pixels of one image row: bits of a run of lanes with the same bitmap
+    // word are OR-ed along the run and only the run's last lane issues the atomic (~10x fewer atomics).  Runs need
+    // not be exact: every lane's bit reaches the last lane of its contiguous run, which always writes.
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int r = 0; r < kProjPerThread; r++) {
+        int w = bmw[r];
+        uint32_t bits = bmb[r];
+#pragma unroll
+        for (int d = 1; d <= 32; d <<= 1) {  // full wave: a run can be as long as the wavefront (dense clouds)
+            const int wn = __shfl_up(w, d);
+            const uint32_t bn = __shfl_up(bits, d);
+            if (lane >= d && wn == w) bits |= bn;
+        }
+        const int wnext = __shfl_down(w, 1);
+        const bool leader = (lane == kWave - 1) || (wnext != w);
+        if (leader && bits)
+            __hip_atomic_fetch_or(GPTRW(uint32_t, s.bitmap) + (size_t)w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1022,6 +1050,53 @@ __device__ __forceinline__ void scan_rows(const Calib& c, const SlotDesc& s,
     }
 }
 
+// Window scan through the occupancy bitmap: the key map has one occupied cell in ~30, so reading it row by row
+// drags almost every 128-byte line of the 1.86 MB map through HBM.  The bitmap (58 KB per frame, cache resident)
+// tells which cells to fetch.  Pass 1 appends the CELL indices of the set bits (row-major order) to the lane's
+// list; pass 2 turns them into point indices with batched key loads.  Windows up to 32 cells wide.
+__device__ __forceinline__ int scan_window_bitmap(const Calib& c, const SlotDesc& s, int x0, int y0, int nx, int ny,
+                                                  uint32_t* lst, int lane) {
+    const int nymax = uniform(wave_max_i32(ny));
+    const auto* bm = GPTR(uint32_t, s.bitmap);
+    const unsigned long long colmask = (nx >= 64) ? ~0ull : ((1ull << nx) - 1ull);
+    int k = 0;
+    for (int r0 = 0; r0 < nymax; r0 += 4) {
+        unsigned long long bits[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool rowok = (r0 + q) < ny;
+            const size_t w = (size_t)(y0 + (rowok ? (r0 + q) : 0)) * (size_t)c.bmStride + (size_t)(x0 >> 5);
+            unsigned long long v = 0;
+            if (rowok) v = (unsigned long long)bm[w] | ((unsigned long long)bm[w + 1] << 32);
+            bits[q] = (v >> (x0 & 31)) & colmask;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            unsigned long long b = bits[q];
+            const uint32_t rowbase = (uint32_t)((y0 + r0 + q) * c.W + x0);
+            while (b) {
+                const int col = __ffsll((long long)b) - 1;
+                b &= b - 1;
+                if (k < c.k1max) LST(k) = rowbase + (uint32_t)col;
+                k++;
+            }
+        }
+    }
+    // cell index -> original point index (every set bit has a key of the current tag)
+    const int kk = k <= c.k1max ? k : 0;  // overflowing lists (k > k1max) are redone by the wave path
+    const int kmax = uniform(wave_max_i32(kk));
+    const auto* mp = GPTR(uint32_t, s.map);
+    for (int e0 = 0; e0 < kmax; e0 += 4) {
+        uint32_t key[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) key[q] = (e0 + q < kk) ? mp[LST(min(e0 + q, c.k1max - 1))] : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (e0 + q < kk) LST(e0 + q) = kIdxMask - (key[q] & kIdxMask);
+    }
+    return k;
+}
+
 // Row-major window scan by one thread (NeighborFinderPixel.cpp:60-95): appends the original indices of the
 // occupied cells to the thread's LDS list.  Returns the count (may exceed c.k1max: overflow).
 __device__ __forceinline__ int scan_window_thread(const Calib& c, const SlotDesc& s, double u, double v, double halfX, double halfY,
@@ -1052,6 +1127,7 @@ __device__ __forceinline__ int scan_window_thread(const Calib& c, const SlotDesc
     int k = 0;
     // Rows are independent: the loads of a group of rows are issued before any of them is consumed, so that
     // the map latency is paid once per group instead of once per row.
+    if (nxmax <= 32 && s.bitmap) return scan_window_bitmap(c, s, x0, y0, nx, ny, lst, lane);
     if (nxmax <= 8)
         scan_rows<4, 1>(c, s, base, nx, ny, nymax, nxmax, lst, lane, k);
     else if (nxmax <= 16)
