@@ -36,6 +36,9 @@ def parse_args():
     ap.add_argument("--frames-per-step", type=int, default=256, help="frame slots processed per step")
     ap.add_argument("--slots", type=int, default=0,
                     help="frame slots of the context (0 = frames-per-step); a step runs frames-per-step/slots launch sets")
+    ap.add_argument("--contexts", type=int, default=1,
+                    help="independent contexts (HIP streams) the frames of a step are split over; >1 lets the "
+                         "HBM-bound projection of one half overlap the VALU-bound feature kernel of the other")
     ap.add_argument("--unique-frames", type=int, default=16, help="distinct synthetic clouds generated per rank")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -157,19 +160,29 @@ def main():
     coeffs = np.stack([planes_h[b % U][0] for b in range(B)])
     torch.cuda.synchronize()
 
-    S = args.slots if args.slots > 0 else B
-    assert B % S == 0, "--frames-per-step must be a multiple of --slots"
-    est = DepthEstimator(device=local_rank, max_frames=S)
-    est.InitConfig(P)
-    est.Initialize(cam, T)
-    # a step walks the B resident frames in sub-batches of S frame slots (the slots' pixel maps are reused, so
-    # their footprint — S x 1.86 MB — can stay cache-resident while the clouds stream through once)
-    batches = [est.prepareBatch(t_clouds[i:i + S], t_uvs[i:i + S], t_depth[i:i + S], t_type[i:i + S],
-                                coeffs[i:i + S], t_masks[i:i + S], stride_bytes=16) for i in range(0, B, S)]
+    NC = max(1, args.contexts)
+    S = args.slots if args.slots > 0 else B // NC
+    assert B % (S * NC) == 0, "--frames-per-step must be a multiple of --slots x --contexts"
+    ests = []
+    for _ in range(NC):
+        e = DepthEstimator(device=local_rank, max_frames=S)
+        e.InitConfig(P)
+        e.Initialize(cam, T)
+        ests.append(e)
+    est = ests[0]
+    # a step walks the B resident frames in launch sets of S frame slots, dealt round-robin to the contexts (one
+    # HIP stream each); the slots' pixel maps are reused from one launch set to the next
+    batches = [(ests[(i // S) % NC], ests[(i // S) % NC].prepareBatch(
+        t_clouds[i:i + S], t_uvs[i:i + S], t_depth[i:i + S], t_type[i:i + S], coeffs[i:i + S], t_masks[i:i + S],
+        stride_bytes=16)) for i in range(0, B, S)]
 
     def run_step():
-        for b in batches:
-            est.runBatch(b)
+        for e, b in batches:
+            e.runBatch(b)
+
+    def sync_all():
+        for e in ests:
+            e.synchronize()
 
     def barrier():
         if world > 1:
@@ -178,7 +191,7 @@ def main():
     # ---- warm-up, then exactly K timed steps ---------------------------------------------------------------
     for _ in range(args.warmup):
         run_step()
-    est.synchronize()
+    sync_all()
     timing = not args.no_kernel_timing
     if timing:
         est.timingEnable(True)
@@ -188,7 +201,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_step()
-    est.synchronize()
+    sync_all()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -197,6 +210,7 @@ def main():
 
     k_proj_ms, n_proj = est.kernelTimeMs(0) if timing else (0.0, 0)
     k_feat_ms, n_feat = est.kernelTimeMs(1) if timing else (0.0, 0)
+    k_road_ms, n_road = est.kernelTimeMs(2) if timing else (0.0, 0)
     est.timingEnable(False)
 
     if rank != 0:
@@ -217,9 +231,15 @@ def main():
         stats.append(fb)
     proj_bytes = float(np.mean([s["project_bytes"] for s in stats])) * S  # per launch: S frames
     feat_bytes = float(np.mean([s["feature_bytes"] for s in stats])) * S
-    dominant = "k_feature_depth" if k_feat_ms >= k_proj_ms else "k_project_scatter"
-    dom_ms = max(k_feat_ms, k_proj_ms)
-    dom_bytes = feat_bytes if dominant == "k_feature_depth" else proj_bytes
+    # the road fallback runs as its own kernel (k_feature_road) when the thread path is on; its algorithmic bytes
+    # are the "+ 4*P2 + 25*k2" terms of the per-feature formula
+    road_bytes = float(np.mean([s["road_bytes"] for s in stats])) * S
+    main_bytes = feat_bytes - road_bytes if n_road else feat_bytes
+    cand = {"k_project_scatter": (k_proj_ms, proj_bytes), "k_feature_depth": (k_feat_ms, main_bytes)}
+    if n_road:
+        cand["k_feature_road"] = (k_road_ms, road_bytes)
+    dominant = max(cand, key=lambda k: cand[k][0])
+    dom_ms, dom_bytes = cand[dominant]
     achieved = (dom_bytes / (dom_ms * 1e-3)) / 1e9 if dom_ms > 0 else 0.0
     roofline = {
         "bound": "hbm",
@@ -234,9 +254,12 @@ def main():
         "kernels": {
             "k_project_scatter": {"avg_ms": k_proj_ms, "launches": n_proj, "algorithmic_bytes_per_launch": proj_bytes,
                                   "GBps": (proj_bytes / (k_proj_ms * 1e-3)) / 1e9 if k_proj_ms > 0 else 0.0},
-            "k_feature_depth": {"avg_ms": k_feat_ms, "launches": n_feat, "algorithmic_bytes_per_launch": feat_bytes,
-                                "GBps": (feat_bytes / (k_feat_ms * 1e-3)) / 1e9 if k_feat_ms > 0 else 0.0},
+            "k_feature_depth": {"avg_ms": k_feat_ms, "launches": n_feat, "algorithmic_bytes_per_launch": main_bytes,
+                                "GBps": (main_bytes / (k_feat_ms * 1e-3)) / 1e9 if k_feat_ms > 0 else 0.0},
+            "k_feature_road": {"avg_ms": k_road_ms, "launches": n_road, "algorithmic_bytes_per_launch": road_bytes,
+                               "GBps": (road_bytes / (k_road_ms * 1e-3)) / 1e9 if k_road_ms > 0 else 0.0},
         },
+        "feature_kernels_GBps": (feat_bytes / ((k_feat_ms + k_road_ms) * 1e-3)) / 1e9 if k_feat_ms > 0 else 0.0,
         "whole_step_GBps": ((proj_bytes + feat_bytes) * (B // S) * args.steps / elapsed) / 1e9,
     }
 
@@ -264,6 +287,7 @@ def main():
                          f"{B} device-resident frames per step per GPU in launch sets of {S}, plane-as-input"),
             "frames_per_step": B,
             "frame_slots_per_launch": S,
+            "contexts": NC,
             "features_per_frame": F,
             "points_per_frame": N,
             "sequences": world,

@@ -38,6 +38,7 @@ struct Slot {
     size_t inl_cap = 0;
     uint32_t* mask_buf = nullptr;
     size_t mask_words = 0;
+    size_t road_cap = 0;  // entries of d.road_queue
     // lazy PointcloudData for the debug getters
     bool full_valid = false;
     size_t dbg_cap = 0;
@@ -68,6 +69,7 @@ struct mld_ctx {
     bool own_stream = true;
     std::vector<Slot> slots;
     SlotDesc* d_slots = nullptr;
+    int32_t* road_counts = nullptr;  // per-slot queue lengths of the road-fallback kernel, contiguous
     uint32_t* bitmaps = nullptr;  // occupancy bitmaps of all slots, contiguous
     size_t bitmap_words = 0;      // per slot
     std::vector<SlotDesc> h_descs;
@@ -230,6 +232,10 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     // MLD_FORCE_WAVE_PATH=1 disables the thread-per-feature fast path (tests exercise both code paths)
     const char* force = std::getenv("MLD_FORCE_WAVE_PATH");
     c.threadPath = (force && force[0] == '1') ? 0 : 1;
+    // the thread path hands road-fallback candidates to a second kernel (dense lanes); MLD_NO_SPLIT_ROAD=1 keeps
+    // them inline
+    const char* nosplit = std::getenv("MLD_NO_SPLIT_ROAD");
+    c.splitRoad = (c.threadPath && c.useRoad && !(nosplit && nosplit[0] == '1')) ? 1 : 0;
     // list capacity of the thread path: 32 entries (8 KB of LDS per wave) keeps 16+ waves per CU resident;
     // longer lists overflow to the wave-cooperative path.  MLD_K1MAX overrides (8..64) for experiments.
     int k1max = 32;
@@ -336,16 +342,44 @@ int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int sl
     return MLD_OK;
 }
 
+// The road-fallback queue of a slot must hold one entry per feature.
+int ensure_road_queue(mld_ctx* ctx, Slot& s, int64_t F) {
+    if (!ctx->calib.splitRoad || (size_t)F <= s.road_cap) return MLD_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (s.d.road_queue) HIP_TRY(ctx, hipFree(s.d.road_queue));
+    s.d.road_queue = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&s.d.road_queue, (size_t)F * 2 * sizeof(int32_t)));
+    s.road_cap = (size_t)F;
+    return MLD_OK;
+}
+
 int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int slot) {
     if (max_F <= 0) return MLD_OK;
     int per_slot = (int)((max_F + kWave - 1) / kWave);
-    ScopedTimer tm(ctx, 1);
-    if (single) {
-        hipLaunchKernelGGL(k_feature_depth, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
-                           ctx->slots[slot].d, 1, ctx->calib, 1, per_slot);
-    } else {
-        hipLaunchKernelGGL(k_feature_depth, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
-                           ctx->stream, ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot);
+    const bool split = ctx->calib.splitRoad != 0;
+    if (split) {
+        int32_t* cnt = single ? ctx->slots[slot].d.road_count : ctx->road_counts;
+        HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(single ? 1 : n_slots), ctx->stream));
+    }
+    {
+        ScopedTimer tm(ctx, 1);
+        if (single) {
+            hipLaunchKernelGGL(k_feature_depth, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
+                               ctx->slots[slot].d, 1, ctx->calib, 1, per_slot);
+        } else {
+            hipLaunchKernelGGL(k_feature_depth, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
+                               ctx->stream, ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot);
+        }
+    }
+    if (split) {
+        ScopedTimer tm(ctx, 2);
+        if (single) {
+            hipLaunchKernelGGL(k_feature_road, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
+                               ctx->slots[slot].d, 1, ctx->calib, 1, per_slot);
+        } else {
+            hipLaunchKernelGGL(k_feature_road, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
+                               ctx->stream, ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot);
+        }
     }
     HIP_TRY(ctx, hipGetLastError());
     return MLD_OK;
@@ -501,6 +535,9 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if (ctx->lds_bytes > 48 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_depth),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_road),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
         if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute");
     }
     ctx->slots.resize(max_frames);
@@ -512,6 +549,9 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if ((e = hipMalloc((void**)&ctx->bitmaps, ctx->bitmap_words * sizeof(uint32_t) * (size_t)max_frames)) != hipSuccess)
         return hip_bail(e, "hipMalloc(bitmaps)");
     for (size_t si = 0; si < ctx->slots.size(); si++) ctx->slots[si].d.bitmap = ctx->bitmaps + si * ctx->bitmap_words;
+    if ((e = hipMalloc((void**)&ctx->road_counts, sizeof(int32_t) * (size_t)max_frames)) != hipSuccess)
+        return hip_bail(e, "hipMalloc(road_counts)");
+    for (size_t si = 0; si < ctx->slots.size(); si++) ctx->slots[si].d.road_count = ctx->road_counts + si;
     for (Slot& s : ctx->slots) {
         if ((e = hipMalloc((void**)&s.d.map, cells * sizeof(uint32_t))) != hipSuccess) return hip_bail(e, "hipMalloc(map)");
         if ((e = hipMemsetAsync(s.d.map, 0, cells * sizeof(uint32_t), ctx->stream)) != hipSuccess)
@@ -539,6 +579,7 @@ void mld_destroy(mld_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (Slot& s : ctx->slots) {
+        if (s.d.road_queue) (void)hipFree(s.d.road_queue);
         void* ptrs[] = {s.d.map,  s.cloud_buf, s.uv_buf, s.depth_buf, s.type_buf, s.inl_buf,    s.mask_buf, s.cam,
                         s.img,    s.vis,       s.rank,   s.pidx,      s.img_vis,  s.block_sums, s.d_total};
         for (void* p : ptrs)
@@ -546,6 +587,7 @@ void mld_destroy(mld_ctx* ctx) {
     }
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->bitmaps) (void)hipFree(ctx->bitmaps);
+    if (ctx->road_counts) (void)hipFree(ctx->road_counts);
     void* rsp[] = {ctx->rs_flags, ctx->rs_cand, ctx->rs_block, ctx->rs_M, ctx->rs_S, ctx->rs_sample, ctx->rs_sp,
                    ctx->rs_counts, ctx->rs_inl, ctx->rs_res};
     for (void* p : rsp)
@@ -770,6 +812,10 @@ static int calc_one(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, dou
     s.d.depth = depth_dev;
     s.d.type = type_dev;
     if (F == 0) return MLD_OK;
+    {
+        int rcq = ensure_road_queue(ctx, s, F);
+        if (rcq) return rcq;
+    }
     if (ctx->P.set_all_depths_to_zero) {
         hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)((F + 255) / 256)), dim3(256), 0, ctx->stream, depth_dev,
                            type_dev, (long long)F);
@@ -838,6 +884,7 @@ int mld_calculate_depths_device(mld_ctx* ctx, int n_slots, const double* const* 
         s.d.F = F[i];
         s.d.depth = depth_out_dev[i];
         s.d.type = type_out_dev ? type_out_dev[i] : nullptr;
+        if ((rc = ensure_road_queue(ctx, s, F[i]))) return rc;
         max_F = std::max(max_F, F[i]);
     }
     if (ctx->P.set_all_depths_to_zero) {

@@ -39,6 +39,7 @@ struct Calib {
     int usePCA;
     int bmStride;    // words per row of the occupancy bitmap: ceil(W/32) + 2 (8-byte reads never overrun a row)
     int k1max;       // thread path: neighbour list capacity per feature (entries in LDS)
+    int splitRoad;   // 1: the thread path queues road-fallback candidates for k_feature_road instead of running them inline
     int threadPath;  // 1: thread-per-feature fast path with wave-cooperative overflow; 0: wave path only
 };
 
@@ -51,6 +52,8 @@ struct SlotDesc {
     double* depth;                // F
     int32_t* type;                // F or nullptr
     const uint32_t* inlier_mask;  // bit i = original point i is a ground-plane inlier; nullptr = no plane
+    int32_t* road_queue;          // (feature index, main-path result) pairs queued for k_feature_road
+    int32_t* road_count;          // number of queued pairs (zeroed before every CalculateDepth launch)
     const long long* F_dev;       // optional device-side feature count (<= F); used when the count is produced on the GPU
     long long n;                  // points
     long long F;                  // features

@@ -747,7 +747,7 @@ __device__ __forceinline__ void finish_road(const Calib& c, bool triangle, doubl
 
 __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, unsigned char* smem, const int lane,
                                        const unsigned long long mask, const double myu, const double myv, int& mytype,
-                                       double& mydepth) {
+                                       double& mydepth, const bool road_only = false) {
     Lists L;
     L.x = reinterpret_cast<double*>(smem);
     L.y = L.x + c.cap;
@@ -761,7 +761,8 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
     int mystate = ST_FINAL;
 
     // ---------------- phase 1 ----------------
-    for (unsigned long long m1 = mask; m1; m1 &= m1 - 1) {
+    // (road_only: the features already went through the main path; mytype holds its result)
+    for (unsigned long long m1 = road_only ? 0ull : mask; m1; m1 &= m1 - 1) {
         const int fi = __ffsll((long long)m1) - 1;
         const double u = readlane_f64(myu, fi), v = readlane_f64(myv, fi);
         int state = ST_FINAL, type = MLD_Unspecified;
@@ -1258,6 +1259,143 @@ __device__ __forceinline__ bool triangle_thread(const Calib& c, const SlotDesc& 
     return ok;
 }
 
+// Road fallback of the thread path (DepthEstimator.cpp:578-597) for the lanes with `cand` set; mytype holds the main
+// path's result (resultOld) on entry.  Lanes whose wide-window list exceeds the capacities set `overflow`.
+__device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, bool cand,
+                                            const double myu, const double myv, int& mytype, double& mydepth,
+                                            bool& overflow) {
+    const int resultOld = mytype;
+    int k2 = scan_window_thread(c, s, myu, myv, c.halfX2, c.halfY2, cand, lst, lane);
+    if (cand && k2 > c.k1max) {
+        overflow = true;
+        cand = false;
+    }
+    if (cand && (unsigned)k2 < c.countMin) {
+        mytype = MLD_RadiusSearchInsufficientPoints;
+        mydepth = -1.0;
+        cand = false;
+    }
+    // CalculateDepthSegmentationPlane (DepthEstimator.cpp:782-900) + first M-estimator pass, serial order
+    const int n2 = cand ? k2 : 0;
+    const int n2max = uniform(wave_max_i32(n2));
+    bool far = false;
+    int kk = 0;
+    double zmn = 1.7976931348623157e308, zmx = -1.7976931348623157e308;
+    double xmn = zmn, xmx = zmx;
+    double sw = 0, sx = 0, sy = 0, sz = 0;
+    const V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
+    for (int e0 = 0; e0 < n2max; e0 += 4) {
+        RawP rp[4];
+        uint32_t ids[4], mw[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            ids[q] = LST_ID(e0 + q, n2);
+            rp[q] = load_raw(s, ids[q]);
+            mw[q] = GPTR(uint32_t, s.inlier_mask)[ids[q] >> 5];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (e0 + q < n2) {
+            const uint32_t id = ids[q];
+            V3 p = raw_point(c, rp[q]);
+            double xl = c.Tinv[3] + (c.Tinv[0] * p.x + (c.Tinv[1] * p.y + c.Tinv[2] * p.z));
+            double yl = c.Tinv[7] + (c.Tinv[4] * p.x + (c.Tinv[5] * p.y + c.Tinv[6] * p.z));
+            double zl = c.Tinv[11] + (c.Tinv[8] * p.x + (c.Tinv[9] * p.y + c.Tinv[10] * p.z));
+            float xf = (float)xl, yf = (float)yl, zf = (float)zl;
+            float d = fabsf(s.coeffs[0] * xf + s.coeffs[1] * yf + s.coeffs[2] * zf + s.coeffs[3]);
+            far = far || ((double)d > c.roadDistThr);
+            bool inl = (mw[q] >> (id & 31)) & 1u;
+            if (inl) {
+                LST(kk) = id;
+                kk++;
+                if (p.z < zmn) zmn = p.z;
+                if (p.z > zmx) zmx = p.z;
+                if (p.x < xmn) xmn = p.x;
+                if (p.x > xmx) xmx = p.x;
+                double w = 1 / fabs(vdot(pn, p) + s.prior_off);  // PlaneEstimationMEstimator.cpp:32
+                sx += w * p.x;
+                sy += w * p.y;
+                sz += w * p.z;
+                sw += w;
+            }
+          }
+        }
+    }
+    if (cand && (far || kk < 3)) {
+        mytype = resultOld;  // :591
+        mydepth = -1.0;
+        cand = false;
+    }
+    double rr[kRecFields];
+#pragma unroll
+    for (int t = 0; t < kRecFields; t++) rr[t] = 0.0;
+    rr[9] = zmn;
+    rr[10] = zmx;
+    if (c.roadMode == 0) {
+        const double cx = sx / sw, cy = sy / sw, cz = sz / sw;
+        const int n3 = cand ? kk : 0;
+        const int n3max = uniform(wave_max_i32(n3));
+        double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+        for (int e0 = 0; e0 < n3max; e0 += 4) {
+            RawP rp[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) rp[q] = load_raw(s, LST_ID(e0 + q, n3));
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              if (e0 + q < n3) {
+                V3 p = raw_point(c, rp[q]);
+                double w = 1 / fabs(vdot(pn, p) + s.prior_off);
+                double dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
+                c0 += w * dx * dx;
+                c1 += w * dx * dy;
+                c2 += w * dx * dz;
+                c3 += w * dy * dy;
+                c4 += w * dy * dz;
+                c5 += w * dz * dz;
+              }
+            }
+        }
+        rr[0] = cx; rr[1] = cy; rr[2] = cz;
+        rr[3] = c0; rr[4] = c1; rr[5] = c2; rr[6] = c3; rr[7] = c4; rr[8] = c5;
+        if (cand) finish_road(c, false, myu, myv, rr, mytype, mydepth);
+    } else {
+        // RoadDepthEstimatorMaxSpanningTriangle::CalculateDepth (:24-75)
+        if (cand && kk > kK2Max) {
+            overflow = true;
+            cand = false;
+        }
+        V3 c1, c2, c3;
+        bool ok = triangle_small<kTriSmall>(c, s, kk, cand && kk <= kTriSmall, lst, lane, c1, c2, c3);
+        if (__any(cand && kk > kTriSmall)) {
+            V3 d1, d2, d3;
+            bool ok2 = triangle_thread(c, s, kk, cand && kk > kTriSmall, lst, lane, d1, d2, d3);
+            if (kk > kTriSmall) {
+                ok = ok2;
+                c1 = d1;
+                c2 = d2;
+                c3 = d3;
+            }
+        }
+        if (cand && !ok) {
+            mytype = MLD_RadiusSearchInsufficientPoints;
+            mydepth = -1.0;
+            cand = false;
+        }
+        if (cand) {
+            double relation = (zmx - zmn) / (xmx - xmn);
+            if (!(relation >= c.zxMinRel)) {
+                mytype = MLD_InsufficientRoadPoints;
+                mydepth = -1.0;
+                cand = false;
+            }
+        }
+        rr[0] = c1.x; rr[1] = c1.y; rr[2] = c1.z;
+        rr[3] = c2.x; rr[4] = c2.y; rr[5] = c2.z;
+        rr[6] = c3.x; rr[7] = c3.y; rr[8] = c3.z;
+        if (cand) finish_road(c, true, myu, myv, rr, mytype, mydepth);
+    }
+}
+
 __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restrict__ slots, SlotDesc single,
                                                          int use_single, Calib c, int n_slots, int per_slot) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1504,136 +1642,22 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
         const bool road_on = c.useRoad && s.has_plane;
         bool cand = road_on && active && !overflow && (mytype != MLD_Success) &&
                     (mytype != MLD_RadiusSearchInsufficientPoints);
-        if (__any(cand)) {
-            const int resultOld = mytype;
-            int k2 = scan_window_thread(c, s, myu, myv, c.halfX2, c.halfY2, cand, lst, lane);
-            if (cand && k2 > c.k1max) {
-                overflow = true;
-                cand = false;
-            }
-            if (cand && (unsigned)k2 < c.countMin) {
-                mytype = MLD_RadiusSearchInsufficientPoints;
-                mydepth = -1.0;
-                cand = false;
-            }
-            // CalculateDepthSegmentationPlane (DepthEstimator.cpp:782-900) + first M-estimator pass, serial order
-            const int n2 = cand ? k2 : 0;
-            const int n2max = uniform(wave_max_i32(n2));
-            bool far = false;
-            int kk = 0;
-            double zmn = 1.7976931348623157e308, zmx = -1.7976931348623157e308;
-            double xmn = zmn, xmx = zmx;
-            double sw = 0, sx = 0, sy = 0, sz = 0;
-            const V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
-            for (int e0 = 0; e0 < n2max; e0 += 4) {
-                RawP rp[4];
-                uint32_t ids[4], mw[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    ids[q] = LST_ID(e0 + q, n2);
-                    rp[q] = load_raw(s, ids[q]);
-                    mw[q] = GPTR(uint32_t, s.inlier_mask)[ids[q] >> 5];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                  if (e0 + q < n2) {
-                    const uint32_t id = ids[q];
-                    V3 p = raw_point(c, rp[q]);
-                    double xl = c.Tinv[3] + (c.Tinv[0] * p.x + (c.Tinv[1] * p.y + c.Tinv[2] * p.z));
-                    double yl = c.Tinv[7] + (c.Tinv[4] * p.x + (c.Tinv[5] * p.y + c.Tinv[6] * p.z));
-                    double zl = c.Tinv[11] + (c.Tinv[8] * p.x + (c.Tinv[9] * p.y + c.Tinv[10] * p.z));
-                    float xf = (float)xl, yf = (float)yl, zf = (float)zl;
-                    float d = fabsf(s.coeffs[0] * xf + s.coeffs[1] * yf + s.coeffs[2] * zf + s.coeffs[3]);
-                    far = far || ((double)d > c.roadDistThr);
-                    bool inl = (mw[q] >> (id & 31)) & 1u;
-                    if (inl) {
-                        LST(kk) = id;
-                        kk++;
-                        if (p.z < zmn) zmn = p.z;
-                        if (p.z > zmx) zmx = p.z;
-                        if (p.x < xmn) xmn = p.x;
-                        if (p.x > xmx) xmx = p.x;
-                        double w = 1 / fabs(vdot(pn, p) + s.prior_off);  // PlaneEstimationMEstimator.cpp:32
-                        sx += w * p.x;
-                        sy += w * p.y;
-                        sz += w * p.z;
-                        sw += w;
-                    }
-                  }
-                }
-            }
-            if (cand && (far || kk < 3)) {
-                mytype = resultOld;  // :591
-                mydepth = -1.0;
-                cand = false;
-            }
-            double rr[kRecFields];
-#pragma unroll
-            for (int t = 0; t < kRecFields; t++) rr[t] = 0.0;
-            rr[9] = zmn;
-            rr[10] = zmx;
-            if (c.roadMode == 0) {
-                const double cx = sx / sw, cy = sy / sw, cz = sz / sw;
-                const int n3 = cand ? kk : 0;
-                const int n3max = uniform(wave_max_i32(n3));
-                double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
-                for (int e0 = 0; e0 < n3max; e0 += 4) {
-                    RawP rp[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) rp[q] = load_raw(s, LST_ID(e0 + q, n3));
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                      if (e0 + q < n3) {
-                        V3 p = raw_point(c, rp[q]);
-                        double w = 1 / fabs(vdot(pn, p) + s.prior_off);
-                        double dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
-                        c0 += w * dx * dx;
-                        c1 += w * dx * dy;
-                        c2 += w * dx * dz;
-                        c3 += w * dy * dy;
-                        c4 += w * dy * dz;
-                        c5 += w * dz * dz;
-                      }
-                    }
-                }
-                rr[0] = cx; rr[1] = cy; rr[2] = cz;
-                rr[3] = c0; rr[4] = c1; rr[5] = c2; rr[6] = c3; rr[7] = c4; rr[8] = c5;
-                if (cand) finish_road(c, false, myu, myv, rr, mytype, mydepth);
-            } else {
-                // RoadDepthEstimatorMaxSpanningTriangle::CalculateDepth (:24-75)
-                if (cand && kk > kK2Max) {
-                    overflow = true;
-                    cand = false;
-                }
-                V3 c1, c2, c3;
-                bool ok = triangle_small<kTriSmall>(c, s, kk, cand && kk <= kTriSmall, lst, lane, c1, c2, c3);
-                if (__any(cand && kk > kTriSmall)) {
-                    V3 d1, d2, d3;
-                    bool ok2 = triangle_thread(c, s, kk, cand && kk > kTriSmall, lst, lane, d1, d2, d3);
-                    if (kk > kTriSmall) {
-                        ok = ok2;
-                        c1 = d1;
-                        c2 = d2;
-                        c3 = d3;
-                    }
-                }
-                if (cand && !ok) {
-                    mytype = MLD_RadiusSearchInsufficientPoints;
-                    mydepth = -1.0;
-                    cand = false;
-                }
+        const unsigned long long cmask = __ballot(cand);
+        if (cmask) {
+            if (c.splitRoad) {
+                // hand the candidates to k_feature_road (dense lanes there instead of ~half-idle waves here)
+                int qbase = 0;
+                if (lane == 0)
+                    qbase = __hip_atomic_fetch_add(GPTRW(int32_t, s.road_count), (int)__popcll(cmask), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                qbase = uniform(qbase);
                 if (cand) {
-                    double relation = (zmx - zmn) / (xmx - xmn);
-                    if (!(relation >= c.zxMinRel)) {
-                        mytype = MLD_InsufficientRoadPoints;
-                        mydepth = -1.0;
-                        cand = false;
-                    }
+                    const int pos = qbase + prefix_count(cmask);
+                    GPTRW(int32_t, s.road_queue)[2 * (size_t)pos] = (int32_t)(f0 + lane);
+                    GPTRW(int32_t, s.road_queue)[2 * (size_t)pos + 1] = mytype;
                 }
-                rr[0] = c1.x; rr[1] = c1.y; rr[2] = c1.z;
-                rr[3] = c2.x; rr[4] = c2.y; rr[5] = c2.z;
-                rr[6] = c3.x; rr[7] = c3.y; rr[8] = c3.z;
-                if (cand) finish_road(c, true, myu, myv, rr, mytype, mydepth);
+            } else {
+                road_thread(c, s, lst, lane, cand, myu, myv, mytype, mydepth, overflow);
             }
         }
     } else {
@@ -1647,6 +1671,40 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
     if (active) {
         GPTRW(double, s.depth)[f0 + lane] = mydepth;
         if (s.type) GPTRW(int32_t, s.type)[f0 + lane] = mytype;
+    }
+}
+
+// Road fallback for the features queued by k_feature_depth (thread path, splitRoad): one lane per queued feature.
+__global__ __launch_bounds__(kWave) void k_feature_road(const SlotDesc* __restrict__ slots, SlotDesc single, int use_single,
+                                                        Calib c, int n_slots, int per_slot) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int slot, j;
+    decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
+    const SlotDesc s = use_single ? single : slots[slot];
+    if (!s.road_count) return;
+    const int count = *GPTR(int32_t, s.road_count);
+    const int e0 = j * kWave;
+    if (e0 >= count) return;
+    const int lane = threadIdx.x;
+    const bool active = e0 + lane < count;
+    uint32_t* lst = reinterpret_cast<uint32_t*>(smem);
+    long long f = 0;
+    int mytype = MLD_Unspecified;
+    double mydepth = -1.0, myu = 0, myv = 0;
+    if (active) {
+        f = (long long)GPTR(int32_t, s.road_queue)[2 * (size_t)(e0 + lane)];
+        mytype = GPTR(int32_t, s.road_queue)[2 * (size_t)(e0 + lane) + 1];
+        const auto* q = GPTR(double, s.uv) + 2 * f;
+        myu = q[0];
+        myv = q[1];
+    }
+    bool overflow = false;
+    road_thread(c, s, lst, lane, active, myu, myv, mytype, mydepth, overflow);
+    const unsigned long long om = __ballot(overflow && active);
+    if (om) wave_path(c, s, smem, lane, om, myu, myv, mytype, mydepth, true);
+    if (active) {
+        GPTRW(double, s.depth)[f] = mydepth;
+        if (s.type) GPTRW(int32_t, s.type)[f] = mytype;
     }
 }
 

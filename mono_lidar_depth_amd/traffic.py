@@ -54,10 +54,12 @@ def frame_bytes(params, width: int, height: int, n_points: int, n_visible: int, 
     road_on = bool(params.do_use_ransac_plane) and has_plane
     fallback = road_on & (types != 1) & (k1 >= max(params.radiusSearch_count_min, 0))
     b_project = 16 * n_points + 4 * width * height + 28 * n_visible
-    b_feature = int((16 + 4 * P1 + 24 * k1 + 12).sum() + (fallback * (4 * P2 + 25 * k2)).sum())
+    b_road = int((fallback * (4 * P2 + 25 * k2)).sum())
+    b_feature = int((16 + 4 * P1 + 24 * k1 + 12).sum()) + b_road
     return {
         "project_bytes": int(b_project),
         "feature_bytes": int(b_feature),
+        "road_bytes": int(b_road),
         "n_visible": int(n_visible),
         "k1_mean": float(k1.mean()) if k1.size else 0.0,
         "k2_mean_fallback": float(k2[fallback].mean()) if fallback.any() else 0.0,
