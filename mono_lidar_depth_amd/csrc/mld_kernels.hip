@@ -185,21 +185,26 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
     // Occupancy bits (lets the feature kernel skip the mostly empty key rows).  Consecutive lanes hold consecutive
     // points of a scan ring, i.e. neighbouring pixels of one image row: bits of a run of lanes with the same bitmap
     // word are OR-ed along the run and only the run's last lane issues the atomic (~10x fewer atomics).  Runs need
-    // not be exact: every lane's bit reaches the last lane of its contiguous run, which always writes.
-    const int lane = threadIdx.x & (kWave - 1);
+    // not be exact: every lane's bit reaches the last lane of its contiguous run (within its 16-lane row), which
+    // always writes.
 #pragma unroll
     for (int r = 0; r < kProjPerThread; r++) {
         int w = bmw[r];
         uint32_t bits = bmb[r];
-#pragma unroll
-        for (int d = 1; d <= 32; d <<= 1) {  // full wave: a run can be as long as the wavefront (dense clouds)
-            const int wn = __shfl_up(w, d);
-            const uint32_t bn = __shfl_up(bits, d);
-            if (lane >= d && wn == w) bits |= bn;
-        }
-        const int wnext = __shfl_down(w, 1);
-        const bool leader = (lane == kWave - 1) || (wnext != w);
-        if (leader && bits)
+        // DPP row shifts (no LDS traffic): runs are merged inside 16-lane rows; a row's last lane always writes
+#define MLD_ROW_STEP(D)                                                                                     \
+    {                                                                                                       \
+        const int wn = __builtin_amdgcn_update_dpp((int)-0x40000000, w, 0x110 + (D), 0xf, 0xf, false);      \
+        const uint32_t bn = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0x110 + (D), 0xf, 0xf, false); \
+        if (wn == w) bits |= bn;                                                                            \
+    }
+        MLD_ROW_STEP(1)
+        MLD_ROW_STEP(2)
+        MLD_ROW_STEP(4)
+        MLD_ROW_STEP(8)
+#undef MLD_ROW_STEP
+        const int wnext = __builtin_amdgcn_update_dpp((int)-0x40000000, w, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+        if ((wnext != w) && bits)
             __hip_atomic_fetch_or(GPTRW(uint32_t, s.bitmap) + (size_t)w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
