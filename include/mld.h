@@ -258,7 +258,7 @@ int mld_result_histogram(const int32_t* types, int64_t F, int64_t counts[MLD_RES
 /*
  * Measurement hooks for bench.py (HIP events on the context's stream).
  *   mld_kernel_time_ms: average duration in ms of the `which` kernel (0 = project/scatter,
- *   1 = feature depth, 2 = road fallback) over the launches since mld_timing_reset, measured with hipEvents recorded
+ *   1 = feature depth, 2 = road fallback, 3 = long-list wave kernel) over the launches since mld_timing_reset, measured with hipEvents recorded
  *   around each launch when timing is enabled.
  */
 int mld_timing_enable(mld_ctx* ctx, int enable);

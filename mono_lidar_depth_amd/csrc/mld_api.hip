@@ -344,11 +344,14 @@ int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int sl
 
 // The road-fallback queue of a slot must hold one entry per feature.
 int ensure_road_queue(mld_ctx* ctx, Slot& s, int64_t F) {
-    if (!ctx->calib.splitRoad || (size_t)F <= s.road_cap) return MLD_OK;
+    if ((size_t)F <= s.road_cap) return MLD_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (s.d.road_queue) HIP_TRY(ctx, hipFree(s.d.road_queue));
+    if (s.d.ovf_queue) HIP_TRY(ctx, hipFree(s.d.ovf_queue));
     s.d.road_queue = nullptr;
+    s.d.ovf_queue = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&s.d.road_queue, (size_t)F * 2 * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&s.d.ovf_queue, (size_t)F * 2 * sizeof(int32_t)));
     s.road_cap = (size_t)F;
     return MLD_OK;
 }
@@ -357,18 +360,21 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     if (max_F <= 0) return MLD_OK;
     int per_slot = (int)((max_F + kWave - 1) / kWave);
     const bool split = ctx->calib.splitRoad != 0;
-    if (split) {
-        int32_t* cnt = single ? ctx->slots[slot].d.road_count : ctx->road_counts;
-        HIP_TRY(ctx, hipMemsetAsync(cnt, 0, sizeof(int32_t) * (size_t)(single ? 1 : n_slots), ctx->stream));
+    if (single) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->slots[slot].d.road_count, 0, sizeof(int32_t), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->slots[slot].d.ovf_count, 0, sizeof(int32_t), ctx->stream));
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->road_counts, 0, sizeof(int32_t) * 2 * ctx->slots.size(), ctx->stream));
     }
     {
         ScopedTimer tm(ctx, 1);
+        auto kern = split ? k_feature_depth<true> : k_feature_depth<false>;
         if (single) {
-            hipLaunchKernelGGL(k_feature_depth, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
+            hipLaunchKernelGGL(kern, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
                                ctx->slots[slot].d, 1, ctx->calib, 1, per_slot);
         } else {
-            hipLaunchKernelGGL(k_feature_depth, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
-                               ctx->stream, ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot);
+            hipLaunchKernelGGL(kern, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes, ctx->stream,
+                               ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot);
         }
     }
     if (split) {
@@ -379,6 +385,18 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         } else {
             hipLaunchKernelGGL(k_feature_road, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
                                ctx->stream, ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot);
+        }
+    }
+    {
+        ScopedTimer tm(ctx, 3);
+        // a batch gets 4 blocks per slot, a single slot up to 256: each block strides over the slot's queue
+        const int pw = single ? std::min(per_slot, 256) : std::min(per_slot, 4);
+        if (single) {
+            hipLaunchKernelGGL(k_feature_wave, dim3(pw), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
+                               ctx->slots[slot].d, 1, ctx->calib, 1, pw);
+        } else {
+            hipLaunchKernelGGL(k_feature_wave, dim3((unsigned)pw * n_slots), dim3(kWave), ctx->lds_bytes, ctx->stream,
+                               ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, pw);
         }
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -533,10 +551,16 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
         return hip_bail(e, "hipStreamCreate");
     if (ctx->lds_bytes > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_depth),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_depth<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
         if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_depth<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
+        if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_road),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_wave),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
         if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute");
     }
@@ -549,9 +573,13 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if ((e = hipMalloc((void**)&ctx->bitmaps, ctx->bitmap_words * sizeof(uint32_t) * (size_t)max_frames)) != hipSuccess)
         return hip_bail(e, "hipMalloc(bitmaps)");
     for (size_t si = 0; si < ctx->slots.size(); si++) ctx->slots[si].d.bitmap = ctx->bitmaps + si * ctx->bitmap_words;
-    if ((e = hipMalloc((void**)&ctx->road_counts, sizeof(int32_t) * (size_t)max_frames)) != hipSuccess)
+    // queue lengths: [0, max_frames) road fallback, [max_frames, 2*max_frames) long-list overflow
+    if ((e = hipMalloc((void**)&ctx->road_counts, sizeof(int32_t) * 2 * (size_t)max_frames)) != hipSuccess)
         return hip_bail(e, "hipMalloc(road_counts)");
-    for (size_t si = 0; si < ctx->slots.size(); si++) ctx->slots[si].d.road_count = ctx->road_counts + si;
+    for (size_t si = 0; si < ctx->slots.size(); si++) {
+        ctx->slots[si].d.road_count = ctx->road_counts + si;
+        ctx->slots[si].d.ovf_count = ctx->road_counts + (size_t)max_frames + si;
+    }
     for (Slot& s : ctx->slots) {
         if ((e = hipMalloc((void**)&s.d.map, cells * sizeof(uint32_t))) != hipSuccess) return hip_bail(e, "hipMalloc(map)");
         if ((e = hipMemsetAsync(s.d.map, 0, cells * sizeof(uint32_t), ctx->stream)) != hipSuccess)
@@ -580,6 +608,7 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (Slot& s : ctx->slots) {
         if (s.d.road_queue) (void)hipFree(s.d.road_queue);
+        if (s.d.ovf_queue) (void)hipFree(s.d.ovf_queue);
         void* ptrs[] = {s.d.map,  s.cloud_buf, s.uv_buf, s.depth_buf, s.type_buf, s.inl_buf,    s.mask_buf, s.cam,
                         s.img,    s.vis,       s.rank,   s.pidx,      s.img_vis,  s.block_sums, s.d_total};
         for (void* p : ptrs)

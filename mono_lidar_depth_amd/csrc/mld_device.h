@@ -54,6 +54,8 @@ struct SlotDesc {
     const uint32_t* inlier_mask;  // bit i = original point i is a ground-plane inlier; nullptr = no plane
     int32_t* road_queue;          // (feature index, main-path result) pairs queued for k_feature_road
     int32_t* road_count;          // number of queued pairs (zeroed before every CalculateDepth launch)
+    int32_t* ovf_queue;           // (feature index, code) pairs queued for k_feature_wave (long lists)
+    int32_t* ovf_count;
     const long long* F_dev;       // optional device-side feature count (<= F); used when the count is produced on the GPU
     long long n;                  // points
     long long F;                  // features

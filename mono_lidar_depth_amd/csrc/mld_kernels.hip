@@ -752,7 +752,7 @@ __device__ __forceinline__ void finish_road(const Calib& c, bool triangle, doubl
 
 __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, unsigned char* smem, const int lane,
                                        const unsigned long long mask, const double myu, const double myv, int& mytype,
-                                       double& mydepth, const bool road_only = false) {
+                                       double& mydepth, const unsigned long long main_mask) {
     Lists L;
     L.x = reinterpret_cast<double*>(smem);
     L.y = L.x + c.cap;
@@ -766,8 +766,8 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
     int mystate = ST_FINAL;
 
     // ---------------- phase 1 ----------------
-    // (road_only: the features already went through the main path; mytype holds its result)
-    for (unsigned long long m1 = road_only ? 0ull : mask; m1; m1 &= m1 - 1) {
+    // (lanes of `mask` outside `main_mask` already went through the main path; mytype holds its result)
+    for (unsigned long long m1 = main_mask; m1; m1 &= m1 - 1) {
         const int fi = __ffsll((long long)m1) - 1;
         const double u = readlane_f64(myu, fi), v = readlane_f64(myv, fi);
         int state = ST_FINAL, type = MLD_Unspecified;
@@ -1264,6 +1264,22 @@ __device__ __forceinline__ bool triangle_thread(const Calib& c, const SlotDesc& 
     return ok;
 }
 
+// Appends (feature index, code) for the lanes with `want` set to a per-slot queue; one atomic per wavefront.
+__device__ __forceinline__ void enqueue_features(int32_t* queue, int32_t* count, bool want, int lane, long long feature,
+                                                 int code) {
+    const unsigned long long m = __ballot(want);
+    if (!m) return;
+    int qbase = 0;
+    if (lane == 0)
+        qbase = __hip_atomic_fetch_add(GPTRW(int32_t, count), (int)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    qbase = uniform(qbase);
+    if (want) {
+        const int pos = qbase + prefix_count(m);
+        GPTRW(int32_t, queue)[2 * (size_t)pos] = (int32_t)feature;
+        GPTRW(int32_t, queue)[2 * (size_t)pos + 1] = code;
+    }
+}
+
 // Road fallback of the thread path (DepthEstimator.cpp:578-597) for the lanes with `cand` set; mytype holds the main
 // path's result (resultOld) on entry.  Lanes whose wide-window list exceeds the capacities set `overflow`.
 __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, bool cand,
@@ -1401,6 +1417,8 @@ __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, u
     }
 }
 
+// SPLIT_ROAD: road-fallback candidates are queued for k_feature_road (the road code is not part of this kernel).
+template <bool SPLIT_ROAD>
 __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restrict__ slots, SlotDesc single,
                                                          int use_single, Calib c, int n_slots, int per_slot) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1428,6 +1446,7 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
     int mytype = MLD_Unspecified;
     double mydepth = -1.0;
     bool overflow = false;
+    int ovf_code = -1;  // -1: the whole feature is redone by the wave kernel; >= 0: only its road part (= main result)
 
     if (c.threadPath) {
         // ---------------- main window (DepthEstimator.cpp:509-576) ----------------
@@ -1649,29 +1668,25 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
                     (mytype != MLD_RadiusSearchInsufficientPoints);
         const unsigned long long cmask = __ballot(cand);
         if (cmask) {
-            if (c.splitRoad) {
+            if (SPLIT_ROAD) {
                 // hand the candidates to k_feature_road (dense lanes there instead of ~half-idle waves here)
-                int qbase = 0;
-                if (lane == 0)
-                    qbase = __hip_atomic_fetch_add(GPTRW(int32_t, s.road_count), (int)__popcll(cmask), __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_AGENT);
-                qbase = uniform(qbase);
-                if (cand) {
-                    const int pos = qbase + prefix_count(cmask);
-                    GPTRW(int32_t, s.road_queue)[2 * (size_t)pos] = (int32_t)(f0 + lane);
-                    GPTRW(int32_t, s.road_queue)[2 * (size_t)pos + 1] = mytype;
-                }
+                enqueue_features(s.road_queue, s.road_count, cand, lane, f0 + lane, mytype);
             } else {
-                road_thread(c, s, lst, lane, cand, myu, myv, mytype, mydepth, overflow);
+                const int resultOld = mytype;
+                bool ovf2 = false;
+                road_thread(c, s, lst, lane, cand, myu, myv, mytype, mydepth, ovf2);
+                if (ovf2) {  // long wide-window list: only the road part is redone by the wave kernel
+                    overflow = true;
+                    ovf_code = resultOld;
+                }
             }
         }
     } else {
         overflow = active;
     }
 
-    // ---------------- long lists: wave-cooperative path ----------------
-    const unsigned long long om = __ballot(overflow && active);
-    if (om) wave_path(c, s, smem, lane, om, myu, myv, mytype, mydepth);
+    // ---------------- long lists: queued for the wave-cooperative kernel (k_feature_wave) ----------------
+    enqueue_features(s.ovf_queue, s.ovf_count, overflow && active, lane, f0 + lane, ovf_code);
 
     if (active) {
         GPTRW(double, s.depth)[f0 + lane] = mydepth;
@@ -1704,12 +1719,49 @@ __global__ __launch_bounds__(kWave) void k_feature_road(const SlotDesc* __restri
         myv = q[1];
     }
     bool overflow = false;
+    const int resultOld = mytype;
     road_thread(c, s, lst, lane, active, myu, myv, mytype, mydepth, overflow);
-    const unsigned long long om = __ballot(overflow && active);
-    if (om) wave_path(c, s, smem, lane, om, myu, myv, mytype, mydepth, true);
+    enqueue_features(s.ovf_queue, s.ovf_count, overflow && active, lane, f, resultOld);
     if (active) {
         GPTRW(double, s.depth)[f] = mydepth;
         if (s.type) GPTRW(int32_t, s.type)[f] = mytype;
+    }
+}
+
+// Wave-cooperative kernel for the features the thread kernels could not hold (lists longer than their capacities).
+// Queue entries: (feature, -1) = main path + road fallback, (feature, t >= 0) = road fallback only, t being the
+// main path's result.
+__global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restrict__ slots, SlotDesc single, int use_single,
+                                                        Calib c, int n_slots, int per_slot) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int slot, j;
+    decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
+    const SlotDesc s = use_single ? single : slots[slot];
+    if (!s.ovf_count) return;
+    const int count = *GPTR(int32_t, s.ovf_count);
+    const int lane = threadIdx.x;
+    // few blocks per slot (the queue is usually empty), each striding over the queue in chunks of 64 entries
+    for (int e0 = j * kWave; e0 < count; e0 += per_slot * kWave) {
+        const bool active = e0 + lane < count;
+        long long f = 0;
+        int code = 0;
+        double myu = 0, myv = 0;
+        if (active) {
+            f = (long long)GPTR(int32_t, s.ovf_queue)[2 * (size_t)(e0 + lane)];
+            code = GPTR(int32_t, s.ovf_queue)[2 * (size_t)(e0 + lane) + 1];
+            const auto* q = GPTR(double, s.uv) + 2 * f;
+            myu = q[0];
+            myv = q[1];
+        }
+        int mytype = code < 0 ? (int)MLD_Unspecified : code;
+        double mydepth = -1.0;
+        const unsigned long long all = __ballot(active);
+        const unsigned long long full = __ballot(active && code < 0);
+        wave_path(c, s, smem, lane, all, myu, myv, mytype, mydepth, full);
+        if (active) {
+            GPTRW(double, s.depth)[f] = mydepth;
+            if (s.type) GPTRW(int32_t, s.type)[f] = mytype;
+        }
     }
 }
 
