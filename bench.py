@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--stat-slots", type=int, default=4, help="slots sampled for the algorithmic-byte statistics")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--timing-every", type=int, default=4,
+                    help="record hipEvents around the kernels of every n-th timed step (event records cost ~6 us each)")
     return ap.parse_args()
 
 
@@ -199,7 +201,9 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for it in range(args.steps):
+        if timing:
+            est.timingEnable(it % max(1, args.timing_every) == 0)  # sampled steps of the timed region
         run_step()
     sync_all()
     torch.cuda.synchronize()

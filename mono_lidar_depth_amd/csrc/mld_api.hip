@@ -69,7 +69,9 @@ struct mld_ctx {
     bool own_stream = true;
     std::vector<Slot> slots;
     SlotDesc* d_slots = nullptr;
-    int32_t* road_counts = nullptr;  // per-slot queue lengths of the road-fallback kernel, contiguous
+    int32_t* road_counts = nullptr;  // per-slot queue lengths (road fallback, then long-list overflow), contiguous,
+                                     // placed in front of the bitmaps so that one fill clears both
+    bool counters_clean = false;
     uint32_t* bitmaps = nullptr;  // occupancy bitmaps of all slots, contiguous
     size_t bitmap_words = 0;      // per slot
     std::vector<SlotDesc> h_descs;
@@ -326,6 +328,15 @@ int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int strid
     return MLD_OK;
 }
 
+// The map tag shared by slots [0, n_slots), or 0 when they differ (then the per-slot tags of the uploaded
+// descriptors are used).
+uint32_t common_tag(mld_ctx* ctx, int n_slots) {
+    const uint32_t t = ctx->slots[0].d.tag;
+    for (int i = 1; i < n_slots; i++)
+        if (ctx->slots[i].d.tag != t) return 0u;
+    return t;
+}
+
 int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int slot) {
     if (max_n <= 0) return MLD_OK;
     const int per_block = kProjThreads * kProjPerThread;
@@ -333,10 +344,10 @@ int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int sl
     ScopedTimer tm(ctx, 0);
     if (single) {
         hipLaunchKernelGGL(k_project_scatter, dim3(per_slot), dim3(kProjThreads), 0, ctx->stream, ctx->d_slots,
-                           ctx->slots[slot].d, 1, ctx->calib, 1, per_slot);
+                           ctx->slots[slot].d, 1, ctx->calib, 1, per_slot, 0u);
     } else {
         hipLaunchKernelGGL(k_project_scatter, dim3((unsigned)per_slot * n_slots), dim3(kProjThreads), 0, ctx->stream,
-                           ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot);
+                           ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot, common_tag(ctx, n_slots));
     }
     HIP_TRY(ctx, hipGetLastError());
     return MLD_OK;
@@ -360,31 +371,30 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     if (max_F <= 0) return MLD_OK;
     int per_slot = (int)((max_F + kWave - 1) / kWave);
     const bool split = ctx->calib.splitRoad != 0;
-    if (single) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->slots[slot].d.road_count, 0, sizeof(int32_t), ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->slots[slot].d.ovf_count, 0, sizeof(int32_t), ctx->stream));
-    } else {
+    const uint32_t tag_all = single ? 0u : common_tag(ctx, n_slots);
+    // queue lengths must be zero at launch; a batched setInputCloud has just cleared them with the bitmaps
+    if (!ctx->counters_clean)
         HIP_TRY(ctx, hipMemsetAsync(ctx->road_counts, 0, sizeof(int32_t) * 2 * ctx->slots.size(), ctx->stream));
-    }
+    ctx->counters_clean = false;
     {
         ScopedTimer tm(ctx, 1);
         auto kern = split ? k_feature_depth<true> : k_feature_depth<false>;
         if (single) {
             hipLaunchKernelGGL(kern, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
-                               ctx->slots[slot].d, 1, ctx->calib, 1, per_slot);
+                               ctx->slots[slot].d, 1, ctx->calib, 1, per_slot, 0u);
         } else {
             hipLaunchKernelGGL(kern, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes, ctx->stream,
-                               ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot);
+                               ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot, tag_all);
         }
     }
     if (split) {
         ScopedTimer tm(ctx, 2);
         if (single) {
             hipLaunchKernelGGL(k_feature_road, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
-                               ctx->slots[slot].d, 1, ctx->calib, 1, per_slot);
+                               ctx->slots[slot].d, 1, ctx->calib, 1, per_slot, 0u);
         } else {
             hipLaunchKernelGGL(k_feature_road, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
-                               ctx->stream, ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot);
+                               ctx->stream, ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot, tag_all);
         }
     }
     {
@@ -393,10 +403,10 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         const int pw = single ? std::min(per_slot, 256) : std::min(per_slot, 4);
         if (single) {
             hipLaunchKernelGGL(k_feature_wave, dim3(pw), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
-                               ctx->slots[slot].d, 1, ctx->calib, 1, pw);
+                               ctx->slots[slot].d, 1, ctx->calib, 1, pw, 0u);
         } else {
             hipLaunchKernelGGL(k_feature_wave, dim3((unsigned)pw * n_slots), dim3(kWave), ctx->lds_bytes, ctx->stream,
-                               ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, pw);
+                               ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, pw, tag_all);
         }
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -404,8 +414,20 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
 }
 
 int upload_descs(mld_ctx* ctx, int n_slots) {
+    // Steady-state batches (same buffers every step) change nothing but the map tags, and a tag common to the
+    // batch travels as a kernel argument: skip the upload when the device copy is still right.
+    const bool tags_by_arg = common_tag(ctx, n_slots) != 0u;
+    bool dirty = false;
+    for (int i = 0; i < n_slots; i++) {
+        SlotDesc d = ctx->slots[i].d;
+        if (tags_by_arg) d.tag = 0;
+        if (std::memcmp(&d, &ctx->h_descs[i], sizeof(SlotDesc)) != 0) {
+            ctx->h_descs[i] = d;
+            dirty = true;
+        }
+    }
+    if (!dirty) return MLD_OK;
     // pageable source: the runtime stages it before returning, so h_descs may be rewritten afterwards
-    for (int i = 0; i < n_slots; i++) ctx->h_descs[i] = ctx->slots[i].d;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slots, ctx->h_descs.data(), sizeof(SlotDesc) * n_slots, hipMemcpyHostToDevice,
                                 ctx->stream));
     return MLD_OK;
@@ -570,12 +592,14 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
         return hip_bail(e, "hipMalloc(slots)");
     size_t cells = (size_t)camera->width * camera->height + kMapPadCells;
     ctx->bitmap_words = (size_t)ctx->calib.bmStride * (size_t)camera->height + 2;
-    if ((e = hipMalloc((void**)&ctx->bitmaps, ctx->bitmap_words * sizeof(uint32_t) * (size_t)max_frames)) != hipSuccess)
+    // one allocation: [queue lengths: max_frames road fallback + max_frames long-list overflow][bitmaps of the slots]
+    const size_t cnt_words = 2 * (size_t)max_frames;
+    if ((e = hipMalloc((void**)&ctx->road_counts, (cnt_words + ctx->bitmap_words * (size_t)max_frames) * sizeof(uint32_t))) != hipSuccess)
         return hip_bail(e, "hipMalloc(bitmaps)");
+    ctx->bitmaps = reinterpret_cast<uint32_t*>(ctx->road_counts) + cnt_words;
+    if ((e = hipMemsetAsync(ctx->road_counts, 0, cnt_words * sizeof(uint32_t), ctx->stream)) != hipSuccess)
+        return hip_bail(e, "hipMemset(counters)");
     for (size_t si = 0; si < ctx->slots.size(); si++) ctx->slots[si].d.bitmap = ctx->bitmaps + si * ctx->bitmap_words;
-    // queue lengths: [0, max_frames) road fallback, [max_frames, 2*max_frames) long-list overflow
-    if ((e = hipMalloc((void**)&ctx->road_counts, sizeof(int32_t) * 2 * (size_t)max_frames)) != hipSuccess)
-        return hip_bail(e, "hipMalloc(road_counts)");
     for (size_t si = 0; si < ctx->slots.size(); si++) {
         ctx->slots[si].d.road_count = ctx->road_counts + si;
         ctx->slots[si].d.ovf_count = ctx->road_counts + (size_t)max_frames + si;
@@ -615,8 +639,7 @@ void mld_destroy(mld_ctx* ctx) {
             if (p) (void)hipFree(p);
     }
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
-    if (ctx->bitmaps) (void)hipFree(ctx->bitmaps);
-    if (ctx->road_counts) (void)hipFree(ctx->road_counts);
+    if (ctx->road_counts) (void)hipFree(ctx->road_counts);  // also holds the bitmaps
     void* rsp[] = {ctx->rs_flags, ctx->rs_cand, ctx->rs_block, ctx->rs_M, ctx->rs_S, ctx->rs_sample, ctx->rs_sp,
                    ctx->rs_counts, ctx->rs_inl, ctx->rs_res};
     for (void* p : rsp)
@@ -675,8 +698,10 @@ int mld_set_clouds_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev,
     int rc = bind_device(ctx);
     if (rc) return rc;
     int64_t max_n = 0;
-    // the slots' occupancy bitmaps are contiguous: one fill for the whole batch
-    HIP_TRY(ctx, hipMemsetAsync(ctx->bitmaps, 0, ctx->bitmap_words * sizeof(uint32_t) * (size_t)n_slots, ctx->stream));
+    // the queue lengths and the slots' occupancy bitmaps are contiguous: one fill for the whole batch
+    HIP_TRY(ctx, hipMemsetAsync(ctx->road_counts, 0,
+                                (2 * ctx->slots.size() + ctx->bitmap_words * (size_t)n_slots) * sizeof(uint32_t), ctx->stream));
+    ctx->counters_clean = true;
     for (int i = 0; i < n_slots; i++) {
         if ((rc = begin_cloud(ctx, ctx->slots[i], pts_dev[i], n[i], stride_bytes, false))) return rc;
         max_n = std::max(max_n, n[i]);

@@ -141,11 +141,15 @@ __device__ __forceinline__ void project(const Calib& c, V3 p, double& u, double&
 constexpr int kProjThreads = 256;
 constexpr int kProjPerThread = 4;
 
+// tag_all != 0: every slot of the batch carries this map tag (the per-slot tag of the descriptor array is then not
+// kept up to date, which lets steady-state batches run without re-uploading the descriptors).
 __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc* __restrict__ slots, SlotDesc single,
-                                                                  int use_single, Calib c, int n_slots, int per_slot) {
+                                                                  int use_single, Calib c, int n_slots, int per_slot,
+                                                                  uint32_t tag_all) {
     int slot, j;
     decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
-    const SlotDesc s = use_single ? single : slots[slot];
+    SlotDesc s = use_single ? single : slots[slot];
+    if (tag_all) s.tag = tag_all;
     const long long base = (long long)j * (kProjThreads * kProjPerThread) + threadIdx.x;
     double px[kProjPerThread], py[kProjPerThread], pz[kProjPerThread];
 #pragma unroll
@@ -1420,11 +1424,13 @@ __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, u
 // SPLIT_ROAD: road-fallback candidates are queued for k_feature_road (the road code is not part of this kernel).
 template <bool SPLIT_ROAD>
 __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restrict__ slots, SlotDesc single,
-                                                         int use_single, Calib c, int n_slots, int per_slot) {
+                                                         int use_single, Calib c, int n_slots, int per_slot,
+                                                         uint32_t tag_all) {
     extern __shared__ __align__(16) unsigned char smem[];
     int slot, j;
     decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
-    const SlotDesc s = use_single ? single : slots[slot];
+    SlotDesc s = use_single ? single : slots[slot];
+    if (tag_all) s.tag = tag_all;
     const long long f0 = (long long)j * kWave;
     long long Fn = s.F;
     if (s.F_dev) {
@@ -1696,11 +1702,12 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
 
 // Road fallback for the features queued by k_feature_depth (thread path, splitRoad): one lane per queued feature.
 __global__ __launch_bounds__(kWave) void k_feature_road(const SlotDesc* __restrict__ slots, SlotDesc single, int use_single,
-                                                        Calib c, int n_slots, int per_slot) {
+                                                        Calib c, int n_slots, int per_slot, uint32_t tag_all) {
     extern __shared__ __align__(16) unsigned char smem[];
     int slot, j;
     decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
-    const SlotDesc s = use_single ? single : slots[slot];
+    SlotDesc s = use_single ? single : slots[slot];
+    if (tag_all) s.tag = tag_all;
     if (!s.road_count) return;
     const int count = *GPTR(int32_t, s.road_count);
     const int e0 = j * kWave;
@@ -1732,11 +1739,12 @@ __global__ __launch_bounds__(kWave) void k_feature_road(const SlotDesc* __restri
 // Queue entries: (feature, -1) = main path + road fallback, (feature, t >= 0) = road fallback only, t being the
 // main path's result.
 __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restrict__ slots, SlotDesc single, int use_single,
-                                                        Calib c, int n_slots, int per_slot) {
+                                                        Calib c, int n_slots, int per_slot, uint32_t tag_all) {
     extern __shared__ __align__(16) unsigned char smem[];
     int slot, j;
     decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
-    const SlotDesc s = use_single ? single : slots[slot];
+    SlotDesc s = use_single ? single : slots[slot];
+    if (tag_all) s.tag = tag_all;
     if (!s.ovf_count) return;
     const int count = *GPTR(int32_t, s.ovf_count);
     const int lane = threadIdx.x;
