@@ -31,9 +31,9 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames-per-step", type=int, default=256, help="frame slots processed per step")
+    ap.add_argument("--frames-per-step", type=int, default=1024, help="resident frames processed per step")
     ap.add_argument("--slots", type=int, default=0,
                     help="frame slots of the context (0 = frames-per-step); a step runs frames-per-step/slots launch sets")
     ap.add_argument("--contexts", type=int, default=1,

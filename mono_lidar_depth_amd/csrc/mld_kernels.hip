@@ -119,6 +119,20 @@ __device__ __forceinline__ void load_point(const SlotDesc& s, long long i, doubl
         z = (double)GPTR(float, p)[2];
     }
 }
+// Streaming (non-temporal) variant for the one pass that reads every point exactly once.
+__device__ __forceinline__ void load_point_stream(const SlotDesc& s, long long i, double& x, double& y, double& z) {
+    const unsigned char* p = s.cloud + (size_t)i * (size_t)s.stride;
+    if ((((size_t)s.cloud) & 15) == 0) {
+        f32x4 q = __builtin_nontemporal_load(GPTR(f32x4, p));
+        x = (double)q.x;
+        y = (double)q.y;
+        z = (double)q.z;
+    } else {
+        x = (double)GPTR(float, p)[0];
+        y = (double)GPTR(float, p)[1];
+        z = (double)GPTR(float, p)[2];
+    }
+}
 __device__ __forceinline__ V3 lidar_to_cam(const Calib& c, double x, double y, double z) {
     V3 r;
     r.x = c.T[3] + ((c.T[0] * x + c.T[1] * y) + c.T[2] * z);
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
         px[r] = 0;
         py[r] = 0;
         pz[r] = 0;
-        if (i < s.n) load_point(s, i, px[r], py[r], pz[r]);
+        if (i < s.n) load_point_stream(s, i, px[r], py[r], pz[r]);
     }
     const double Wd = (double)c.W, Hd = (double)c.H;
     int bmw[kProjPerThread];       // occupancy-bitmap word of the point (or a unique negative value)
