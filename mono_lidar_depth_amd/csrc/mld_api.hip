@@ -236,6 +236,8 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     c.threadPath = (force && force[0] == '1') ? 0 : 1;
     // the thread path hands road-fallback candidates to a second kernel (dense lanes); MLD_NO_SPLIT_ROAD=1 keeps
     // them inline
+    const char* noxcd = std::getenv("MLD_NO_XCD");
+    c.xcdAware = (noxcd && noxcd[0] == '1') ? 0 : 1;
     const char* nosplit = std::getenv("MLD_NO_SPLIT_ROAD");
     c.splitRoad = (c.threadPath && c.useRoad && !(nosplit && nosplit[0] == '1')) ? 1 : 0;
     // list capacity of the thread path: 32 entries (8 KB of LDS per wave) keeps 16+ waves per CU resident;

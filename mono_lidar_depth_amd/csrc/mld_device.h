@@ -40,6 +40,7 @@ struct Calib {
     int bmStride;    // words per row of the occupancy bitmap: ceil(W/32) + 2 (8-byte reads never overrun a row)
     int k1max;       // thread path: neighbour list capacity per feature (entries in LDS)
     int splitRoad;   // 1: the thread path queues road-fallback candidates for k_feature_road instead of running them inline
+    int xcdAware;    // 1: blocks of one slot are congruent mod 8 (same XCD under round-robin dispatch)
     int threadPath;  // 1: thread-per-feature fast path with wave-cooperative overflow; 0: wave path only
 };
 

@@ -71,6 +71,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // blockIdx -> (slot, block-within-slot).  With a multiple of 8 slots, all blocks of one slot are congruent
 // mod 8, i.e. land on the same XCD under round-robin dispatch: the slot's map and cloud stay in one L2.
 // This is a speed-only mapping; nothing depends on placement.
+// (a negative n_slots selects the plain slot-major mapping: MLD_NO_XCD=1, for A/B measurements)
 __device__ __forceinline__ void decode_block(int b, int n_slots, int per_slot, int& slot, int& j) {
     if (n_slots >= 8 && (n_slots & 7) == 0) {
         int x = b & 7, q = b >> 3;
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
                                                                   int use_single, Calib c, int n_slots, int per_slot,
                                                                   uint32_t tag_all) {
     int slot, j;
-    decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
+    decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
     SlotDesc s = use_single ? single : slots[slot];
     if (tag_all) s.tag = tag_all;
     const long long base = (long long)j * (kProjThreads * kProjPerThread) + threadIdx.x;
@@ -1442,7 +1443,7 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
                                                          uint32_t tag_all) {
     extern __shared__ __align__(16) unsigned char smem[];
     int slot, j;
-    decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
+    decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
     SlotDesc s = use_single ? single : slots[slot];
     if (tag_all) s.tag = tag_all;
     const long long f0 = (long long)j * kWave;
@@ -1719,7 +1720,7 @@ __global__ __launch_bounds__(kWave) void k_feature_road(const SlotDesc* __restri
                                                         Calib c, int n_slots, int per_slot, uint32_t tag_all) {
     extern __shared__ __align__(16) unsigned char smem[];
     int slot, j;
-    decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
+    decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
     SlotDesc s = use_single ? single : slots[slot];
     if (tag_all) s.tag = tag_all;
     if (!s.road_count) return;
@@ -1756,7 +1757,7 @@ __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restri
                                                         Calib c, int n_slots, int per_slot, uint32_t tag_all) {
     extern __shared__ __align__(16) unsigned char smem[];
     int slot, j;
-    decode_block((int)blockIdx.x, n_slots, per_slot, slot, j);
+    decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
     SlotDesc s = use_single ? single : slots[slot];
     if (tag_all) s.tag = tag_all;
     if (!s.ovf_count) return;
