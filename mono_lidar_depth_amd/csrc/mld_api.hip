@@ -391,6 +391,7 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     }
     if (split) {
         ScopedTimer tm(ctx, 2);
+        auto k_feature_road = ctx->calib.roadMode ? mld::k_feature_road<1> : mld::k_feature_road<0>;
         if (single) {
             hipLaunchKernelGGL(k_feature_road, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
                                ctx->slots[slot].d, 1, ctx->calib, 1, per_slot, 0u);
@@ -581,7 +582,10 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_depth<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_road),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_road<0>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_road<1>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_wave),

@@ -1028,53 +1028,6 @@ __device__ __forceinline__ V3 raw_point(const Calib& c, RawP r) { return lidar_t
 // list entry e of this lane, or 0 (a valid point index whenever any list is non-empty) beyond the list end
 #define LST_ID(e, n) (((e) < (n)) ? (LST(min((e), c.k1max - 1)) & kIdxMask) : 0u)
 
-// Scans `nymax` window rows in groups of RG rows; a row is covered by NCH chunks of 8 cells (two 16-byte loads
-// each; NCH == 0: any width, chunk loop not unrolled).  The map allocation is padded so that reading past the
-// window's last cell stays inside the buffer.  Appends hits in row-major order.
-template <int RG, int NCH>
-__device__ __forceinline__ void scan_rows(const Calib& c, const SlotDesc& s,
-                                          const uint32_t __attribute__((address_space(1)))* base, int nx, int ny,
-                                          int nymax, int nxmax, uint32_t* lst, int lane, int& k) {
-    constexpr int NC = NCH > 0 ? NCH : 1;
-    const int nchunks = NCH > 0 ? NCH : (nxmax + 7) / 8;
-    for (int r0 = 0; r0 < nymax; r0 += RG) {
-        for (int cc = 0; cc < nchunks; cc += NC) {  // one iteration when NCH > 0
-            uint32_t key[RG][NC][8];
-#pragma unroll
-            for (int q = 0; q < RG; q++) {
-                const bool rowok = (r0 + q) < ny;
-                const auto* rowp = base + (size_t)(rowok ? (r0 + q) : 0) * (size_t)c.W;
-#pragma unroll
-                for (int h = 0; h < NC; h++) {
-                    const int c0 = (cc + h) * 8;
-                    u32x4_a4 ka = {0, 0, 0, 0}, kb = {0, 0, 0, 0};
-                    if (rowok && c0 < nx) ka = *GPTR(u32x4_a4, rowp + c0);
-                    if (rowok && c0 + 4 < nx) kb = *GPTR(u32x4_a4, rowp + c0 + 4);
-                    key[q][h][0] = ka.x; key[q][h][1] = ka.y; key[q][h][2] = ka.z; key[q][h][3] = ka.w;
-                    key[q][h][4] = kb.x; key[q][h][5] = kb.y; key[q][h][6] = kb.z; key[q][h][7] = kb.w;
-                }
-            }
-            // all chunks of the group's rows are in registers: consume row by row (row-major order)
-#pragma unroll
-            for (int q = 0; q < RG; q++) {
-#pragma unroll
-                for (int h = 0; h < NC; h++) {
-                    const int c0 = (cc + h) * 8;
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        // cells beyond nx / rows beyond ny were not loaded (key 0 never matches a tag >= 1)
-                        const bool has = (c0 + i < nx) && ((key[q][h][i] >> kIdxBits) == s.tag);
-                        if (has) {
-                            if (k < c.k1max) LST(k) = kIdxMask - (key[q][h][i] & kIdxMask);
-                            k++;
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
 // Window scan through the occupancy bitmap: the key map has one occupied cell in ~30, so reading it row by row
 // drags almost every 128-byte line of the 1.86 MB map through HBM.  The bitmap (58 KB per frame, cache resident)
 // tells which cells to fetch.  Pass 1 appends the CELL indices of the set bits (row-major order) to the lane's
@@ -1152,13 +1105,12 @@ __device__ __forceinline__ int scan_window_thread(const Calib& c, const SlotDesc
     int k = 0;
     // Rows are independent: the loads of a group of rows are issued before any of them is consumed, so that
     // the map latency is paid once per group instead of once per row.
-    if (nxmax <= 32 && s.bitmap) return scan_window_bitmap(c, s, x0, y0, nx, ny, lst, lane);
-    if (nxmax <= 8)
-        scan_rows<4, 1>(c, s, base, nx, ny, nymax, nxmax, lst, lane, k);
-    else if (nxmax <= 16)
-        scan_rows<2, 2>(c, s, base, nx, ny, nymax, nxmax, lst, lane, k);
-    else
-        scan_rows<1, 0>(c, s, base, nx, ny, nymax, nxmax, lst, lane, k);
+    if (nxmax <= 32) return scan_window_bitmap(c, s, x0, y0, nx, ny, lst, lane);
+    // windows wider than 32 cells (non-default parameters): every lane with a window reports an overflowing list,
+    // which sends its feature to the wave-cooperative kernel
+    (void)base;
+    (void)nymax;
+    k = (nx > 0) ? c.k1max + 1 : 0;
     return k;
 }
 
@@ -1301,9 +1253,12 @@ __device__ __forceinline__ void enqueue_features(int32_t* queue, int32_t* count,
 
 // Road fallback of the thread path (DepthEstimator.cpp:578-597) for the lanes with `cand` set; mytype holds the main
 // path's result (resultOld) on entry.  Lanes whose wide-window list exceeds the capacities set `overflow`.
+// ROAD_MODE: 0 = M-estimator, 1 = max-spanning triangle, -1 = decided at run time (c.roadMode).
+template <int ROAD_MODE>
 __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, bool cand,
                                             const double myu, const double myv, int& mytype, double& mydepth,
                                             bool& overflow) {
+    const int roadMode = ROAD_MODE >= 0 ? ROAD_MODE : c.roadMode;
     const int resultOld = mytype;
     int k2 = scan_window_thread(c, s, myu, myv, c.halfX2, c.halfY2, cand, lst, lane);
     if (cand && k2 > c.k1max) {
@@ -1322,7 +1277,10 @@ __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, u
     int kk = 0;
     double zmn = 1.7976931348623157e308, zmx = -1.7976931348623157e308;
     double xmn = zmn, xmx = zmx;
-    double sw = 0, sx = 0, sy = 0, sz = 0;
+    // weighted mean / scatter of the inliers, updated point by point in list order (West's one-pass update: no second
+    // sweep over the list, no cancellation)
+    double sw = 0, mx = 0, my = 0, mz = 0;
+    double q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
     const V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
     for (int e0 = 0; e0 < n2max; e0 += 4) {
         RawP rp[4];
@@ -1352,11 +1310,23 @@ __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, u
                 if (p.z > zmx) zmx = p.z;
                 if (p.x < xmn) xmn = p.x;
                 if (p.x > xmx) xmx = p.x;
-                double w = 1 / fabs(vdot(pn, p) + s.prior_off);  // PlaneEstimationMEstimator.cpp:32
-                sx += w * p.x;
-                sy += w * p.y;
-                sz += w * p.z;
-                sw += w;
+                if (roadMode == 0) {
+                    const double w = 1 / fabs(vdot(pn, p) + s.prior_off);  // PlaneEstimationMEstimator.cpp:32
+                    const double swn = sw + w;
+                    const double r = w / swn;
+                    const double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
+                    mx += dx * r;
+                    my += dy * r;
+                    mz += dz * r;
+                    const double ex = p.x - mx, ey = p.y - my, ez = p.z - mz;
+                    q0 += w * dx * ex;
+                    q1 += w * dx * ey;
+                    q2 += w * dx * ez;
+                    q3 += w * dy * ey;
+                    q4 += w * dy * ez;
+                    q5 += w * dz * ez;
+                    sw = swn;
+                }
             }
           }
         }
@@ -1371,32 +1341,9 @@ __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, u
     for (int t = 0; t < kRecFields; t++) rr[t] = 0.0;
     rr[9] = zmn;
     rr[10] = zmx;
-    if (c.roadMode == 0) {
-        const double cx = sx / sw, cy = sy / sw, cz = sz / sw;
-        const int n3 = cand ? kk : 0;
-        const int n3max = uniform(wave_max_i32(n3));
-        double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
-        for (int e0 = 0; e0 < n3max; e0 += 4) {
-            RawP rp[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) rp[q] = load_raw(s, LST_ID(e0 + q, n3));
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              if (e0 + q < n3) {
-                V3 p = raw_point(c, rp[q]);
-                double w = 1 / fabs(vdot(pn, p) + s.prior_off);
-                double dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
-                c0 += w * dx * dx;
-                c1 += w * dx * dy;
-                c2 += w * dx * dz;
-                c3 += w * dy * dy;
-                c4 += w * dy * dz;
-                c5 += w * dz * dz;
-              }
-            }
-        }
-        rr[0] = cx; rr[1] = cy; rr[2] = cz;
-        rr[3] = c0; rr[4] = c1; rr[5] = c2; rr[6] = c3; rr[7] = c4; rr[8] = c5;
+    if (roadMode == 0) {
+        rr[0] = mx; rr[1] = my; rr[2] = mz;
+        rr[3] = q0; rr[4] = q1; rr[5] = q2; rr[6] = q3; rr[7] = q4; rr[8] = q5;
         if (cand) finish_road(c, false, myu, myv, rr, mytype, mydepth);
     } else {
         // RoadDepthEstimatorMaxSpanningTriangle::CalculateDepth (:24-75)
@@ -1695,7 +1642,7 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
             } else {
                 const int resultOld = mytype;
                 bool ovf2 = false;
-                road_thread(c, s, lst, lane, cand, myu, myv, mytype, mydepth, ovf2);
+                road_thread<-1>(c, s, lst, lane, cand, myu, myv, mytype, mydepth, ovf2);
                 if (ovf2) {  // long wide-window list: only the road part is redone by the wave kernel
                     overflow = true;
                     ovf_code = resultOld;
@@ -1716,6 +1663,7 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
 }
 
 // Road fallback for the features queued by k_feature_depth (thread path, splitRoad): one lane per queued feature.
+template <int ROAD_MODE>
 __global__ __launch_bounds__(kWave) void k_feature_road(const SlotDesc* __restrict__ slots, SlotDesc single, int use_single,
                                                         Calib c, int n_slots, int per_slot, uint32_t tag_all) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1742,7 +1690,7 @@ __global__ __launch_bounds__(kWave) void k_feature_road(const SlotDesc* __restri
     }
     bool overflow = false;
     const int resultOld = mytype;
-    road_thread(c, s, lst, lane, active, myu, myv, mytype, mydepth, overflow);
+    road_thread<ROAD_MODE>(c, s, lst, lane, active, myu, myv, mytype, mydepth, overflow);
     enqueue_features(s.ovf_queue, s.ovf_count, overflow && active, lane, f, resultOld);
     if (active) {
         GPTRW(double, s.depth)[f] = mydepth;
