@@ -9,14 +9,18 @@ from helpers import assert_depth_parity, kitti_camera, make_estimator, make_orac
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["thread+wave", "wave-only"])
+@pytest.fixture(autouse=True, params=["split", "inline-road", "wave-only"])
 def feature_kernel_path(request, monkeypatch):
-    """Every test runs twice: with the thread-per-feature fast path (long lists overflow to the wave-cooperative
-    path) and with the wave-cooperative path forced for all features (MLD_FORCE_WAVE_PATH is read by mld_create)."""
+    """Every test runs three ways (the switches are read by mld_create):
+    split       thread-per-feature kernel + road-fallback kernel + long-list wave kernel (the default)
+    inline-road thread kernel with the road fallback inline (MLD_NO_SPLIT_ROAD=1)
+    wave-only   every feature through the wave-cooperative kernel (MLD_FORCE_WAVE_PATH=1)"""
+    monkeypatch.delenv("MLD_FORCE_WAVE_PATH", raising=False)
+    monkeypatch.delenv("MLD_NO_SPLIT_ROAD", raising=False)
     if request.param == "wave-only":
         monkeypatch.setenv("MLD_FORCE_WAVE_PATH", "1")
-    else:
-        monkeypatch.delenv("MLD_FORCE_WAVE_PATH", raising=False)
+    elif request.param == "inline-road":
+        monkeypatch.setenv("MLD_NO_SPLIT_ROAD", "1")
     yield request.param
 
 
