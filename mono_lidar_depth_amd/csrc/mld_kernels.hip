@@ -983,7 +983,8 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
 constexpr int kK1MaxLimit = 64;  // upper bound of Calib::k1max, the per-feature neighbour list capacity
                                  // (LDS: k1max entries x 64 lanes x 4 B per wave; relative bins need k1max < 254)
 constexpr int kK2Max = 16;  // longest list the per-thread O(n^2) triangle search accepts
-constexpr int kTriSmall = 8;  // lists up to this length use the fully unrolled in-register triangle search
+constexpr int kTriSmall = 8;
+constexpr int kBatch = 4;    // list entries fetched ahead of use in the per-lane list loops  // lists up to this length use the fully unrolled in-register triangle search
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -1064,12 +1065,12 @@ __device__ __forceinline__ int scan_window_bitmap(const Calib& c, const SlotDesc
     const int kk = k <= c.k1max ? k : 0;  // overflowing lists (k > k1max) are redone by the wave path
     const int kmax = uniform(wave_max_i32(kk));
     const auto* mp = GPTR(uint32_t, s.map);
-    for (int e0 = 0; e0 < kmax; e0 += 4) {
-        uint32_t key[4];
+    for (int e0 = 0; e0 < kmax; e0 += kBatch) {
+        uint32_t key[kBatch];
 #pragma unroll
-        for (int q = 0; q < 4; q++) key[q] = (e0 + q < kk) ? mp[LST(min(e0 + q, c.k1max - 1))] : 0u;
+        for (int q = 0; q < kBatch; q++) key[q] = (e0 + q < kk) ? mp[LST(min(e0 + q, c.k1max - 1))] : 0u;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
+        for (int q = 0; q < kBatch; q++)
             if (e0 + q < kk) LST(e0 + q) = kIdxMask - (key[q] & kIdxMask);
     }
     return k;
@@ -1282,17 +1283,17 @@ __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, u
     double sw = 0, mx = 0, my = 0, mz = 0;
     double q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
     const V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
-    for (int e0 = 0; e0 < n2max; e0 += 4) {
-        RawP rp[4];
-        uint32_t ids[4], mw[4];
+    for (int e0 = 0; e0 < n2max; e0 += kBatch) {
+        RawP rp[kBatch];
+        uint32_t ids[kBatch], mw[kBatch];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < kBatch; q++) {
             ids[q] = LST_ID(e0 + q, n2);
             rp[q] = load_raw(s, ids[q]);
             mw[q] = GPTR(uint32_t, s.inlier_mask)[ids[q] >> 5];
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < kBatch; q++) {
           if (e0 + q < n2) {
             const uint32_t id = ids[q];
             V3 p = raw_point(c, rp[q]);
@@ -1432,12 +1433,12 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
             const int kmax = uniform(wave_max_i32(ks));
             int md = 0;
             double dmin = 1.7976931348623157e308;
-            for (int e0 = 0; e0 < kmax; e0 += 4) {
-                RawP rp[4];
+            for (int e0 = 0; e0 < kmax; e0 += kBatch) {
+                RawP rp[kBatch];
 #pragma unroll
-                for (int q = 0; q < 4; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ks));
+                for (int q = 0; q < kBatch; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ks));
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < kBatch; q++) {
                     double d = raw_z(c, rp[q]);
                     d = (999. < d) ? 999. : d;
                     int ce = (int)ceil(d);
@@ -1455,16 +1456,16 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
                 double q = fabs(value / c.binW);
                 bmin = (int)((lim < q) ? lim : q);  // bin index is monotone in d: the smallest d gives the first bin
             }
-            for (int e0 = 0; e0 < kmax; e0 += 4) {
-                RawP rp[4];
-                uint32_t ids[4];
+            for (int e0 = 0; e0 < kmax; e0 += kBatch) {
+                RawP rp[kBatch];
+                uint32_t ids[kBatch];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < kBatch; q++) {
                     ids[q] = LST_ID(e0 + q, ks);
                     rp[q] = load_raw(s, ids[q]);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < kBatch; q++) {
                     double d = raw_z(c, rp[q]);
                     d = (999. < d) ? 999. : d;
                     double value = (1e10 < d) ? 1e10 : d;
@@ -1506,16 +1507,16 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
             const double lower = (double)(bmin + binMaxRel) * c.binW - 0.0 * c.binW;
             const double higher = (double)(bmin + binMaxRel) * c.binW + 1.0 * c.binW;
             int kk = 0;
-            for (int e0 = 0; e0 < kmax; e0 += 4) {
-                RawP rp[4];
-                uint32_t packed[4];
+            for (int e0 = 0; e0 < kmax; e0 += kBatch) {
+                RawP rp[kBatch];
+                uint32_t packed[kBatch];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < kBatch; q++) {
                     packed[q] = (e0 + q < ks) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
                     rp[q] = load_raw(s, packed[q] & kIdxMask);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < kBatch; q++) {
                     const int rel = (int)(packed[q] >> kIdxBits);
                     const uint32_t id = packed[q] & kIdxMask;
                     const double z = raw_z(c, rp[q]);
@@ -1538,12 +1539,12 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
             ks = live ? kk : 0;
         } else {
             const int kmax = uniform(wave_max_i32(ks));
-            for (int e0 = 0; e0 < kmax; e0 += 4) {
-                RawP rp[4];
+            for (int e0 = 0; e0 < kmax; e0 += kBatch) {
+                RawP rp[kBatch];
 #pragma unroll
-                for (int q = 0; q < 4; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ks));
+                for (int q = 0; q < kBatch; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ks));
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < kBatch; q++) {
                     const double z = raw_z(c, rp[q]);
                     if (e0 + q < ks) {
                         if (z < minZ) minZ = z;
