@@ -193,6 +193,10 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     c.f = ctx->cam.focal_length;
     c.cu = ctx->cam.principal_point_x;
     c.cv = ctx->cam.principal_point_y;
+    for (int t = 0; t < 12; t++) c.Tf[t] = (float)T[t];
+    c.ff = (float)c.f;
+    c.cuf = (float)c.cu;
+    c.cvf = (float)c.cv;
     c.W = ctx->cam.width;
     c.H = ctx->cam.height;
     c.bmStride = (ctx->cam.width + 31) / 32 + 2;

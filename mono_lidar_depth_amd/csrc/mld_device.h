@@ -18,6 +18,9 @@ struct Calib {
     double Tinv[12];  // camera -> lidar
     double Kinv[9];   // inverse intrinsics, row-major
     double f, cu, cv;
+    float Tf[12];           // single-precision copies for the conservative pre-cull of k_project_scatter
+    float ff, cuf, cvf;
+    float padf_;
     double halfX1, halfY1;  // main search window half sizes  (scale 1.0, 1.0)
     double halfX2, halfY2;  // road search window half sizes  (scale 2.0, 1.5)
     double binW;
