@@ -1519,7 +1519,16 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
                     } else {
                         int last = binValue;
                         int cnt = 0;
-                        for (int e = 0; e < ks; e++) cnt += ((LST(e) >> kIdxBits) == (uint32_t)irel) ? 1 : 0;
+                        // four independent LDS reads per step (wave-uniform bound) instead of one dependent read
+                        // per entry
+                        for (int e = 0; e < kmax; e += 4) {
+                            uint32_t vv[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) vv[q] = LST(min(e + q, c.k1max - 1));
+#pragma unroll
+                            for (int q = 0; q < 4; q++)
+                                cnt += ((e + q < ks) && ((vv[q] >> kIdxBits) == (uint32_t)irel)) ? 1 : 0;
+                        }
                         binValue = cnt;
                         if ((binValue > binMaxVal) && (binValue >= c.minCount)) {
                             binMaxVal = binValue;
