@@ -121,10 +121,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; RCCL ("nccl" on ROCm) carries the calibration broadcast and the two scalar reductions.
+    # MLD_BENCH_BACKEND=gloo is a functional-test hook: it lets several ranks share one GPU box (collectives on CPU
+    # tensors) so that the N>1 code path can be exercised where only one GPU is visible.
+    backend = os.environ.get("MLD_BENCH_BACKEND", "nccl")
+    gpu_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
+    coll_dev = dev if backend == "nccl" else None
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+    local_rank = gpu_index
 
     from mono_lidar_depth_amd import CameraPinhole, DepthEstimator, capi, sharding, synth, traffic
 
@@ -135,7 +145,7 @@ def main():
         T = synth.T_CAM_LIDAR
     else:
         P = cam_struct = T = None
-    P, cam_struct, T = sharding.broadcast_calibration(P, cam_struct, T, device=dev)
+    P, cam_struct, T = sharding.broadcast_calibration(P, cam_struct, T, device=coll_dev)
     cam = CameraPinhole(cam_struct.width, cam_struct.height, cam_struct.focal_length, cam_struct.principal_point_x,
                         cam_struct.principal_point_y)
 
@@ -209,8 +219,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    elapsed = sharding.max_over_ranks(elapsed, device=dev)
-    units = sharding.sum_over_ranks(float(B * F * args.steps), device=dev)
+    elapsed = sharding.max_over_ranks(elapsed, device=coll_dev)
+    units = sharding.sum_over_ranks(float(B * F * args.steps), device=coll_dev)
 
     k_proj_ms, n_proj = est.kernelTimeMs(0) if timing else (0.0, 0)
     k_feat_ms, n_feat = est.kernelTimeMs(1) if timing else (0.0, 0)
@@ -282,7 +292,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "ms_per_frame": 1e3 * elapsed / args.steps / B,
+        "ms_per_frame": 1e3 * elapsed / args.steps / (B * world),  # whole job: all ranks' frames
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
