@@ -76,6 +76,7 @@ struct mld_ctx {
     size_t bitmap_words = 0;      // per slot
     std::vector<SlotDesc> h_descs;
     size_t lds_bytes = 0;
+    size_t lds_main = 0;  // k_feature_main: four per-wave index lists + the dealing table
     std::string err;
     // ground-plane estimation scratch (device)
     int32_t* rs_flags = nullptr;
@@ -250,6 +251,7 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     if (const char* k = std::getenv("MLD_K1MAX")) k1max = std::atoi(k);
     c.k1max = std::min(std::max(k1max, 8), kK1MaxLimit);
     if (c.threadPath) ctx->lds_bytes = std::max(ctx->lds_bytes, (size_t)c.k1max * kWave * sizeof(uint32_t));
+    ctx->lds_main = (size_t)(kMainThreads / kWave) * c.k1max * kWave * sizeof(uint32_t) + kMainThreads * sizeof(uint32_t) + 64;
 }
 
 int check_slot(mld_ctx* ctx, int slot) {
@@ -384,13 +386,22 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     ctx->counters_clean = false;
     {
         ScopedTimer tm(ctx, 1);
-        auto kern = split ? k_feature_depth<true> : k_feature_depth<false>;
-        if (single) {
-            hipLaunchKernelGGL(kern, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
-                               ctx->slots[slot].d, 1, ctx->calib, 1, per_slot, 0u);
+        if (split) {
+            // 256 features per block; the block re-deals its live features to dense wavefronts
+            const int pm = (int)((max_F + kMainThreads - 1) / kMainThreads);
+            if (single) {
+                hipLaunchKernelGGL(k_feature_main, dim3(pm), dim3(kMainThreads), ctx->lds_main, ctx->stream, ctx->d_slots,
+                                   ctx->slots[slot].d, 1, ctx->calib, 1, pm, 0u);
+            } else {
+                hipLaunchKernelGGL(k_feature_main, dim3((unsigned)pm * n_slots), dim3(kMainThreads), ctx->lds_main,
+                                   ctx->stream, ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, pm, tag_all);
+            }
+        } else if (single) {
+            hipLaunchKernelGGL(k_feature_depth<false>, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream,
+                               ctx->d_slots, ctx->slots[slot].d, 1, ctx->calib, 1, per_slot, 0u);
         } else {
-            hipLaunchKernelGGL(kern, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes, ctx->stream,
-                               ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot, tag_all);
+            hipLaunchKernelGGL(k_feature_depth<false>, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
+                               ctx->stream, ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot, tag_all);
         }
     }
     if (split) {
@@ -579,11 +590,13 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     }
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
         return hip_bail(e, "hipStreamCreate");
+    if (ctx->lds_main > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_main), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)ctx->lds_main);
+        if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute");
+    }
     if (ctx->lds_bytes > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_depth<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_depth<false>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_depth<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_road<0>),

@@ -1417,6 +1417,227 @@ __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, u
     }
 }
 
+// Everything between the window scan and the road fallback for one feature per lane (DepthEstimator.cpp:564-576):
+// histogram segmentation, corner selection, tail.  `lst` / `lane` address the lane's index list (they need not be
+// the executing wave's own region: k_feature_main re-deals the live features of a block to dense wavefronts).
+__device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane,
+                                                const int k, bool live, const double myu, const double myv,
+                                                int& mytype, double& mydepth, bool& overflow) {
+    int ks = live ? k : 0;
+    double minZ = 1.7976931348623157e308, maxZ = -1.7976931348623157e308;
+    if (c.useHist) {
+        // PointHistogram::FilterPointsMinDistBlob (HistogramPointDepth.cpp:15-123), per thread
+        const int kmax = uniform(wave_max_i32(ks));
+        int md = 0;
+        double dmin = 1.7976931348623157e308;
+        for (int e0 = 0; e0 < kmax; e0 += kBatch) {
+            RawP rp[kBatch];
+#pragma unroll
+            for (int q = 0; q < kBatch; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ks));
+#pragma unroll
+            for (int q = 0; q < kBatch; q++) {
+                double d = raw_z(c, rp[q]);
+                d = (999. < d) ? 999. : d;
+                int ce = (int)ceil(d);
+                const bool ok = e0 + q < ks;
+                md = ok ? max(md, ce) : md;
+                dmin = (ok && d < dmin) ? d : dmin;
+            }
+        }
+        const int binCount = (int)((double)md / c.binW + 1.0);
+        bool hfail = binCount <= 1;
+        const double lim = (double)binCount - 1.;
+        int bmin = 0;
+        {
+            double value = (1e10 < dmin) ? 1e10 : dmin;
+            double q = fabs(value / c.binW);
+            bmin = (int)((lim < q) ? lim : q);  // bin index is monotone in d: the smallest d gives the first bin
+        }
+        for (int e0 = 0; e0 < kmax; e0 += kBatch) {
+            RawP rp[kBatch];
+            uint32_t ids[kBatch];
+#pragma unroll
+            for (int q = 0; q < kBatch; q++) {
+                ids[q] = LST_ID(e0 + q, ks);
+                rp[q] = load_raw(s, ids[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < kBatch; q++) {
+                double d = raw_z(c, rp[q]);
+                d = (999. < d) ? 999. : d;
+                double value = (1e10 < d) ? 1e10 : d;
+                double qq = fabs(value / c.binW);
+                int bi = (int)((lim < qq) ? lim : qq);
+                int rel = bi - bmin;
+                rel = rel > 255 ? 255 : rel;
+                if (e0 + q < ks) LST(e0 + q) = ids[q] | ((uint32_t)rel << kIdxBits);
+            }
+        }
+        // scan of the bins (HistogramPointDepth.cpp:70-85) from the first non-empty one
+        int binMaxRel = -1, binMaxVal = -1, binValue = 0, irel = 0;
+        bool run = live && !hfail && ks > 0;
+        while (__any(run)) {
+            if (run) {
+                if (bmin + irel >= binCount) {
+                    run = false;
+                } else {
+                    int last = binValue;
+                    int cnt = 0;
+                    // four independent LDS reads per step (wave-uniform bound) instead of one dependent read
+                    // per entry
+                    for (int e = 0; e < kmax; e += 4) {
+                        uint32_t vv[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) vv[q] = LST(min(e + q, c.k1max - 1));
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            cnt += ((e + q < ks) && ((vv[q] >> kIdxBits) == (uint32_t)irel)) ? 1 : 0;
+                    }
+                    binValue = cnt;
+                    if ((binValue > binMaxVal) && (binValue >= c.minCount)) {
+                        binMaxVal = binValue;
+                        binMaxRel = irel;
+                    } else if (binValue < binMaxVal) {
+                        run = false;
+                    }
+                    if (run && (last > 0) && (binValue == 0)) {
+                        hfail = true;
+                        run = false;
+                    }
+                    irel++;
+                    if (irel >= 255) run = false;  // cannot happen: at most ks+1 <= 65 bins are visited
+                }
+            }
+        }
+        if (binMaxRel < 0) hfail = true;
+        const double lower = (double)(bmin + binMaxRel) * c.binW - 0.0 * c.binW;
+        const double higher = (double)(bmin + binMaxRel) * c.binW + 1.0 * c.binW;
+        int kk = 0;
+        for (int e0 = 0; e0 < kmax; e0 += kBatch) {
+            RawP rp[kBatch];
+            uint32_t packed[kBatch];
+#pragma unroll
+            for (int q = 0; q < kBatch; q++) {
+                packed[q] = (e0 + q < ks) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
+                rp[q] = load_raw(s, packed[q] & kIdxMask);
+            }
+#pragma unroll
+            for (int q = 0; q < kBatch; q++) {
+                const int rel = (int)(packed[q] >> kIdxBits);
+                const uint32_t id = packed[q] & kIdxMask;
+                const double z = raw_z(c, rp[q]);
+                const double d = (999. < z) ? 999. : z;
+                // membership is by [lower, higher), not by bin; only the neighbouring bins can qualify
+                const bool keep = (e0 + q < ks) && !hfail && (rel >= binMaxRel - 1) && (rel <= binMaxRel + 1) &&
+                                  (d >= lower) && (d < higher);
+                if (keep) {
+                    LST(kk) = id;  // kk <= e0 + q: entries not yet read are never overwritten
+                    kk++;
+                    if (z < minZ) minZ = z;
+                    if (z > maxZ) maxZ = z;
+                }
+            }
+        }
+        if (live && hfail) {
+            mytype = MLD_HistogramNoLocalMax;
+            live = false;
+        }
+        ks = live ? kk : 0;
+    } else {
+        const int kmax = uniform(wave_max_i32(ks));
+        for (int e0 = 0; e0 < kmax; e0 += kBatch) {
+            RawP rp[kBatch];
+#pragma unroll
+            for (int q = 0; q < kBatch; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ks));
+#pragma unroll
+            for (int q = 0; q < kBatch; q++) {
+                const double z = raw_z(c, rp[q]);
+                if (e0 + q < ks) {
+                    if (z < minZ) minZ = z;
+                    if (z > maxZ) maxZ = z;
+                }
+            }
+        }
+    }
+
+    // ---- CalculateDepthSegmented (DepthEstimator.cpp:903-1037) ----
+    double r[kRecFields];
+#pragma unroll
+    for (int t = 0; t < kRecFields; t++) r[t] = 0.0;
+    bool pca = false;
+    if (!c.usePCA && c.useTriMax) {
+        if (live && ks > kK2Max) {
+            overflow = true;
+            live = false;
+        }
+        if (live && ks < 3) {
+            mytype = MLD_TriangleNotPlanarInsufficientPoints;
+            live = false;
+        }
+        V3 c1, c2, c3;
+        bool ok = triangle_small<kTriSmall>(c, s, ks, live && ks <= kTriSmall, lst, lane, c1, c2, c3);
+        if (__any(live && ks > kTriSmall)) {  // rare: longer segmented lists take the generic serial loops
+            V3 d1, d2, d3;
+            bool ok2 = triangle_thread(c, s, ks, live && ks > kTriSmall, lst, lane, d1, d2, d3);
+            if (ks > kTriSmall) {
+                ok = ok2;
+                c1 = d1;
+                c2 = d2;
+                c3 = d3;
+            }
+        }
+        if (live && !ok) {
+            mytype = MLD_TriangleNotPlanarInsufficientPoints;
+            live = false;
+        }
+        r[0] = c1.x; r[1] = c1.y; r[2] = c1.z;
+        r[3] = c2.x; r[4] = c2.y; r[5] = c2.z;
+        r[6] = c3.x; r[7] = c3.y; r[8] = c3.z;
+    } else {
+        if (live && ks < 3) {
+            mytype = MLD_HistogramNoLocalMax;  // :920-921
+            live = false;
+        }
+        if (c.usePCA) {
+            // Mono_LidarPipeline::PCA::CalculatePCA (PCA.cpp:45-62): mean, scatter, in index order
+            pca = true;
+            const int n = live ? ks : 0;
+            const int nmax = uniform(wave_max_i32(n));
+            double sx = 0, sy = 0, sz = 0;
+            for (int e = 0; e < nmax; e++)
+                if (e < n) {
+                    V3 p = cam_point(c, s, LST(e));
+                    sx += p.x;
+                    sy += p.y;
+                    sz += p.z;
+                }
+            const double mx = sx / (double)n, my = sy / (double)n, mz = sz / (double)n;
+            double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
+            for (int e = 0; e < nmax; e++)
+                if (e < n) {
+                    V3 p = cam_point(c, s, LST(e));
+                    double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
+                    c0 += dx * dx;
+                    c1 += dx * dy;
+                    c2 += dx * dz;
+                    c3 += dy * dy;
+                    c4 += dy * dz;
+                    c5 += dz * dz;
+                }
+            r[0] = mx; r[1] = my; r[2] = mz;
+            r[3] = c0; r[4] = c1; r[5] = c2; r[6] = c3; r[7] = c4; r[8] = c5;
+        } else if (live) {
+            V3 p0 = cam_point(c, s, LST(0)), p1 = cam_point(c, s, LST(1)), p2 = cam_point(c, s, LST(2));
+            r[0] = p0.x; r[1] = p0.y; r[2] = p0.z;
+            r[3] = p1.x; r[4] = p1.y; r[5] = p1.z;
+            r[6] = p2.x; r[7] = p2.y; r[8] = p2.z;
+        }
+    }
+    r[9] = minZ;
+    r[10] = maxZ;
+    if (live) finish_main(c, pca, myu, myv, r, mytype, mydepth);
+}
+
 // SPLIT_ROAD: road-fallback candidates are queued for k_feature_road (the road code is not part of this kernel).
 template <bool SPLIT_ROAD>
 __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restrict__ slots, SlotDesc single,
@@ -1459,219 +1680,7 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
             mytype = MLD_RadiusSearchInsufficientPoints;
             live = false;
         }
-        int ks = live ? k : 0;
-        double minZ = 1.7976931348623157e308, maxZ = -1.7976931348623157e308;
-        if (c.useHist) {
-            // PointHistogram::FilterPointsMinDistBlob (HistogramPointDepth.cpp:15-123), per thread
-            const int kmax = uniform(wave_max_i32(ks));
-            int md = 0;
-            double dmin = 1.7976931348623157e308;
-            for (int e0 = 0; e0 < kmax; e0 += kBatch) {
-                RawP rp[kBatch];
-#pragma unroll
-                for (int q = 0; q < kBatch; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ks));
-#pragma unroll
-                for (int q = 0; q < kBatch; q++) {
-                    double d = raw_z(c, rp[q]);
-                    d = (999. < d) ? 999. : d;
-                    int ce = (int)ceil(d);
-                    const bool ok = e0 + q < ks;
-                    md = ok ? max(md, ce) : md;
-                    dmin = (ok && d < dmin) ? d : dmin;
-                }
-            }
-            const int binCount = (int)((double)md / c.binW + 1.0);
-            bool hfail = binCount <= 1;
-            const double lim = (double)binCount - 1.;
-            int bmin = 0;
-            {
-                double value = (1e10 < dmin) ? 1e10 : dmin;
-                double q = fabs(value / c.binW);
-                bmin = (int)((lim < q) ? lim : q);  // bin index is monotone in d: the smallest d gives the first bin
-            }
-            for (int e0 = 0; e0 < kmax; e0 += kBatch) {
-                RawP rp[kBatch];
-                uint32_t ids[kBatch];
-#pragma unroll
-                for (int q = 0; q < kBatch; q++) {
-                    ids[q] = LST_ID(e0 + q, ks);
-                    rp[q] = load_raw(s, ids[q]);
-                }
-#pragma unroll
-                for (int q = 0; q < kBatch; q++) {
-                    double d = raw_z(c, rp[q]);
-                    d = (999. < d) ? 999. : d;
-                    double value = (1e10 < d) ? 1e10 : d;
-                    double qq = fabs(value / c.binW);
-                    int bi = (int)((lim < qq) ? lim : qq);
-                    int rel = bi - bmin;
-                    rel = rel > 255 ? 255 : rel;
-                    if (e0 + q < ks) LST(e0 + q) = ids[q] | ((uint32_t)rel << kIdxBits);
-                }
-            }
-            // scan of the bins (HistogramPointDepth.cpp:70-85) from the first non-empty one
-            int binMaxRel = -1, binMaxVal = -1, binValue = 0, irel = 0;
-            bool run = live && !hfail && ks > 0;
-            while (__any(run)) {
-                if (run) {
-                    if (bmin + irel >= binCount) {
-                        run = false;
-                    } else {
-                        int last = binValue;
-                        int cnt = 0;
-                        // four independent LDS reads per step (wave-uniform bound) instead of one dependent read
-                        // per entry
-                        for (int e = 0; e < kmax; e += 4) {
-                            uint32_t vv[4];
-#pragma unroll
-                            for (int q = 0; q < 4; q++) vv[q] = LST(min(e + q, c.k1max - 1));
-#pragma unroll
-                            for (int q = 0; q < 4; q++)
-                                cnt += ((e + q < ks) && ((vv[q] >> kIdxBits) == (uint32_t)irel)) ? 1 : 0;
-                        }
-                        binValue = cnt;
-                        if ((binValue > binMaxVal) && (binValue >= c.minCount)) {
-                            binMaxVal = binValue;
-                            binMaxRel = irel;
-                        } else if (binValue < binMaxVal) {
-                            run = false;
-                        }
-                        if (run && (last > 0) && (binValue == 0)) {
-                            hfail = true;
-                            run = false;
-                        }
-                        irel++;
-                        if (irel >= 255) run = false;  // cannot happen: at most ks+1 <= 65 bins are visited
-                    }
-                }
-            }
-            if (binMaxRel < 0) hfail = true;
-            const double lower = (double)(bmin + binMaxRel) * c.binW - 0.0 * c.binW;
-            const double higher = (double)(bmin + binMaxRel) * c.binW + 1.0 * c.binW;
-            int kk = 0;
-            for (int e0 = 0; e0 < kmax; e0 += kBatch) {
-                RawP rp[kBatch];
-                uint32_t packed[kBatch];
-#pragma unroll
-                for (int q = 0; q < kBatch; q++) {
-                    packed[q] = (e0 + q < ks) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
-                    rp[q] = load_raw(s, packed[q] & kIdxMask);
-                }
-#pragma unroll
-                for (int q = 0; q < kBatch; q++) {
-                    const int rel = (int)(packed[q] >> kIdxBits);
-                    const uint32_t id = packed[q] & kIdxMask;
-                    const double z = raw_z(c, rp[q]);
-                    const double d = (999. < z) ? 999. : z;
-                    // membership is by [lower, higher), not by bin; only the neighbouring bins can qualify
-                    const bool keep = (e0 + q < ks) && !hfail && (rel >= binMaxRel - 1) && (rel <= binMaxRel + 1) &&
-                                      (d >= lower) && (d < higher);
-                    if (keep) {
-                        LST(kk) = id;  // kk <= e0 + q: entries not yet read are never overwritten
-                        kk++;
-                        if (z < minZ) minZ = z;
-                        if (z > maxZ) maxZ = z;
-                    }
-                }
-            }
-            if (live && hfail) {
-                mytype = MLD_HistogramNoLocalMax;
-                live = false;
-            }
-            ks = live ? kk : 0;
-        } else {
-            const int kmax = uniform(wave_max_i32(ks));
-            for (int e0 = 0; e0 < kmax; e0 += kBatch) {
-                RawP rp[kBatch];
-#pragma unroll
-                for (int q = 0; q < kBatch; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ks));
-#pragma unroll
-                for (int q = 0; q < kBatch; q++) {
-                    const double z = raw_z(c, rp[q]);
-                    if (e0 + q < ks) {
-                        if (z < minZ) minZ = z;
-                        if (z > maxZ) maxZ = z;
-                    }
-                }
-            }
-        }
-
-        // ---- CalculateDepthSegmented (DepthEstimator.cpp:903-1037) ----
-        double r[kRecFields];
-#pragma unroll
-        for (int t = 0; t < kRecFields; t++) r[t] = 0.0;
-        bool pca = false;
-        if (!c.usePCA && c.useTriMax) {
-            if (live && ks > kK2Max) {
-                overflow = true;
-                live = false;
-            }
-            if (live && ks < 3) {
-                mytype = MLD_TriangleNotPlanarInsufficientPoints;
-                live = false;
-            }
-            V3 c1, c2, c3;
-            bool ok = triangle_small<kTriSmall>(c, s, ks, live && ks <= kTriSmall, lst, lane, c1, c2, c3);
-            if (__any(live && ks > kTriSmall)) {  // rare: longer segmented lists take the generic serial loops
-                V3 d1, d2, d3;
-                bool ok2 = triangle_thread(c, s, ks, live && ks > kTriSmall, lst, lane, d1, d2, d3);
-                if (ks > kTriSmall) {
-                    ok = ok2;
-                    c1 = d1;
-                    c2 = d2;
-                    c3 = d3;
-                }
-            }
-            if (live && !ok) {
-                mytype = MLD_TriangleNotPlanarInsufficientPoints;
-                live = false;
-            }
-            r[0] = c1.x; r[1] = c1.y; r[2] = c1.z;
-            r[3] = c2.x; r[4] = c2.y; r[5] = c2.z;
-            r[6] = c3.x; r[7] = c3.y; r[8] = c3.z;
-        } else {
-            if (live && ks < 3) {
-                mytype = MLD_HistogramNoLocalMax;  // :920-921
-                live = false;
-            }
-            if (c.usePCA) {
-                // Mono_LidarPipeline::PCA::CalculatePCA (PCA.cpp:45-62): mean, scatter, in index order
-                pca = true;
-                const int n = live ? ks : 0;
-                const int nmax = uniform(wave_max_i32(n));
-                double sx = 0, sy = 0, sz = 0;
-                for (int e = 0; e < nmax; e++)
-                    if (e < n) {
-                        V3 p = cam_point(c, s, LST(e));
-                        sx += p.x;
-                        sy += p.y;
-                        sz += p.z;
-                    }
-                const double mx = sx / (double)n, my = sy / (double)n, mz = sz / (double)n;
-                double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0;
-                for (int e = 0; e < nmax; e++)
-                    if (e < n) {
-                        V3 p = cam_point(c, s, LST(e));
-                        double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
-                        c0 += dx * dx;
-                        c1 += dx * dy;
-                        c2 += dx * dz;
-                        c3 += dy * dy;
-                        c4 += dy * dz;
-                        c5 += dz * dz;
-                    }
-                r[0] = mx; r[1] = my; r[2] = mz;
-                r[3] = c0; r[4] = c1; r[5] = c2; r[6] = c3; r[7] = c4; r[8] = c5;
-            } else if (live) {
-                V3 p0 = cam_point(c, s, LST(0)), p1 = cam_point(c, s, LST(1)), p2 = cam_point(c, s, LST(2));
-                r[0] = p0.x; r[1] = p0.y; r[2] = p0.z;
-                r[3] = p1.x; r[4] = p1.y; r[5] = p1.z;
-                r[6] = p2.x; r[7] = p2.y; r[8] = p2.z;
-            }
-        }
-        r[9] = minZ;
-        r[10] = maxZ;
-        if (live) finish_main(c, pca, myu, myv, r, mytype, mydepth);
+        main_after_scan(c, s, lst, lane, k, live, myu, myv, mytype, mydepth, overflow);
 
         // ---------------- road fallback (DepthEstimator.cpp:578-597) ----------------
         const bool road_on = c.useRoad && s.has_plane;
@@ -1703,6 +1712,104 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
         GPTRW(double, s.depth)[f0 + lane] = mydepth;
         if (s.type) GPTRW(int32_t, s.type)[f0 + lane] = mytype;
     }
+}
+
+// Main kernel of the default configuration: 256 features per block.  After the window scan only the features that
+// still need work (enough neighbours for the histogram) are LIVE — about a third in a KITTI-like frame, where the
+// sky has no LiDAR returns — so the block re-deals them to dense wavefronts before the histogram / triangle / tail
+// code runs; wavefronts that receive nothing retire at once.  A dealt lane addresses the index list of the lane
+// that scanned the feature (same LDS, other wave's region).
+constexpr int kMainThreads = 256;
+__global__ __launch_bounds__(kMainThreads) void k_feature_main(const SlotDesc* __restrict__ slots, SlotDesc single,
+                                                               int use_single, Calib c, int n_slots, int per_slot,
+                                                               uint32_t tag_all) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int slot, j;
+    decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
+    SlotDesc s = use_single ? single : slots[slot];
+    if (tag_all) s.tag = tag_all;
+    const long long f0 = (long long)j * kMainThreads;
+    long long Fn = s.F;
+    if (s.F_dev) {
+        const long long fd = *GPTR(long long, s.F_dev);
+        Fn = fd < Fn ? fd : Fn;
+    }
+    if (f0 >= Fn) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & (kWave - 1);
+    constexpr int kWaves = kMainThreads / kWave;
+    uint32_t* lst_all = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* info = lst_all + kWaves * c.k1max * kWave;  // [kMainThreads] dealt slot -> (origin thread | k << 16)
+    int* wsum = reinterpret_cast<int*>(info + kMainThreads);
+    uint32_t* lst = lst_all + wave * c.k1max * kWave;
+    const bool active = f0 + tid < Fn;
+    double myu = 0, myv = 0;
+    if (active) {
+        const auto* q = GPTR(double, s.uv) + 2 * (f0 + tid);
+        myu = q[0];
+        myv = q[1];
+    }
+    // ---------------- main window (DepthEstimator.cpp:509-510) ----------------
+    const int k = scan_window_thread(c, s, myu, myv, c.halfX1, c.halfY1, active, lst, lane);
+    const bool overflow = active && (k > c.k1max);
+    int mytype = MLD_Unspecified;
+    bool live = active && !overflow;
+    if (live && (unsigned)k < c.countMin) {
+        mytype = MLD_RadiusSearchInsufficientPoints;
+        live = false;
+    }
+    // fewer neighbours than the histogram's minimum bin count: no bin can become a maximum, FilterPointsMinDistBlob
+    // returns false on every path (HistogramPointDepth.cpp:53,84,95)
+    if (live && c.useHist && c.minCount >= 1 && k < c.minCount) {
+        mytype = MLD_HistogramNoLocalMax;
+        live = false;
+    }
+    const bool road_on = c.useRoad && s.has_plane;
+    // ---------------- deal the live features to dense wavefronts ----------------
+    const unsigned long long lm = __ballot(live);
+    if (lane == 0) wsum[wave] = (int)__popcll(lm);
+    __syncthreads();
+    int base = 0, nlive = 0;
+#pragma unroll
+    for (int q = 0; q < kWaves; q++) {
+        const int t = wsum[q];
+        base += (q < wave) ? t : 0;
+        nlive += t;
+    }
+    if (live) info[base + prefix_count(lm)] = (uint32_t)tid | ((uint32_t)k << 16);
+    __syncthreads();
+    // features finished (or handed on) by the scanning lane itself
+    if (active && !live) {
+        GPTRW(double, s.depth)[f0 + tid] = -1.0;
+        if (s.type) GPTRW(int32_t, s.type)[f0 + tid] = mytype;
+    }
+    enqueue_features(s.road_queue, s.road_count, road_on && active && !live && !overflow && mytype == MLD_HistogramNoLocalMax,
+                     lane, f0 + tid, mytype);
+    enqueue_features(s.ovf_queue, s.ovf_count, overflow, lane, f0 + tid, -1);
+    if (wave * kWave >= nlive) return;  // nothing dealt to this wavefront (no barrier follows)
+    // ---------------- dealt features: histogram, triangle, tail ----------------
+    const bool has = tid < nlive;
+    const uint32_t inf = has ? info[tid] : 0u;
+    const int origin = (int)(inf & 0xFFFFu), kd = (int)(inf >> 16);
+    const long long f = f0 + origin;
+    double u = 0, v = 0;
+    if (has) {
+        const auto* q = GPTR(double, s.uv) + 2 * f;
+        u = q[0];
+        v = q[1];
+    }
+    uint32_t* olst = lst_all + (origin >> 6) * c.k1max * kWave;
+    int type2 = MLD_Unspecified;
+    double depth2 = -1.0;
+    bool ovf2 = false;
+    main_after_scan(c, s, olst, origin & (kWave - 1), kd, has, u, v, type2, depth2, ovf2);
+    if (has) {
+        GPTRW(double, s.depth)[f] = depth2;
+        if (s.type) GPTRW(int32_t, s.type)[f] = type2;
+    }
+    enqueue_features(s.road_queue, s.road_count,
+                     road_on && has && !ovf2 && (type2 != MLD_Success) && (type2 != MLD_RadiusSearchInsufficientPoints), lane,
+                     f, type2);
+    enqueue_features(s.ovf_queue, s.ovf_count, has && ovf2, lane, f, -1);
 }
 
 // Road fallback for the features queued by k_feature_depth (thread path, splitRoad): one lane per queued feature.
