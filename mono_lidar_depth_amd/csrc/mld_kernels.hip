@@ -1017,6 +1017,7 @@ constexpr int kK1MaxLimit = 64;  // upper bound of Calib::k1max, the per-feature
                                  // (LDS: k1max entries x 64 lanes x 4 B per wave; relative bins need k1max < 254)
 constexpr int kK2Max = 16;  // longest list the per-thread O(n^2) triangle search accepts
 constexpr int kTriSmall = 8;
+constexpr int kZc = 12;      // list entries whose depth stays in registers over the histogram passes
 constexpr int kBatch = 4;    // list entries fetched ahead of use in the per-lane list loops  // lists up to this length use the fully unrolled in-register triangle search
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -1430,7 +1431,23 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
         const int kmax = uniform(wave_max_i32(ks));
         int md = 0;
         double dmin = 1.7976931348623157e308;
-        for (int e0 = 0; e0 < kmax; e0 += kBatch) {
+        // z of the first kZc entries stays in registers over the three passes; longer lists reload the rest
+        double zc[kZc];
+        {
+            RawP rp[kZc];
+#pragma unroll
+            for (int q = 0; q < kZc; q++) rp[q] = load_raw(s, LST_ID(q, ks));
+#pragma unroll
+            for (int q = 0; q < kZc; q++) {
+                zc[q] = raw_z(c, rp[q]);
+                double d = (999. < zc[q]) ? 999. : zc[q];
+                int ce = (int)ceil(d);
+                const bool ok = q < ks;
+                md = ok ? max(md, ce) : md;
+                dmin = (ok && d < dmin) ? d : dmin;
+            }
+        }
+        for (int e0 = kZc; e0 < kmax; e0 += kBatch) {
             RawP rp[kBatch];
 #pragma unroll
             for (int q = 0; q < kBatch; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ks));
@@ -1453,7 +1470,17 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
             double q = fabs(value / c.binW);
             bmin = (int)((lim < q) ? lim : q);  // bin index is monotone in d: the smallest d gives the first bin
         }
-        for (int e0 = 0; e0 < kmax; e0 += kBatch) {
+#pragma unroll
+        for (int q = 0; q < kZc; q++) {
+            double d = (999. < zc[q]) ? 999. : zc[q];
+            double value = (1e10 < d) ? 1e10 : d;
+            double qq = fabs(value / c.binW);
+            int bi = (int)((lim < qq) ? lim : qq);
+            int rel = bi - bmin;
+            rel = rel > 255 ? 255 : rel;
+            if (q < ks) LST(q) = (LST(q) & kIdxMask) | ((uint32_t)rel << kIdxBits);
+        }
+        for (int e0 = kZc; e0 < kmax; e0 += kBatch) {
             RawP rp[kBatch];
             uint32_t ids[kBatch];
 #pragma unroll
@@ -1513,7 +1540,22 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
         const double lower = (double)(bmin + binMaxRel) * c.binW - 0.0 * c.binW;
         const double higher = (double)(bmin + binMaxRel) * c.binW + 1.0 * c.binW;
         int kk = 0;
-        for (int e0 = 0; e0 < kmax; e0 += kBatch) {
+#pragma unroll
+        for (int q = 0; q < kZc; q++) {
+            const uint32_t packed = (q < ks) ? LST(q) : 0u;
+            const int rel = (int)(packed >> kIdxBits);
+            const double z = zc[q];
+            const double d = (999. < z) ? 999. : z;
+            const bool keep = (q < ks) && !hfail && (rel >= binMaxRel - 1) && (rel <= binMaxRel + 1) &&
+                              (d >= lower) && (d < higher);
+            if (keep) {
+                LST(kk) = packed & kIdxMask;
+                kk++;
+                if (z < minZ) minZ = z;
+                if (z > maxZ) maxZ = z;
+            }
+        }
+        for (int e0 = kZc; e0 < kmax; e0 += kBatch) {
             RawP rp[kBatch];
             uint32_t packed[kBatch];
 #pragma unroll
