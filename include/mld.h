@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLD_ABI_VERSION 2
+#define MLD_ABI_VERSION 3
 
 typedef enum mld_status {
     MLD_OK = 0,
@@ -101,6 +101,7 @@ typedef struct mld_params {
     double plane_estimator_z_x_min_relation;     /* :141 */
     double triangleplanar_crossnorm_treshold;    /* :154 */
     double viewray_plane_orthoganality_treshold; /* :155 */
+    double ransac_plane_treshold_camx;           /* :121  |x_cam| bound of the ground-plane debug cloud */
     int32_t neighbor_search_mode;                /* :20  must be 0 */
     int32_t pixelarea_search_witdh;              /* :21  */
     int32_t pixelarea_search_height;             /* :22  */
@@ -126,7 +127,7 @@ typedef struct mld_params {
     int32_t set_all_depths_to_zero;              /* :156 */
     int32_t ransac_plane_max_iterations;         /* :117 */
     int32_t ransac_plane_use_refinement;         /* :118 */
-    int32_t reserved_;
+    int32_t ransac_plane_use_camx_treshold;      /* :120 */
 } mld_params;
 
 /* Header defaults of DepthEstimatorParameters.h (note viewray_plane_orthoganality_treshold{01} == 1.0). */
@@ -251,6 +252,25 @@ int mld_get_point_index(mld_ctx* ctx, int slot, int32_t* index_out, int64_t capa
 int mld_get_cloud_camera_cs(mld_ctx* ctx, int slot, double* xyz_out, int64_t capacity);
 int mld_get_pixel_map(mld_ctx* ctx, int slot, int32_t* map_out, int64_t capacity);
 int mld_get_point_depth_cam_visible(mld_ctx* ctx, int slot, int64_t visible_index, double* depth_out);
+
+/*
+ * Debug mode (ActivateDebugMode, DepthEstimator.h:85-87) — the debug vectors behind getCloudTriangleCorners /
+ * getCloudRansacPlane (DepthEstimator.cpp:347-349, 396-398).
+ *   mld_calculate_depth_debug  -> CalculateDepth plus `_points_triangle_corners` as filled by
+ *                                 CalculatePlaneCorners (PlaneEstimationCalcMaxSpanningTriangle.cpp:20-35,
+ *                                 called from DepthEstimator.cpp:916): corners_out is 9 x F column-major
+ *                                 (corner1 xyz, corner2 xyz, corner3 xyz; camera frame) for every feature whose
+ *                                 spanning triangle was found, NaN otherwise.  Feature order instead of the
+ *                                 reference's unordered OpenMP push order.  Same depths/types as
+ *                                 mld_calculate_depth; slower (every feature takes the wave-cooperative kernel).
+ *   mld_get_ground_plane_cloud -> `_points_groundplane` (DepthEstimator.cpp:294-308): camera-frame coordinates of
+ *                                 the slot's ground-plane inliers, ascending original index, filtered by
+ *                                 ransac_plane_use_camx_treshold / ransac_plane_treshold_camx.  3 x n
+ *                                 column-major; xyz_out == NULL only counts.
+ */
+int mld_calculate_depth_debug(mld_ctx* ctx, int slot, const double* uv_host, int64_t F, double* depth_out_host,
+                              int32_t* type_out_host, double* corners_out_host);
+int mld_get_ground_plane_cloud(mld_ctx* ctx, int slot, double* xyz_out, int64_t capacity, int64_t* n_out);
 
 /* DepthCalculationStatistics counterpart: histogram of a resultType array (counts[MLD_RESULT_TYPE_COUNT]). */
 int mld_result_histogram(const int32_t* types, int64_t F, int64_t counts[MLD_RESULT_TYPE_COUNT]);

@@ -61,6 +61,7 @@ class MldParams(C.Structure):
         ("plane_estimator_z_x_min_relation", C.c_double),
         ("triangleplanar_crossnorm_treshold", C.c_double),
         ("viewray_plane_orthoganality_treshold", C.c_double),
+        ("ransac_plane_treshold_camx", C.c_double),
         ("neighbor_search_mode", C.c_int32),
         ("pixelarea_search_witdh", C.c_int32),
         ("pixelarea_search_height", C.c_int32),
@@ -86,7 +87,7 @@ class MldParams(C.Structure):
         ("set_all_depths_to_zero", C.c_int32),
         ("ransac_plane_max_iterations", C.c_int32),
         ("ransac_plane_use_refinement", C.c_int32),
-        ("reserved_", C.c_int32),
+        ("ransac_plane_use_camx_treshold", C.c_int32),
     ]
 
     def copy(self) -> "MldParams":
@@ -140,6 +141,9 @@ _SIGNATURES = [
     ("mld_get_cloud_camera_cs", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     ("mld_get_pixel_map", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     ("mld_get_point_depth_cam_visible", C.c_int, [C.c_void_p, C.c_int, C.c_int64, _P(C.c_double)]),
+    ("mld_calculate_depth_debug", C.c_int,
+     [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mld_get_ground_plane_cloud", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     ("mld_result_histogram", C.c_int, [C.c_void_p, C.c_int64, _P(C.c_int64)]),
     ("mld_timing_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("mld_timing_reset", C.c_int, [C.c_void_p]),

@@ -375,10 +375,11 @@ int ensure_road_queue(mld_ctx* ctx, Slot& s, int64_t F) {
     return MLD_OK;
 }
 
-int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int slot) {
+int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int slot, const Calib* override_calib = nullptr) {
     if (max_F <= 0) return MLD_OK;
+    const Calib& calib = override_calib ? *override_calib : ctx->calib;
     int per_slot = (int)((max_F + kWave - 1) / kWave);
-    const bool split = ctx->calib.splitRoad != 0;
+    const bool split = calib.splitRoad != 0;
     const uint32_t tag_all = single ? 0u : common_tag(ctx, n_slots);
     // queue lengths must be zero at launch; a batched setInputCloud has just cleared them with the bitmaps
     if (!ctx->counters_clean)
@@ -391,28 +392,28 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
             const int pm = (int)((max_F + kMainThreads - 1) / kMainThreads);
             if (single) {
                 hipLaunchKernelGGL(k_feature_main, dim3(pm), dim3(kMainThreads), ctx->lds_main, ctx->stream, ctx->d_slots,
-                                   ctx->slots[slot].d, 1, ctx->calib, 1, pm, 0u);
+                                   ctx->slots[slot].d, 1, calib, 1, pm, 0u);
             } else {
                 hipLaunchKernelGGL(k_feature_main, dim3((unsigned)pm * n_slots), dim3(kMainThreads), ctx->lds_main,
-                                   ctx->stream, ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, pm, tag_all);
+                                   ctx->stream, ctx->d_slots, SlotDesc{}, 0, calib, n_slots, pm, tag_all);
             }
         } else if (single) {
             hipLaunchKernelGGL(k_feature_depth<false>, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream,
-                               ctx->d_slots, ctx->slots[slot].d, 1, ctx->calib, 1, per_slot, 0u);
+                               ctx->d_slots, ctx->slots[slot].d, 1, calib, 1, per_slot, 0u);
         } else {
             hipLaunchKernelGGL(k_feature_depth<false>, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
-                               ctx->stream, ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot, tag_all);
+                               ctx->stream, ctx->d_slots, SlotDesc{}, 0, calib, n_slots, per_slot, tag_all);
         }
     }
     if (split) {
         ScopedTimer tm(ctx, 2);
-        auto k_feature_road = ctx->calib.roadMode ? mld::k_feature_road<1> : mld::k_feature_road<0>;
+        auto k_feature_road = calib.roadMode ? mld::k_feature_road<1> : mld::k_feature_road<0>;
         if (single) {
             hipLaunchKernelGGL(k_feature_road, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
-                               ctx->slots[slot].d, 1, ctx->calib, 1, per_slot, 0u);
+                               ctx->slots[slot].d, 1, calib, 1, per_slot, 0u);
         } else {
             hipLaunchKernelGGL(k_feature_road, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
-                               ctx->stream, ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot, tag_all);
+                               ctx->stream, ctx->d_slots, SlotDesc{}, 0, calib, n_slots, per_slot, tag_all);
         }
     }
     {
@@ -421,10 +422,10 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         const int pw = single ? std::min(per_slot, 256) : std::min(per_slot, 4);
         if (single) {
             hipLaunchKernelGGL(k_feature_wave, dim3(pw), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
-                               ctx->slots[slot].d, 1, ctx->calib, 1, pw, 0u);
+                               ctx->slots[slot].d, 1, calib, 1, pw, 0u);
         } else {
             hipLaunchKernelGGL(k_feature_wave, dim3((unsigned)pw * n_slots), dim3(kWave), ctx->lds_bytes, ctx->stream,
-                               ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, pw, tag_all);
+                               ctx->d_slots, SlotDesc{}, 0, calib, n_slots, pw, tag_all);
         }
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -882,7 +883,8 @@ int mld_set_ground_planes_mask_device(mld_ctx* ctx, int n_slots, const float* co
 }
 
 // ---------------------------------------------------------------------------- CalculateDepth
-static int calc_one(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, double* depth_dev, int32_t* type_dev) {
+static int calc_one(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, double* depth_dev, int32_t* type_dev,
+                    double* corners_dev = nullptr) {
     Slot& s = ctx->slots[slot];
     s.d.uv = uv_dev;
     s.d.F = F;
@@ -898,6 +900,16 @@ static int calc_one(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, dou
                            type_dev, (long long)F);
         HIP_TRY(ctx, hipGetLastError());
         return MLD_OK;
+    }
+    if (corners_dev) {
+        // debug mode: every feature takes the wave-cooperative kernel, which also stores the triangle corners
+        Calib dbg = ctx->calib;
+        dbg.threadPath = 0;
+        dbg.splitRoad = 0;
+        s.d.corners = corners_dev;
+        int rc = launch_features(ctx, 1, F, true, slot, &dbg);
+        s.d.corners = nullptr;
+        return rc;
     }
     return launch_features(ctx, 1, F, true, slot);
 }
@@ -942,6 +954,83 @@ int mld_calculate_depth(mld_ctx* ctx, int slot, const double* uv_host, int64_t F
         HIP_TRY(ctx, hipMemcpyAsync(type_out_host, s.type_buf, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost,
                                     ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MLD_OK;
+}
+
+int mld_calculate_depth_debug(mld_ctx* ctx, int slot, const double* uv_host, int64_t F, double* depth_out_host,
+                              int32_t* type_out_host, double* corners_out_host) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    if ((rc = precheck_calc(ctx, s, F))) return rc;
+    if (F == 0) return MLD_OK;
+    if (!uv_host || !depth_out_host || !corners_out_host) return fail(ctx, MLD_ERR_INVALID_ARG, "null feature/output pointer");
+    double *uv = nullptr, *depth = nullptr, *corners = nullptr;
+    int32_t* type = nullptr;
+    hipError_t e = hipMalloc((void**)&uv, (size_t)F * 2 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&depth, (size_t)F * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&type, (size_t)F * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&corners, (size_t)F * 9 * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(uv, uv_host, (size_t)F * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(corners, 0xFF, (size_t)F * 9 * sizeof(double), ctx->stream);  // all-ones = NaN
+    if (e == hipSuccess) {
+        // set_all_depths_to_zero never reaches the plane code: no corners
+        rc = calc_one(ctx, slot, uv, F, depth, type, ctx->P.set_all_depths_to_zero ? nullptr : corners);
+        if (rc == MLD_OK) {
+            e = hipMemcpyAsync(depth_out_host, depth, (size_t)F * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess && type_out_host)
+                e = hipMemcpyAsync(type_out_host, type, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(corners_out_host, corners, (size_t)F * 9 * sizeof(double), hipMemcpyDeviceToHost,
+                                   ctx->stream);
+        }
+    }
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    // the slot must not keep pointers into the temporaries
+    s.d.uv = nullptr;
+    s.d.depth = nullptr;
+    s.d.type = nullptr;
+    s.d.F = 0;
+    for (void* q : {(void*)uv, (void*)depth, (void*)type, (void*)corners})
+        if (q) (void)hipFree(q);
+    if (rc) return rc;
+    HIP_TRY(ctx, e);
+    HIP_TRY(ctx, e2);
+    return MLD_OK;
+}
+
+int mld_get_ground_plane_cloud(mld_ctx* ctx, int slot, double* xyz_out, int64_t capacity, int64_t* n_out) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    if (!n_out) return fail(ctx, MLD_ERR_INVALID_ARG, "null count pointer");
+    *n_out = 0;
+    if (!s.cloud_set) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "no cloud set for this slot");
+    if (!s.d.has_plane || !s.d.inlier_mask || s.d.n == 0) return MLD_OK;
+    if ((rc = ensure_full(ctx, s))) return rc;
+    const size_t words = ((size_t)s.d.n + 31) / 32;
+    std::vector<uint32_t> mask(words);
+    std::vector<double> cam((size_t)s.d.n * 3);
+    HIP_TRY(ctx, hipMemcpyAsync(mask.data(), s.d.inlier_mask, words * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(cam.data(), s.cam, cam.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t k = 0;
+    for (int64_t i = 0; i < s.d.n; i++) {
+        if (!((mask[(size_t)i >> 5] >> (i & 31)) & 1u)) continue;
+        const double* q = &cam[(size_t)i * 3];
+        if (ctx->P.ransac_plane_use_camx_treshold && !(std::fabs(q[0]) <= ctx->P.ransac_plane_treshold_camx))
+            continue;  // DepthEstimator.cpp:300-307
+        if (xyz_out && k < capacity) {
+            xyz_out[3 * k] = q[0];
+            xyz_out[3 * k + 1] = q[1];
+            xyz_out[3 * k + 2] = q[2];
+        }
+        k++;
+    }
+    *n_out = k;
+    if (xyz_out && k > capacity) return fail(ctx, MLD_ERR_CAPACITY, "output buffer too small");
     return MLD_OK;
 }
 

@@ -804,7 +804,8 @@ __device__ __forceinline__ void finish_road(const Calib& c, bool triangle, doubl
 
 __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, unsigned char* smem, const int lane,
                                        const unsigned long long mask, const double myu, const double myv, int& mytype,
-                                       double& mydepth, const unsigned long long main_mask) {
+                                       double& mydepth, const unsigned long long main_mask, double (&corners)[9],
+                                       bool& has_corners) {
     Lists L;
     L.x = reinterpret_cast<double*>(smem);
     L.y = L.x + c.cap;
@@ -883,6 +884,10 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
 
     // ---------------- phase 2 (lane = feature) ----------------
     if (mystate == ST_TRIANGLE || mystate == ST_PCA) {
+        // debug vector of CalculatePlaneCorners (PlaneEstimationCalcMaxSpanningTriangle.cpp:20-35)
+        has_corners = (mystate == ST_TRIANGLE) && !c.usePCA && c.useTriMax;
+#pragma unroll
+        for (int t = 0; t < 9; t++) corners[t] = myr[t];
         finish_main(c, mystate == ST_PCA, myu, myv, myr, mytype, mydepth);
         mystate = ST_FINAL;
     }
@@ -1920,10 +1925,16 @@ __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restri
         double mydepth = -1.0;
         const unsigned long long all = __ballot(active);
         const unsigned long long full = __ballot(active && code < 0);
-        wave_path(c, s, smem, lane, all, myu, myv, mytype, mydepth, full);
+        double corners[9];
+        bool has_corners = false;
+        wave_path(c, s, smem, lane, all, myu, myv, mytype, mydepth, full, corners, has_corners);
         if (active) {
             GPTRW(double, s.depth)[f] = mydepth;
             if (s.type) GPTRW(int32_t, s.type)[f] = mytype;
+            if (s.corners && has_corners) {
+#pragma unroll
+                for (int t = 0; t < 9; t++) GPTRW(double, s.corners)[9 * f + t] = corners[t];
+            }
         }
     }
 }

@@ -44,6 +44,8 @@ void mld_params_default(mld_params* p) {
     p->ransac_plane_use_refinement = 1;
     p->ransac_plane_refinement_treshold = 10.2;
     p->ransac_plane_probability = 0.999;
+    p->ransac_plane_use_camx_treshold = 0;
+    p->ransac_plane_treshold_camx = 2.0;
     p->plane_estimator_use_triangle_maximation = 0;
     p->plane_estimator_z_x_min_relation = 0;
     p->plane_estimator_use_leastsquares = 0;
@@ -112,6 +114,8 @@ const Field kFields[] = {
     FI(ransac_plane_use_refinement),
     FD(ransac_plane_refinement_treshold),
     FD(ransac_plane_probability),
+    FI(ransac_plane_use_camx_treshold),
+    FD(ransac_plane_treshold_camx),
     FI(plane_estimator_use_triangle_maximation),
     FD(plane_estimator_z_x_min_relation),
     FI(plane_estimator_use_leastsquares),
@@ -134,7 +138,7 @@ bool is_bool_field(const char* key) {
                                   "plane_estimator_use_leastsquares", "plane_estimator_use_mestimator",
                                   "do_use_cut_behind_camera", "do_use_triangle_size_maximation",
                                   "do_check_triangleplanar_condition", "set_all_depths_to_zero",
-                                  "ransac_plane_use_refinement"};
+                                  "ransac_plane_use_refinement", "ransac_plane_use_camx_treshold"};
     for (const char* k : kBool)
         if (std::strcmp(k, key) == 0) return true;
     return false;

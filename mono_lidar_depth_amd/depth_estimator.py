@@ -122,6 +122,8 @@ class DepthEstimator:
         self._isInitializedConfig = False
         self._isInitialized = False
         self._keepalive = {}
+        self._debug = False
+        self._debug_last = None
 
     # ------------------------------------------------------------------ lifecycle
     def InitConfig(self, parameters=None, printparams: bool = False) -> bool:
@@ -359,9 +361,61 @@ class DepthEstimator:
         F = int(uvh.size // 2)
         depth = np.empty(F, dtype=np.float64)
         types = np.empty(F, dtype=np.int32)
-        self._check(self._lib.mld_calculate_depth(self._ctx, slot, uvh.ctypes.data, F, depth.ctypes.data,
-                                                  types.ctypes.data))
+        if self._debug:
+            corners = np.empty((F, 9), dtype=np.float64)
+            self._check(self._lib.mld_calculate_depth_debug(self._ctx, slot, uvh.ctypes.data, F, depth.ctypes.data,
+                                                            types.ctypes.data, corners.ctypes.data))
+            self._debug_last = (uvh.reshape(F, 2).copy(), depth.copy(), types.copy(), corners)
+        else:
+            self._check(self._lib.mld_calculate_depth(self._ctx, slot, uvh.ctypes.data, F, depth.ctypes.data,
+                                                      types.ctypes.data))
         return (depth, types) if return_types else depth
+
+    # ------------------------------------------------------------------ debug mode
+    def ActivateDebugMode(self):
+        """ActivateDebugMode (DepthEstimator.h:85-87): host-input CalculateDepth calls also record the debug
+        vectors behind getCloudTriangleCorners / getCloudInterpolated."""
+        self._debug = True
+
+    def getTriangleCorners(self) -> np.ndarray:
+        """F x 9 corners (corner1 xyz, corner2 xyz, corner3 xyz; NaN = no triangle) of the last debug-mode call."""
+        if self._debug_last is None:
+            return np.empty((0, 9))
+        return self._debug_last[3]
+
+    def getCloudTriangleCorners(self) -> np.ndarray:
+        """getCloudTriangleCorners (DepthEstimator.cpp:347-349): 3 x 3m, the corners CalculatePlaneCorners
+        published (PlaneEstimationCalcMaxSpanningTriangle.cpp:27-32), in feature order."""
+        c = self.getTriangleCorners()
+        c = c[np.isfinite(c[:, 0])] if c.size else c
+        return c.reshape(-1, 3).T.copy()
+
+    def getCloudInterpolated(self) -> np.ndarray:
+        """getCloudInterpolated (DepthEstimator.cpp:339-341): 3 x m intersection points ray ∩ plane of the features
+        with a valid depth.  (The reference's push at DepthEstimator.cpp:1032 is commented out, so its cloud is
+        always empty; debug mode here returns what the member is documented to hold, DepthEstimator.h:328.)"""
+        if self._debug_last is None:
+            return np.empty((3, 0))
+        uv, depth, types, _ = self._debug_last
+        ok = depth >= 0
+        f, cu, cv = self._camera.focal_length, self._camera.principal_point_x, self._camera.principal_point_y
+        ray = np.stack([(uv[ok, 0] - cu) / f, (uv[ok, 1] - cv) / f, np.ones(int(ok.sum()))])
+        return ray * depth[ok]
+
+    def getCloudNeighbors(self) -> np.ndarray:
+        """getCloudNeighbors (DepthEstimator.cpp:335-337): never filled by the reference (push commented out,
+        DepthEstimator.cpp:663) — always empty."""
+        return np.empty((3, 0))
+
+    def getCloudRansacPlane(self, slot: int = 0) -> np.ndarray:
+        """getCloudRansacPlane (DepthEstimator.cpp:396-398): 3 x n camera-frame ground-plane inliers
+        (`_points_groundplane`, DepthEstimator.cpp:294-308)."""
+        n = C.c_int64(0)
+        self._check(self._lib.mld_get_ground_plane_cloud(self._ctx, slot, None, 0, C.byref(n)))
+        out = np.empty((n.value, 3), dtype=np.float64)
+        if n.value:
+            self._check(self._lib.mld_get_ground_plane_cloud(self._ctx, slot, out.ctypes.data, n.value, C.byref(n)))
+        return out.T
 
     @staticmethod
     def _uv_host(uv) -> np.ndarray:

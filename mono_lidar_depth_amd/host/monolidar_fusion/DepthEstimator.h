@@ -253,6 +253,52 @@ public:
         check(mld_get_visible_image_points(_ctx, 0, uv.data(), n));
     }
 
+    // ---- debug mode (DepthEstimator.h:85-87) and the debug clouds (DepthEstimator.cpp:335-398) ----
+    void ActivateDebugMode() { _debugMode = true; }
+    // triangle corners published by CalculatePlaneCorners (PlaneEstimationCalcMaxSpanningTriangle.cpp:27-32) in the
+    // last debug-mode CalculateDepth, feature order
+    void getCloudTriangleCorners(Cloud::Ptr& pointCloud_triangle_corner) {
+        pointCloud_triangle_corner->points.clear();
+        for (size_t i = 0; i + 8 < _dbgCorners.size(); i += 9) {
+            if (_dbgCorners[i] != _dbgCorners[i]) continue;  // NaN: no triangle for this feature
+            for (int c = 0; c < 3; c++) pushPoint(*pointCloud_triangle_corner, &_dbgCorners[i + 3 * c]);
+        }
+    }
+    // `_points_groundplane` (DepthEstimator.cpp:294-308)
+    void getCloudRansacPlane(Cloud::Ptr& pointCloud_plane_ransac) {
+        int64_t n = 0;
+        check(mld_get_ground_plane_cloud(_ctx, 0, nullptr, 0, &n));
+        std::vector<double> xyz((size_t)n * 3);
+        if (n) check(mld_get_ground_plane_cloud(_ctx, 0, xyz.data(), n, &n));
+        pointCloud_plane_ransac->points.clear();
+        for (int64_t i = 0; i < n; i++) pushPoint(*pointCloud_plane_ransac, &xyz[(size_t)i * 3]);
+    }
+    // Intersection points ray x plane of the features with a valid depth (debug mode).  The reference's push is
+    // commented out (DepthEstimator.cpp:1032), its cloud is always empty; this returns what the member is documented
+    // to hold (DepthEstimator.h:328).
+    void getCloudInterpolated(Cloud::Ptr& pointCloud_interpolated) {
+        pointCloud_interpolated->points.clear();
+        const mld_camera cam = _camera->asStruct();
+        for (size_t i = 0; i < _dbgDepth.size(); i++) {
+            if (!(_dbgDepth[i] >= 0)) continue;
+            const double p[3] = {(_dbgUv[2 * i] - cam.principal_point_x) / cam.focal_length * _dbgDepth[i],
+                                 (_dbgUv[2 * i + 1] - cam.principal_point_y) / cam.focal_length * _dbgDepth[i], _dbgDepth[i]};
+            pushPoint(*pointCloud_interpolated, p);
+        }
+    }
+    void getCloudInterpolatedPlane(Cloud::Ptr& pointCloud_interpolated_plane) {
+        getCloudInterpolated(pointCloud_interpolated_plane);  // same source vector in the reference (:343-345)
+    }
+    // never filled by the reference (push commented out, DepthEstimator.cpp:663): always empty
+    void getCloudNeighbors(Cloud::Ptr& pointCloud_neighbors) { pointCloud_neighbors->points.clear(); }
+    // getCloudCameraCs as a cloud (DepthEstimator.cpp:314-334)
+    void getCloudCameraCs(Cloud::Ptr& pointCloud_cam_cs) {
+        std::vector<double> xyz;
+        getCloudCameraCs(xyz);
+        pointCloud_cam_cs->points.clear();
+        for (int64_t i = 0; i < _numPoints; i++) pushPoint(*pointCloud_cam_cs, &xyz[(size_t)i * 3]);
+    }
+
     // CalculateDepth overloads (DepthEstimator.cpp:404-488).  uv: 2 x F column-major.
     void CalculateDepth(const Cloud::ConstPtr& pointCloud, const std::vector<double>& points_image_cs,
                         std::vector<double>& points_depths, GroundPlane::Ptr& ransacPlane) {
@@ -278,6 +324,14 @@ public:
         points_depths.resize((size_t)F);  // callee-resized outputs, DepthEstimator.cpp:442-443
         resultType.resize((size_t)F);
         static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
+        if (_debugMode) {
+            _dbgCorners.assign((size_t)F * 9, 0.0);
+            check(mld_calculate_depth_debug(_ctx, 0, points_image_cs.data(), F, points_depths.data(),
+                                            reinterpret_cast<int32_t*>(resultType.data()), _dbgCorners.data()));
+            _dbgUv = points_image_cs;
+            _dbgDepth = points_depths;
+            return;
+        }
         check(mld_calculate_depth(_ctx, 0, points_image_cs.data(), F, points_depths.data(),
                                   reinterpret_cast<int32_t*>(resultType.data())));
     }
@@ -317,6 +371,17 @@ private:
         if (rc == MLD_ERR_CLOUD_TOO_SMALL) throw GroundPlane::ExceptionPclInvalid();
         throw std::runtime_error(std::string("DepthEstimator: ") + mld_last_error(_ctx));
     }
+    // FillCloud (DepthEstimator.cpp:351-371): xyz as float, intensity 1
+    static void pushPoint(Cloud& cloud, const double* xyz) {
+        PointXYZI q{};
+        q.x = (float)xyz[0];
+        q.y = (float)xyz[1];
+        q.z = (float)xyz[2];
+        q.intensity = 1;
+        cloud.points.push_back(q);
+    }
+    bool _debugMode = false;
+    std::vector<double> _dbgCorners, _dbgUv, _dbgDepth;
     int _device;
     mld_ctx* _ctx = nullptr;
     bool _isInitialized = false, _isInitializedConfig = false, _isInitializedPointCloud = false;

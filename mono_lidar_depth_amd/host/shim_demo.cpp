@@ -64,6 +64,24 @@ int main(int argc, char** argv) {
         auto stats = DepthEstimator::getDepthCalcStats(types);
         std::cout << "features " << types.size() << " success " << stats[Success] << " road " << stats[SuccessRoad]
                   << " insufficient " << stats[RadiusSearchInsufficientPoints] << "\n";
+        // debug mode: same results, plus the debug clouds of the reference's getters
+        est.ActivateDebugMode();
+        std::vector<double> depths_dbg;
+        std::vector<int> types_dbg;
+        est.CalculateDepth(uv, depths_dbg, types_dbg, gp);
+        auto corners = std::make_shared<PointCloud>(), plane = std::make_shared<PointCloud>(),
+             interp = std::make_shared<PointCloud>(), nb = std::make_shared<PointCloud>(),
+             camcs = std::make_shared<PointCloud>();
+        est.getCloudTriangleCorners(corners);
+        est.getCloudRansacPlane(plane);
+        est.getCloudInterpolated(interp);
+        est.getCloudNeighbors(nb);
+        est.getCloudCameraCs(camcs);
+        size_t valid = 0;
+        for (double d : depths_dbg) valid += d >= 0 ? 1 : 0;
+        std::cout << "debug same_types " << (types_dbg == types ? 1 : 0) << " corners " << corners->points.size()
+                  << " plane " << plane->points.size() << " interpolated " << interp->points.size() << " valid " << valid
+                  << " neighbors " << nb->points.size() << " camcs " << camcs->points.size() << "\n";
         // usage error as in the reference: CalculateDepth before setInputCloud
         DepthEstimator fresh(0);
         fresh.InitConfig();

@@ -20,12 +20,12 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, f"libmld_hip.so lacks: {missing}"
     assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
-    assert lib.mld_abi_version() == 2
+    assert lib.mld_abi_version() == 3
 
 
 def test_struct_layout_matches_header():
-    # doubles first, then int32s: 14*8 + 26*4 = 216 bytes; camera 3*8 + 2*4 = 32
-    assert C.sizeof(capi.MldParams) == 216
+    # doubles first, then int32s: 15*8 + 26*4 = 224 bytes; camera 3*8 + 2*4 = 32
+    assert C.sizeof(capi.MldParams) == 224
     assert C.sizeof(capi.MldCamera) == 32
     header = (ROOT / "include" / "mld.h").read_text()
     body = header[header.index("typedef struct mld_params {"):header.index("} mld_params;")]
@@ -63,7 +63,8 @@ def test_params_from_file(tmp_path):
                  "do_check_triangleplanar_condition: 1\ntriangleplanar_crossnorm_treshold: 0.1\n"
                  "viewray_plane_orthoganality_treshold: 0.03\nunknown_key: 7\nransac_plane_distance_treshold: 0.3\n"
                  "ransac_plane_max_iterations: 10000\nransac_plane_probability: 0.999\nransac_plane_use_refinement: 1\n"
-                 "ransac_plane_refinement_treshold: 10.2\n")
+                 "ransac_plane_refinement_treshold: 10.2\nransac_plane_use_camx_treshold: 0\n"
+                 "ransac_plane_treshold_camx: 2.0\n")
     p = capi.params_from_file(str(y))
     c0 = capi.params_c0()
     for name, _ in capi.MldParams._fields_:

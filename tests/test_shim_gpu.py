@@ -40,3 +40,14 @@ def test_cpp_shim_matches_oracle(tmp_path, with_plane):
     coeffs[3] = np.float32(1.73)
     _, (d0, t0) = run_oracle(P, cloud, uv, (coeffs, inl) if with_plane else None)
     assert_depth_parity(depth, types, d0, t0)
+    # debug-mode leg of the demo: identical result types, 3 corners per found triangle, one interpolated point per
+    # valid depth, the ground-plane cloud of the supplied inliers, the reference's always-empty neighbour cloud
+    import re
+    m = re.search(r"debug same_types (\d+) corners (\d+) plane (\d+) interpolated (\d+) valid (\d+) neighbors (\d+) "
+                  r"camcs (\d+)", r.stdout)
+    assert m, r.stdout
+    same, n_corners, n_plane, n_interp, n_valid, n_nb, n_cam = map(int, m.groups())
+    assert same == 1 and n_corners % 3 == 0 and n_corners > 0
+    assert n_interp == n_valid == int((d0 >= 0).sum())
+    assert n_plane == (np.unique(inl).size if with_plane else 0)
+    assert n_nb == 0 and n_cam == cloud.shape[0]
