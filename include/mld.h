@@ -188,6 +188,24 @@ int mld_set_ground_plane_device(mld_ctx* ctx, int slot, const float coeffs[4], c
  * Synchronises.  MLD_ERR_CLOUD_TOO_SMALL: fewer than 3 usable points / no model (ExceptionPclInvalid).
  */
 int mld_estimate_ground_plane(mld_ctx* ctx, int slot, uint32_t seed, float coeffs_out[4], int64_t* n_inliers_out);
+/*
+ * SemanticPlane::CalculateInliersPlane on the GPU (monolidar_fusion/src/RansacPlane.cpp:195-274) — the ground plane
+ * tracklets_depth uses when a semantic label image accompanies the frame (tracklet_depth_module.cpp:270-284):
+ * points whose projection falls on a pixel with a ground label (:198-221), least-squares plane through them
+ * (:238-246), all cloud points within `inlier_threshold` of it (:252), plane refitted to those (:253); installs the
+ * result as the slot's ground plane (coefficients of the refit, inliers = the selected points, :259-268).
+ * SemanticPlane::Camera is the context's own calibration (f, cu, cv, T_cam_lidar), as the caller builds it.
+ * label_image: rows x cols uint8, row_stride_bytes apart.  Fewer than 3 labelled points: MLD_ERR_CLOUD_TOO_SMALL
+ * (ExceptionPclInvalid, :224-227).  Pixels x == cols / y == rows, which the reference reads out of bounds, carry no
+ * label here.  PCL's sequential float sums are replaced by 256 interleaved partial sums (parity unpinned, as for
+ * mld_estimate_ground_plane).
+ */
+int mld_estimate_semantic_plane(mld_ctx* ctx, int slot, const uint8_t* label_image_host, int rows, int cols,
+                                int row_stride_bytes, const int32_t* ground_labels, int n_labels, double inlier_threshold,
+                                float coeffs_out[4], int64_t* n_inliers_out);
+int mld_estimate_semantic_plane_device(mld_ctx* ctx, int slot, const uint8_t* label_image_dev, int rows, int cols,
+                                       int row_stride_bytes, const int32_t* ground_labels, int n_labels,
+                                       double inlier_threshold, float coeffs_out[4], int64_t* n_inliers_out);
 /* The slot's current inlier set as ascending original indices (GroundPlane::getInlinersIndex). */
 int mld_get_ground_plane_inliers(mld_ctx* ctx, int slot, int32_t* index_out, int64_t capacity, int64_t* n_out);
 /* Same, with the inlier set already as a device bitmask (bit i of word i/32 = point i is an inlier). */

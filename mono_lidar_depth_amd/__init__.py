@@ -6,9 +6,9 @@ sharding.py (sequence -> GPU assignment and the calibration broadcast).
 """
 from .capi import MldCamera, MldParams, params_c0, params_default, params_from_file, RESULT_TYPE_NAMES
 from .depth_estimator import (NO_PLANE, CameraPinhole, DepthEstimator, DepthEstimatorError, ExceptionPclInvalid,
-                              GroundPlane, RansacPlane)
+                              GroundPlane, RansacPlane, SemanticPlane)
 
 from .tracklets import TrackletDepthModule
 
 __all__ = ["TrackletDepthModule", "MldCamera", "MldParams", "params_c0", "params_default", "params_from_file", "RESULT_TYPE_NAMES",
-           "NO_PLANE", "RansacPlane", "CameraPinhole", "DepthEstimator", "DepthEstimatorError", "ExceptionPclInvalid", "GroundPlane"]
+           "NO_PLANE", "RansacPlane", "SemanticPlane", "CameraPinhole", "DepthEstimator", "DepthEstimatorError", "ExceptionPclInvalid", "GroundPlane"]

@@ -124,6 +124,10 @@ _SIGNATURES = [
     ("mld_set_ground_plane", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p, C.c_int64]),
     ("mld_set_ground_plane_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p, C.c_int64]),
     ("mld_estimate_ground_plane", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, _P(C.c_float), _P(C.c_int64)]),
+    ("mld_estimate_semantic_plane", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_int, C.c_double, _P(C.c_float), _P(C.c_int64)]),
+    ("mld_estimate_semantic_plane_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                     C.c_void_p, C.c_int, C.c_double, _P(C.c_float), _P(C.c_int64)]),
     ("mld_get_ground_plane_inliers", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, _P(C.c_int64)]),
     ("mld_set_ground_plane_mask_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p]),
     ("mld_set_ground_planes_mask_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), _P(C.c_void_p)]),

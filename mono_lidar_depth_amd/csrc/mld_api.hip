@@ -91,6 +91,11 @@ struct mld_ctx {
     size_t rs_counts_cap = 0;
     int32_t* rs_inl = nullptr;
     ransac::Result* rs_res = nullptr;
+    // semantic ground plane scratch (device)
+    unsigned char* sem_img = nullptr;
+    size_t sem_img_cap = 0;
+    float* sem_coeffs = nullptr;  // dummy prior, first fit, second fit
+    ransac::SemResult* sem_res = nullptr;
     // tracklet gather/scatter scratch (device)
     double* trk_uv_cur = nullptr;
     double* trk_uv_last = nullptr;
@@ -665,7 +670,7 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->road_counts) (void)hipFree(ctx->road_counts);  // also holds the bitmaps
     void* rsp[] = {ctx->rs_flags, ctx->rs_cand, ctx->rs_block, ctx->rs_M, ctx->rs_S, ctx->rs_sample, ctx->rs_sp,
-                   ctx->rs_counts, ctx->rs_inl, ctx->rs_res};
+                   ctx->rs_counts, ctx->rs_inl, ctx->rs_res, ctx->sem_img, ctx->sem_coeffs, ctx->sem_res};
     for (void* p : rsp)
         if (p) (void)hipFree(p);
     void* trk[] = {ctx->trk_uv_cur, ctx->trk_uv_last, ctx->trk_depth_cur, ctx->trk_depth_last, ctx->trk_type_cur,
@@ -765,6 +770,24 @@ int mld_set_ground_plane(mld_ctx* ctx, int slot, const float coeffs[4], const in
     return build_mask_from_indices(ctx, s, s.inl_buf, n_inliers);
 }
 
+// per-point flags, their order-preserving compaction and the block sums in between
+static int ensure_scan_buffers(mld_ctx* ctx, long long n) {
+    if ((size_t)n <= ctx->rs_cap) return MLD_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    void* olds[] = {ctx->rs_flags, ctx->rs_cand, ctx->rs_block};
+    for (void* p : olds)
+        if (p) HIP_TRY(ctx, hipFree(p));
+    ctx->rs_flags = nullptr;
+    ctx->rs_cand = nullptr;
+    ctx->rs_block = nullptr;
+    ctx->rs_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_flags, (size_t)n * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_cand, (size_t)n * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_block, ((size_t)n / kScanBlock + 1) * sizeof(int32_t)));
+    ctx->rs_cap = (size_t)n;
+    return MLD_OK;
+}
+
 int mld_estimate_ground_plane(mld_ctx* ctx, int slot, uint32_t seed, float coeffs_out[4], int64_t* n_inliers_out) {
     using namespace ransac;
     int rc = check_slot(ctx, slot);
@@ -779,7 +802,7 @@ int mld_estimate_ground_plane(mld_ctx* ctx, int slot, uint32_t seed, float coeff
     if (n_draws < 1) return fail(ctx, MLD_ERR_INVALID_ARG, "ransac_plane_max_iterations must be >= 0");
     // scratch
     if (!ctx->rs_res) {
-        HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_M, sizeof(int32_t)));
+        if (!ctx->rs_M) HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_M, sizeof(int32_t)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_S, sizeof(int32_t)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_sample, kSample * sizeof(int32_t)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_sp, kSample * 3 * sizeof(float)));
@@ -794,16 +817,7 @@ int mld_estimate_ground_plane(mld_ctx* ctx, int slot, uint32_t seed, float coeff
     }
     const bool pass = P.ransac_plane_min_z > -1001.;  // RansacPlane.cpp:57
     if (pass) {
-        if ((size_t)n > ctx->rs_cap) {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            void* olds[] = {ctx->rs_flags, ctx->rs_cand, ctx->rs_block};
-            for (void* p : olds)
-                if (p) HIP_TRY(ctx, hipFree(p));
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_flags, (size_t)n * sizeof(int32_t)));
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_cand, (size_t)n * sizeof(int32_t)));
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_block, ((size_t)n / kScanBlock + 1) * sizeof(int32_t)));
-            ctx->rs_cap = (size_t)n;
-        }
+        if ((rc = ensure_scan_buffers(ctx, n))) return rc;
         const int nb = (int)((n + kScanBlock - 1) / kScanBlock);
         hipLaunchKernelGGL(k_rs_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, s.d.cloud, n,
                            s.d.stride, (float)P.ransac_plane_min_z, (float)P.ransac_plane_max_z, ctx->rs_flags);
@@ -836,6 +850,100 @@ int mld_estimate_ground_plane(mld_ctx* ctx, int slot, uint32_t seed, float coeff
         for (int t = 0; t < 4; t++) coeffs_out[t] = res.coeffs[t];
     if (n_inliers_out) *n_inliers_out = res.n_inliers;
     return MLD_OK;
+}
+
+static int semantic_plane_core(mld_ctx* ctx, Slot& s, const unsigned char* img_dev, int rows, int cols, int row_stride,
+                               const int32_t* labels, int n_labels, double inlier_threshold, float coeffs_out[4],
+                               int64_t* n_inliers_out) {
+    using namespace ransac;
+    int rc = MLD_OK;
+    const long long n = s.d.n;
+    LabelSet ls{};
+    for (int i = 0; i < n_labels; i++)
+        if (labels[i] >= 0 && labels[i] < 256) ls.w[labels[i] >> 5] |= 1u << (labels[i] & 31);
+    SemCalib sc{};
+    for (int t = 0; t < 12; t++) sc.T[t] = ctx->calib.T[t];
+    sc.f = ctx->cam.focal_length;
+    sc.cu = ctx->cam.principal_point_x;
+    sc.cv = ctx->cam.principal_point_y;
+    if (!ctx->sem_res) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->sem_coeffs, 12 * sizeof(float)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->sem_res, sizeof(SemResult)));
+        const float init[12] = {0.f, 0.f, 1.f, 0.f, 0, 0, 0, 0, 0, 0, 0, 0};  // dummy prior (:241-242)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->sem_coeffs, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (!ctx->rs_M) HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_M, sizeof(int32_t)));
+    if ((rc = ensure_scan_buffers(ctx, n))) return rc;
+    const size_t words = (size_t)((n + 31) / 32);
+    if ((rc = grow(ctx, s.mask_buf, s.mask_words, words))) return rc;
+    const int nb = (int)((n + kScanBlock - 1) / kScanBlock);
+    const dim3 gp((unsigned)((n + 255) / 256)), bp(256);
+    auto compact = [&]() {
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(kScanBlock), 0, ctx->stream, ctx->rs_flags, n, ctx->rs_block);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, ctx->stream, ctx->rs_block, nb, ctx->rs_M);
+        hipLaunchKernelGGL(k_rs_compact, dim3(nb), dim3(kScanBlock), 0, ctx->stream, ctx->rs_flags, n, ctx->rs_block,
+                           ctx->rs_cand);
+    };
+    // candidates by label, first fit
+    hipLaunchKernelGGL(k_sem_flags, gp, bp, 0, ctx->stream, s.d.cloud, n, s.d.stride, sc, img_dev, rows, cols, row_stride,
+                       ls, ctx->rs_flags);
+    compact();
+    hipLaunchKernelGGL(k_ls_fit, dim3(1), dim3(kPartials), 0, ctx->stream, s.d.cloud, s.d.stride, ctx->rs_cand, ctx->rs_M,
+                       ctx->sem_coeffs, ctx->sem_coeffs + 4, 3, 0, ctx->sem_res);
+    // re-selection over the whole cloud, second fit, inlier mask
+    hipLaunchKernelGGL(k_sem_select, gp, bp, 0, ctx->stream, s.d.cloud, n, s.d.stride, ctx->sem_coeffs + 4,
+                       inlier_threshold, ctx->rs_flags);
+    compact();
+    hipLaunchKernelGGL(k_ls_fit, dim3(1), dim3(kPartials), 0, ctx->stream, s.d.cloud, s.d.stride, ctx->rs_cand, ctx->rs_M,
+                       ctx->sem_coeffs + 4, ctx->sem_coeffs + 8, 0, 1, ctx->sem_res);
+    hipLaunchKernelGGL(k_mask_from_flags, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs_flags, n,
+                       s.mask_buf);
+    HIP_TRY(ctx, hipGetLastError());
+    SemResult res;
+    HIP_TRY(ctx, hipMemcpyAsync(&res, ctx->sem_res, sizeof(SemResult), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (res.status != 0) return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");  // :224-227
+    rc = set_plane_common(ctx, s, res.coeffs);
+    if (rc) return rc;
+    s.d.inlier_mask = s.mask_buf;
+    if (coeffs_out)
+        for (int t = 0; t < 4; t++) coeffs_out[t] = res.coeffs[t];
+    if (n_inliers_out) *n_inliers_out = res.n_inliers;
+    return MLD_OK;
+}
+
+static int semantic_plane_args(mld_ctx* ctx, int slot, const void* img, int rows, int cols, int row_stride,
+                               const int32_t* labels, int n_labels) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if ((rc = bind_device(ctx))) return rc;
+    Slot& s = ctx->slots[slot];
+    if (!s.cloud_set) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "ground plane estimation before the slot's cloud");
+    if (!img || rows <= 0 || cols <= 0 || row_stride < cols || n_labels < 0 || (n_labels > 0 && !labels))
+        return fail(ctx, MLD_ERR_INVALID_ARG, "bad label image / label set");
+    return MLD_OK;
+}
+
+int mld_estimate_semantic_plane_device(mld_ctx* ctx, int slot, const uint8_t* label_image_dev, int rows, int cols,
+                                       int row_stride_bytes, const int32_t* ground_labels, int n_labels,
+                                       double inlier_threshold, float coeffs_out[4], int64_t* n_inliers_out) {
+    int rc = semantic_plane_args(ctx, slot, label_image_dev, rows, cols, row_stride_bytes, ground_labels, n_labels);
+    if (rc) return rc;
+    return semantic_plane_core(ctx, ctx->slots[slot], label_image_dev, rows, cols, row_stride_bytes, ground_labels,
+                               n_labels, inlier_threshold, coeffs_out, n_inliers_out);
+}
+
+int mld_estimate_semantic_plane(mld_ctx* ctx, int slot, const uint8_t* label_image_host, int rows, int cols,
+                                int row_stride_bytes, const int32_t* ground_labels, int n_labels, double inlier_threshold,
+                                float coeffs_out[4], int64_t* n_inliers_out) {
+    int rc = semantic_plane_args(ctx, slot, label_image_host, rows, cols, row_stride_bytes, ground_labels, n_labels);
+    if (rc) return rc;
+    const size_t bytes = (size_t)rows * (size_t)row_stride_bytes;
+    if ((rc = grow(ctx, ctx->sem_img, ctx->sem_img_cap, bytes))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->sem_img, label_image_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return semantic_plane_core(ctx, ctx->slots[slot], ctx->sem_img, rows, cols, row_stride_bytes, ground_labels, n_labels,
+                               inlier_threshold, coeffs_out, n_inliers_out);
 }
 
 int mld_get_ground_plane_inliers(mld_ctx* ctx, int slot, int32_t* index_out, int64_t capacity, int64_t* n_out) {

@@ -321,5 +321,132 @@ __global__ __launch_bounds__(kPartials) void k_rs_refine(const float* __restrict
     if (tid == 0) res->n_inliers = total_s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// SemanticPlane::CalculateInliersPlane (monolidar_fusion/src/RansacPlane.cpp:195-274): ground candidates from a
+// label image, least-squares plane, re-selection over the whole cloud, second fit.  Flag kernels feed the same
+// order-preserving compaction as the pass-through above; the fits use the 256-partial float association of
+// k_rs_refine.
+struct LabelSet {
+    uint32_t w[8];  // bit l set: label l (0..255) is ground
+};
+struct SemCalib {
+    double T[12];  // lidar -> camera, row-major 3x4
+    double f, cu, cv;
+};
+struct SemResult {
+    float coeffs[4];
+    int32_t n_candidates;
+    int32_t n_inliers;
+    int32_t status;  // 0 ok, 1 fewer than 3 candidates
+    int32_t pad_;
+};
+
+// :198-221  pcl::transformPointCloud (double arithmetic, float result), project() (K * p as Eigen evaluates a
+// 3x3 * 3x1 product: x0 + (x1 + x2); p /= p[2]; cv::Point truncation), image bounds, label lookup.  The pixels
+// x == cols / y == rows the reference reads out of bounds count as unlabeled; non-finite projections as invalid.
+__global__ void k_sem_flags(const unsigned char* cloud, long long n, int stride, SemCalib sc, const unsigned char* img,
+                            int rows, int cols, int row_stride, LabelSet ls, int32_t* flags) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* q = reinterpret_cast<const float*>(cloud + (size_t)i * stride);
+    const double x = q[0], y = q[1], z = q[2];
+    const float xc = (float)(((sc.T[0] * x + sc.T[1] * y) + sc.T[2] * z) + sc.T[3]);
+    const float yc = (float)(((sc.T[4] * x + sc.T[5] * y) + sc.T[6] * z) + sc.T[7]);
+    const float zc = (float)(((sc.T[8] * x + sc.T[9] * y) + sc.T[10] * z) + sc.T[11]);
+    const double px = (double)xc, py = (double)yc, pz = (double)zc;
+    const double p0 = sc.f * px + (0.0 * py + sc.cu * pz);
+    const double p1 = 0.0 * px + (sc.f * py + sc.cv * pz);
+    const double p2 = 0.0 * px + (0.0 * py + 1.0 * pz);
+    const double u = p0 / p2, v = p1 / p2;
+    int flag = 0;
+    if (isfinite(u) && isfinite(v) && fabs(u) < 2147483648.0 && fabs(v) < 2147483648.0) {
+        const int ix = (int)u, iy = (int)v;
+        if (ix >= 0 && ix < cols && iy >= 0 && iy < rows) {
+            const unsigned l = img[(size_t)iy * row_stride + ix];
+            flag = (ls.w[l >> 5] >> (l & 31)) & 1u;
+        }
+    }
+    flags[i] = flag;
+}
+
+// SampleConsensusModelPlane::selectWithinDistance over the whole cloud (:252), float distance < double threshold
+__global__ void k_sem_select(const unsigned char* cloud, long long n, int stride, const float* __restrict__ coeffs,
+                             double thr, int32_t* flags) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float c[4] = {coeffs[0], coeffs[1], coeffs[2], coeffs[3]};
+    const float* q = reinterpret_cast<const float*>(cloud + (size_t)i * stride);
+    flags[i] = ((double)plane_dist(c, q) < thr) ? 1 : 0;
+}
+
+// optimizeModelCoefficients over the cloud points idx[0..*m_dev): fewer than 4 entries return `fallback`.
+// One block of kPartials threads; thread p owns entries p, p+256, ...; partials combined in index order.
+// Also records the entry count (and the < min_count failure) in the result.
+__global__ __launch_bounds__(kPartials) void k_ls_fit(const unsigned char* cloud, int stride, const int32_t* __restrict__ idx,
+                                                     const int32_t* __restrict__ m_dev, const float* __restrict__ fallback,
+                                                     float* __restrict__ out, int min_count, int stage, SemResult* res) {
+    __shared__ float acc[kPartials][9];
+    const int tid = threadIdx.x;
+    const int m = *m_dev;
+    if (tid == 0) {
+        if (stage == 0) {
+            res->n_candidates = m;
+            res->status = (m < min_count) ? 1 : 0;
+        } else {
+            res->n_inliers = m;
+        }
+    }
+    if (m < 4) {
+        if (tid < 4) out[tid] = fallback[tid];
+        if (stage == 1 && tid < 4) res->coeffs[tid] = fallback[tid];
+        return;
+    }
+    float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = tid; q < m; q += kPartials) {
+        const float* v = reinterpret_cast<const float*>(cloud + (size_t)idx[q] * stride);
+        a[0] += v[0] * v[0];
+        a[1] += v[0] * v[1];
+        a[2] += v[0] * v[2];
+        a[3] += v[1] * v[1];
+        a[4] += v[1] * v[2];
+        a[5] += v[2] * v[2];
+        a[6] += v[0];
+        a[7] += v[1];
+        a[8] += v[2];
+    }
+    for (int t = 0; t < 9; t++) acc[tid][t] = a[t];
+    __syncthreads();
+    if (tid == 0) {
+        float s9[9];
+        for (int t = 0; t < 9; t++) {
+            float sum = 0.0f;
+            for (int p = 0; p < kPartials; p++) sum += acc[p][t];
+            s9[t] = sum / (float)m;
+        }
+        float cov[6] = {s9[0] - s9[6] * s9[6], s9[1] - s9[6] * s9[7], s9[2] - s9[6] * s9[8],
+                        s9[3] - s9[7] * s9[7], s9[4] - s9[7] * s9[8], s9[5] - s9[8] * s9[8]};
+        double sd[6] = {cov[0], cov[1], cov[2], cov[3], cov[4], cov[5]}, n0[3];
+        rs_smallest_eigvec(sd, n0);
+        const float e0 = (float)n0[0], e1 = (float)n0[1], e2 = (float)n0[2];
+        const float c[4] = {e0, e1, e2, -1.0f * (e0 * s9[6] + e1 * s9[7] + e2 * s9[8])};
+        for (int t = 0; t < 4; t++) {
+            out[t] = c[t];
+            if (stage == 1) res->coeffs[t] = c[t];
+        }
+    }
+}
+
+// inlier bitmask from per-point flags: one word per thread
+__global__ void k_mask_from_flags(const int32_t* __restrict__ flags, long long n, uint32_t* __restrict__ mask) {
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w * 32 >= n) return;
+    uint32_t bits = 0;
+    for (int b = 0; b < 32; b++) {
+        const long long i = w * 32 + b;
+        if (i < n && flags[i]) bits |= 1u << b;
+    }
+    mask[w] = bits;
+}
+
 }  // namespace ransac
 }  // namespace mld

@@ -87,6 +87,18 @@ class RansacPlane(GroundPlane):
         return self.inliers
 
 
+class SemanticPlane(RansacPlane):
+    """SemanticPlane(img, cam, groundplane_label, inlier_threshold) (RansacPlane.h:175-218): ground plane from a label
+    image; estimated on the GPU by setInputCloud while not segmented (SemanticPlane::CalculateInliersPlane,
+    RansacPlane.cpp:195-274).  The camera is the estimator's own calibration."""
+
+    def __init__(self, img, groundplane_label=(6, 7, 8, 9), inlier_threshold: float = 0.1):
+        super().__init__(0)
+        self.img = img
+        self.groundplane_label = tuple(int(x) for x in groundplane_label)
+        self.inlier_threshold = float(inlier_threshold)
+
+
 class _NoPlane:
     """`ransacPlane == nullptr` of the feature-only CalculateDepth overloads: the road fallback is skipped
     (DepthEstimator.cpp:580)."""
@@ -245,7 +257,11 @@ class DepthEstimator:
         if groundPlane is None:
             groundPlane = RansacPlane()
         if isinstance(groundPlane, RansacPlane) and not groundPlane.isSegmented():
-            coeffs, _ = self.estimateGroundPlane(slot, groundPlane.seed)
+            if isinstance(groundPlane, SemanticPlane):
+                coeffs, _ = self.estimateSemanticPlane(groundPlane.img, groundPlane.groundplane_label,
+                                                       groundPlane.inlier_threshold, slot)
+            else:
+                coeffs, _ = self.estimateGroundPlane(slot, groundPlane.seed)
             groundPlane.coeffs = coeffs
             groundPlane.inliers = None
             groundPlane._segmented = True
@@ -304,6 +320,31 @@ class DepthEstimator:
         coeffs = (C.c_float * 4)()
         n_inl = C.c_int64(0)
         self._check(self._lib.mld_estimate_ground_plane(self._ctx, slot, int(seed) & 0xFFFFFFFF, coeffs, C.byref(n_inl)))
+        return np.array(list(coeffs), dtype=np.float32), int(n_inl.value)
+
+    def estimateSemanticPlane(self, label_image, groundplane_label=(6, 7, 8, 9), inlier_threshold: float = 0.1,
+                              slot: int = 0):
+        """SemanticPlane::CalculateInliersPlane for the slot's cloud (RansacPlane.cpp:195-274).  `label_image`:
+        rows x cols uint8 (numpy, or a torch CUDA tensor for the device entry point).
+        Returns (coefficients float32[4], inlier count)."""
+        lab = np.ascontiguousarray(groundplane_label, dtype=np.int32)
+        coeffs = (C.c_float * 4)()
+        n_inl = C.c_int64(0)
+        if _is_torch_cuda(label_image):
+            import torch
+            if label_image.dtype != torch.uint8 or label_image.dim() != 2 or label_image.stride(1) != 1:
+                raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "label image must be a 2-D uint8 tensor")
+            torch.cuda.current_stream(label_image.device).synchronize()
+            self._check(self._lib.mld_estimate_semantic_plane_device(
+                self._ctx, slot, label_image.data_ptr(), label_image.shape[0], label_image.shape[1],
+                label_image.stride(0), lab.ctypes.data, lab.size, float(inlier_threshold), coeffs, C.byref(n_inl)))
+        else:
+            img = np.ascontiguousarray(label_image, dtype=np.uint8)
+            if img.ndim != 2:
+                raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "label image must be 2-D")
+            self._check(self._lib.mld_estimate_semantic_plane(
+                self._ctx, slot, img.ctypes.data, img.shape[0], img.shape[1], img.strides[0], lab.ctypes.data, lab.size,
+                float(inlier_threshold), coeffs, C.byref(n_inl)))
         return np.array(list(coeffs), dtype=np.float32), int(n_inl.value)
 
     def getGroundPlaneInliers(self, slot: int = 0) -> np.ndarray:

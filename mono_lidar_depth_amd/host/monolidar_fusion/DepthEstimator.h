@@ -10,10 +10,12 @@
 // Header-only; link with -lmld_hip.
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <exception>
 #include <memory>
+#include <set>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -144,6 +146,35 @@ public:
     uint32_t seed = 0;
 };
 
+// SemanticPlane (RansacPlane.h:175-218): ground plane from a semantic label image, estimated on the GPU by
+// DepthEstimator::setInputCloud while not segmented (SemanticPlane::CalculateInliersPlane, RansacPlane.cpp:195-274 ->
+// mld_estimate_semantic_plane).  The image replaces cv::Mat: rows x cols uint8, copied like the reference's
+// std::make_unique<cv::Mat>(img).  SemanticPlane::Camera is the estimator's own calibration.
+class SemanticPlane : public RansacPlane {
+public:
+    using Ptr = std::shared_ptr<SemanticPlane>;
+    SemanticPlane(const uint8_t* img, int rows, int cols, int row_stride_bytes, std::set<int> groundplane_label,
+                  double inlier_threshold)
+            : rows_(rows), cols_(cols), groundplane_label_(groundplane_label.begin(), groundplane_label.end()),
+              inlier_threshold_(inlier_threshold) {
+        semantic_image_.resize((size_t)rows * (size_t)cols);
+        for (int r = 0; r < rows; r++)
+            std::copy(img + (size_t)r * row_stride_bytes, img + (size_t)r * row_stride_bytes + cols,
+                      semantic_image_.begin() + (size_t)r * cols);
+    }
+    const std::vector<uint8_t>& image() const { return semantic_image_; }
+    int rows() const { return rows_; }
+    int cols() const { return cols_; }
+    const std::vector<int>& labels() const { return groundplane_label_; }
+    double inlierThreshold() const { return inlier_threshold_; }
+
+private:
+    std::vector<uint8_t> semantic_image_;
+    int rows_, cols_;
+    std::vector<int> groundplane_label_{6, 7, 8, 9};
+    double inlier_threshold_{0.1};
+};
+
 class DepthEstimator {
 public:
     using Point = PointXYZI;
@@ -215,9 +246,15 @@ public:
                 } else {
                     float coeffs[4];
                     int64_t n_inl = 0;
-                    check(mld_estimate_ground_plane(_ctx, 0, rp->seed, coeffs, &n_inl));
-                    std::vector<int> inl((size_t)n_inl);
                     static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
+                    if (auto* sp = dynamic_cast<SemanticPlane*>(rp)) {
+                        check(mld_estimate_semantic_plane(_ctx, 0, sp->image().data(), sp->rows(), sp->cols(), sp->cols(),
+                                                          reinterpret_cast<const int32_t*>(sp->labels().data()),
+                                                          (int)sp->labels().size(), sp->inlierThreshold(), coeffs, &n_inl));
+                    } else {
+                        check(mld_estimate_ground_plane(_ctx, 0, rp->seed, coeffs, &n_inl));
+                    }
+                    std::vector<int> inl((size_t)n_inl);
                     check(mld_get_ground_plane_inliers(_ctx, 0, reinterpret_cast<int32_t*>(inl.data()), n_inl, &n_inl));
                     rp->assign({coeffs[0], coeffs[1], coeffs[2], coeffs[3]}, std::move(inl));
                     return;  // the estimator already installed the plane on the device

@@ -82,6 +82,18 @@ int main(int argc, char** argv) {
         std::cout << "debug same_types " << (types_dbg == types ? 1 : 0) << " corners " << corners->points.size()
                   << " plane " << plane->points.size() << " interpolated " << interp->points.size() << " valid " << valid
                   << " neighbors " << nb->points.size() << " camcs " << camcs->points.size() << "\n";
+        // semantic ground plane (the 4-argument TrackletDepthModule::process, tracklet_depth_module.cpp:270-284): a
+        // label image with every pixel "road" makes every projectable point a candidate
+        if (est.getParameters()->do_use_ransac_plane) {
+            std::vector<uint8_t> labels((size_t)375 * 1242, 7);
+            GroundPlane::Ptr sem = std::make_shared<SemanticPlane>(labels.data(), 375, 1242, 1242, std::set<int>{6, 7, 8, 9},
+                                                                   est.getParameters()->ransac_plane_refinement_treshold);
+            std::vector<double> d3;
+            std::vector<int> t3;
+            est.CalculateDepth(ccloud, uv, d3, t3, sem);
+            std::cout << "semantic segmented " << (sem->isSegmented() ? 1 : 0) << " inliers " << sem->getInlinersIndex().size()
+                      << " nz " << sem->getModelCoeffs()[2] << "\n";
+        }
         // usage error as in the reference: CalculateDepth before setInputCloud
         DepthEstimator fresh(0);
         fresh.InitConfig();

@@ -114,3 +114,28 @@ def make_ground_plane(cloud: np.ndarray, subsample: int = 0, seed: int = 0):
         inl = np.sort(rng.choice(inl, subsample, replace=False)).astype(np.int32)
     coeffs = np.array([0.0, 0.0, 1.0, -GROUND_Z], dtype=np.float32)
     return coeffs, inl
+
+
+def make_label_image(cloud: np.ndarray, width: int = KITTI_W, height: int = KITTI_H) -> np.ndarray:
+    """Synthetic semantic label image (rows x cols uint8) for SemanticPlane, rendered from the frame itself: pixels
+    hit by ground returns carry label 7 (road) or 8 (sidewalk, |y_lidar| > 6 m), pixels hit by anything else label 11,
+    the rest 23 (sky).  Object returns are painted last, so that they occlude the ground as in a real segmentation."""
+    xyz = cloud[:, :3].astype(np.float64)
+    cam = xyz @ T_CAM_LIDAR[:, :3].T + T_CAM_LIDAR[:, 3]
+    front = cam[:, 2] > 0.5
+    u = np.where(front, cam[:, 0] / np.where(front, cam[:, 2], 1.0) * KITTI_F + KITTI_CU, -1.0)
+    v = np.where(front, cam[:, 1] / np.where(front, cam[:, 2], 1.0) * KITTI_F + KITTI_CV, -1.0)
+    inside = front & (u >= 0) & (u < width) & (v >= 0) & (v < height)
+    ground = np.abs(xyz[:, 2] - GROUND_Z) < 0.1
+    img = np.full((height, width), 23, dtype=np.uint8)
+
+    def paint(sel, label, rx, ry):
+        ix, iy = u[sel].astype(np.int64), v[sel].astype(np.int64)
+        for dy in range(-ry, ry + 1):
+            for dx in range(-rx, rx + 1):
+                img[np.clip(iy + dy, 0, height - 1), np.clip(ix + dx, 0, width - 1)] = label
+
+    paint(inside & ground & (np.abs(xyz[:, 1]) <= 6.0), 7, 2, 1)
+    paint(inside & ground & (np.abs(xyz[:, 1]) > 6.0), 8, 2, 1)
+    paint(inside & ~ground, 11, 1, 1)
+    return img

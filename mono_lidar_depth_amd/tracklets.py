@@ -18,7 +18,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from . import capi
-from .depth_estimator import CameraPinhole, DepthEstimator, GroundPlane, _is_torch_cuda
+from .depth_estimator import CameraPinhole, DepthEstimator, GroundPlane, SemanticPlane, _is_torch_cuda
 
 
 class TrackletDepthModule:
@@ -40,8 +40,10 @@ class TrackletDepthModule:
     def known_ids(self):
         return self._tracklet_map.keys()
 
-    def process(self, cloud, ids, u_new, v_new, u_old, v_old, ground_plane: Optional[GroundPlane]):
-        """One frame (tracklet_depth_module.cpp:261-396).
+    def process(self, cloud, ids, u_new, v_new, u_old, v_old, ground_plane: Optional[GroundPlane], img=None):
+        """One frame (tracklet_depth_module.cpp:261-396).  With a semantic label image `img` (the 4-argument
+        overload, :261-284) the ground plane is a SemanticPlane with labels {6,7,8,9} and the inlier threshold
+        ransac_plane_refinement_treshold, and `ground_plane` is ignored.
 
         ids: track ids; u_new/v_new: newest feature of every track (feature_points[0]); u_old/v_old: previous
         feature (feature_points[1]; only read for tracks that are new to the module).  Returns
@@ -55,6 +57,8 @@ class TrackletDepthModule:
         is_new = np.fromiter((int(i) not in known for i in ids), dtype=np.uint8, count=n)  # :31
         slot_cur = self._slot_cur
         slot_last = (1 - slot_cur) if self._have_last else -1
+        if img is not None:
+            ground_plane = SemanticPlane(img, (6, 7, 8, 9), est.getParameters().ransac_plane_refinement_treshold)
         est.setInputCloud(cloud, ground_plane, slot=slot_cur)  # the only projection of this frame
         arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (u_new, v_new, u_old, v_old)]
         d_cur = np.empty(n, dtype=np.float32)

@@ -1149,6 +1149,104 @@ int orc_estimate_ground_plane(orc_frame* h, const void* pts_v, int64_t n, int st
     return orc_set_ground_plane(h, coeffs, inlier_idx.data(), static_cast<int64_t>(inlier_idx.size()));
 }
 
+// SampleConsensusModelPlane::optimizeModelCoefficients (PCL sac_model_plane.hpp, restated in SURVEY.md §9) over the
+// cloud points idx[0..m): computeMeanAndCovarianceMatrix with float accumulators (partial p takes the entries
+// q = p, p+256, ... and the partials are combined in index order — the association the HIP kernel uses), smallest
+// eigenvector of the covariance, d = -n.centroid.  Fewer than 4 entries: `fallback` is returned.
+static void ls_plane_fit(const uint8_t* pts, int stride, const int32_t* idx, size_t m, const float fallback[4], float out[4]) {
+    using namespace ransac;
+    for (int t = 0; t < 4; t++) out[t] = fallback[t];
+    if (m < 4) return;
+    std::vector<float> acc(static_cast<size_t>(kPartials) * 9, 0.0f);
+    for (int p = 0; p < kPartials; p++) {
+        float* a = &acc[static_cast<size_t>(p) * 9];
+        for (size_t q = p; q < m; q += kPartials) {
+            const float* v = reinterpret_cast<const float*>(pts + static_cast<int64_t>(idx[q]) * stride);
+            a[0] += v[0] * v[0];
+            a[1] += v[0] * v[1];
+            a[2] += v[0] * v[2];
+            a[3] += v[1] * v[1];
+            a[4] += v[1] * v[2];
+            a[5] += v[2] * v[2];
+            a[6] += v[0];
+            a[7] += v[1];
+            a[8] += v[2];
+        }
+    }
+    float a[9];
+    for (int t = 0; t < 9; t++) {
+        a[t] = 0.0f;
+        for (int p = 0; p < kPartials; p++) a[t] += acc[static_cast<size_t>(p) * 9 + t];
+        a[t] /= static_cast<float>(m);
+    }
+    float cov[6] = {a[0] - a[6] * a[6], a[1] - a[6] * a[7], a[2] - a[6] * a[8],
+                    a[3] - a[7] * a[7], a[4] - a[7] * a[8], a[5] - a[8] * a[8]};
+    double m9[9] = {cov[0], cov[1], cov[2], cov[1], cov[3], cov[4], cov[2], cov[4], cov[5]};
+    double ev[3], evec[9];
+    jacobi_eig3(m9, ev, evec);
+    float e0 = static_cast<float>(evec[0]), e1 = static_cast<float>(evec[3]), e2 = static_cast<float>(evec[6]);
+    out[0] = e0;
+    out[1] = e1;
+    out[2] = e2;
+    out[3] = -1.0f * (e0 * a[6] + e1 * a[7] + e2 * a[8]);
+}
+
+// SemanticPlane::CalculateInliersPlane (monolidar_fusion/src/RansacPlane.cpp:195-274) with the estimator's own
+// calibration as SemanticPlane::Camera (tracklets_depth/src/tracklet_depth_module.cpp:273-284 builds it from the same
+// camera info and transform).  `img`: rows x cols uint8 labels, row_stride bytes per row.
+//   :198-199  pcl::transformPointCloud (double arithmetic, float result) and project(): K * p (Eigen 3x3 * 3x1 in
+//             double), p /= p[2], cv::Point(int) truncation
+//   :202-221  keep the points whose pixel is inside [0,cols] x [0,rows] and carries a ground label.  The reference
+//             reads image(x == cols) / image(y == rows) out of bounds; those pixels count as unlabeled here, and
+//             non-finite or int-overflowing projections (UB in the reference) as invalid.
+//   :224-227  fewer than 3 candidates: ExceptionPclInvalid
+//   :238-246  least-squares fit to the candidates (dummy prior 0,0,1,0 returned for < 4 points)
+//   :250-254  selectWithinDistance(all points, inlier_threshold) and the fit to them
+//   :259-268  coefficients = refined fit, inliers = the selected points
+int orc_estimate_semantic_plane(orc_frame* h, const void* pts_v, int64_t n, int stride, const uint8_t* img, int rows,
+                                int cols, int row_stride, const int32_t* labels, int n_labels, double inlier_threshold,
+                                float coeffs_out[4], int64_t* n_inliers_out) {
+    if (!h || !h->fr.cloud_set) return MLD_ERR_NOT_INITIALIZED;
+    const Frame& fr = h->fr;
+    const uint8_t* pts = static_cast<const uint8_t*>(pts_v);
+    const double* T = fr.T;
+    const double f = fr.cam.focal_length, cu = fr.cam.principal_point_x, cv = fr.cam.principal_point_y;
+    bool is_ground[256] = {false};
+    for (int i = 0; i < n_labels; i++)
+        if (labels[i] >= 0 && labels[i] < 256) is_ground[labels[i]] = true;
+    std::vector<int32_t> cand;
+    for (int64_t i = 0; i < n; i++) {
+        const float* q = reinterpret_cast<const float*>(pts + i * stride);
+        const double x = q[0], y = q[1], z = q[2];
+        const float xc = static_cast<float>(((T[0] * x + T[1] * y) + T[2] * z) + T[3]);
+        const float yc = static_cast<float>(((T[4] * x + T[5] * y) + T[6] * z) + T[7]);
+        const float zc = static_cast<float>(((T[8] * x + T[9] * y) + T[10] * z) + T[11]);
+        const double px = static_cast<double>(xc), py = static_cast<double>(yc), pz = static_cast<double>(zc);
+        const double p0 = f * px + (0.0 * py + cu * pz);
+        const double p1 = 0.0 * px + (f * py + cv * pz);
+        const double p2 = 0.0 * px + (0.0 * py + 1.0 * pz);
+        const double u = p0 / p2, v = p1 / p2;
+        if (!std::isfinite(u) || !std::isfinite(v) || std::fabs(u) >= 2147483648.0 || std::fabs(v) >= 2147483648.0) continue;
+        const int ix = static_cast<int>(u), iy = static_cast<int>(v);
+        if (ix < 0 || ix > cols || iy < 0 || iy > rows) continue;  // :206-207
+        if (ix == cols || iy == rows) continue;                    // out-of-bounds read in the reference
+        if (is_ground[img[static_cast<size_t>(iy) * row_stride + ix]]) cand.push_back(static_cast<int32_t>(i));
+    }
+    if (cand.size() < 3) return MLD_ERR_CLOUD_TOO_SMALL;  // :224-227
+    const float dummy[4] = {0.f, 0.f, 1.f, 0.f};
+    float c1[4], c2[4];
+    ls_plane_fit(pts, stride, cand.data(), cand.size(), dummy, c1);
+    std::vector<int32_t> inl;
+    for (int64_t i = 0; i < n; i++) {
+        const float* q = reinterpret_cast<const float*>(pts + i * stride);
+        if (static_cast<double>(ransac::plane_dist(c1, q)) < inlier_threshold) inl.push_back(static_cast<int32_t>(i));
+    }
+    ls_plane_fit(pts, stride, inl.data(), inl.size(), c1, c2);
+    for (int t = 0; t < 4; t++) coeffs_out[t] = c2[t];
+    if (n_inliers_out) *n_inliers_out = static_cast<int64_t>(inl.size());
+    return orc_set_ground_plane(h, c2, inl.data(), static_cast<int64_t>(inl.size()));
+}
+
 int64_t orc_get_plane_inliers(const orc_frame* h, int32_t* out, int64_t cap) {
     int64_t k = 0;
     for (int64_t i = 0; i < h->fr.n; i++)

@@ -334,3 +334,62 @@ class NpDepthEstimator:
             return np.full(len(uv), -1.0), np.ones(len(uv), dtype=np.int32), [{} for _ in uv]
         out = [self.feature(float(a), float(b)) for a, b in uv]
         return (np.array([o[1] for o in out]), np.array([o[0] for o in out], dtype=np.int32), [o[2] for o in out])
+
+
+def _f32_partials_sum(values: np.ndarray, partials: int = 256) -> np.float32:
+    """Sum of float32 `values`: partial p accumulates entries p, p+256, ... sequentially, then the partials are
+    added in index order (the association of ls_plane_fit in the C++ restatement)."""
+    m = values.shape[0]
+    rows = (m + partials - 1) // partials
+    pad = np.zeros(rows * partials, dtype=np.float32)
+    pad[:m] = values
+    part = np.add.accumulate(pad.reshape(rows, partials), axis=0, dtype=np.float32)[-1]
+    return np.add.accumulate(part, dtype=np.float32)[-1]
+
+
+def ls_plane_fit(xyz: np.ndarray, idx: np.ndarray, fallback):
+    """optimizeModelCoefficients (PCL sac_model_plane.hpp): float32 moments, smallest eigenvector (LAPACK here, Jacobi
+    in the C++ restatement: same subspace, last-bit differences allowed)."""
+    if idx.size < 4:
+        return np.asarray(fallback, dtype=np.float32)
+    v = xyz[idx].astype(np.float32)
+    x, y, z = v[:, 0], v[:, 1], v[:, 2]
+    m = np.float32(idx.size)
+    a = [_f32_partials_sum(q) / m for q in (x * x, x * y, x * z, y * y, y * z, z * z, x, y, z)]
+    cov = np.array([[a[0] - a[6] * a[6], a[1] - a[6] * a[7], a[2] - a[6] * a[8]],
+                    [a[1] - a[6] * a[7], a[3] - a[7] * a[7], a[4] - a[7] * a[8]],
+                    [a[2] - a[6] * a[8], a[4] - a[7] * a[8], a[5] - a[8] * a[8]]], dtype=np.float64)
+    w, vec = np.linalg.eigh(cov)
+    n = vec[:, 0].astype(np.float32)
+    d = np.float32(-1.0) * (n[0] * a[6] + n[1] * a[7] + n[2] * a[8])
+    return np.array([n[0], n[1], n[2], d], dtype=np.float32)
+
+
+def semantic_plane(cloud: np.ndarray, T, f, cu, cv, img: np.ndarray, labels, thr: float):
+    """SemanticPlane::CalculateInliersPlane (monolidar_fusion/src/RansacPlane.cpp:195-274), vectorised.
+    Returns (candidate indices, first fit, inlier indices, refined fit)."""
+    T = np.asarray(T, dtype=np.float64).reshape(3, 4)
+    xyz = cloud[:, :3].astype(np.float64)
+    x, y, z = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    pc = [(((T[r, 0] * x + T[r, 1] * y) + T[r, 2] * z) + T[r, 3]).astype(np.float32).astype(np.float64) for r in range(3)]
+    with np.errstate(all="ignore"):
+        p0 = f * pc[0] + (0.0 * pc[1] + cu * pc[2])
+        p1 = 0.0 * pc[0] + (f * pc[1] + cv * pc[2])
+        p2 = 0.0 * pc[0] + (0.0 * pc[1] + 1.0 * pc[2])
+        u, v = p0 / p2, p1 / p2
+        ok = np.isfinite(u) & np.isfinite(v) & (np.abs(u) < 2147483648.0) & (np.abs(v) < 2147483648.0)
+        ix = np.where(ok, np.trunc(np.where(ok, u, 0.0)), -1).astype(np.int64)
+        iy = np.where(ok, np.trunc(np.where(ok, v, 0.0)), -1).astype(np.int64)
+    rows, cols = img.shape
+    ok &= (ix >= 0) & (ix < cols) & (iy >= 0) & (iy < rows)
+    lab = np.zeros(cloud.shape[0], dtype=np.int64) - 1
+    lab[ok] = img[iy[ok], ix[ok]]
+    cand = np.nonzero(np.isin(lab, np.asarray(labels)))[0].astype(np.int32)
+    if cand.size < 3:
+        raise ValueError("In GroundPlane: Input pointcloud is invalid")
+    xyz32 = cloud[:, :3].astype(np.float32)
+    c1 = ls_plane_fit(xyz32, cand, [0, 0, 1, 0])
+    dist = np.abs(((c1[0] * xyz32[:, 0] + c1[1] * xyz32[:, 1]) + c1[2] * xyz32[:, 2]) + c1[3])
+    inl = np.nonzero(dist.astype(np.float64) < thr)[0].astype(np.int32)
+    c2 = ls_plane_fit(xyz32, inl, c1)
+    return cand, c1, inl, c2

@@ -55,6 +55,8 @@ def load() -> C.CDLL:
     lib.orc_trace_feature.argtypes = [C.c_void_p, C.c_double, C.c_double, P(OrcTrace), C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int32]
     lib.orc_estimate_ground_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_uint32, P(C.c_float), P(C.c_int64)]
+    lib.orc_estimate_semantic_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                C.c_int, C.c_void_p, C.c_int, C.c_double, P(C.c_float), P(C.c_int64)]
     lib.orc_get_plane_inliers.restype = C.c_int64
     lib.orc_get_plane_inliers.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     lib.orc_tracklets_depth.argtypes = [C.c_void_p, C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 4 + [C.c_int]
@@ -128,6 +130,22 @@ class OracleDepthEstimator:
             raise RuntimeError(f"orc_estimate_ground_plane: status {rc}")
         inl = np.empty(n_inl.value, dtype=np.int32)
         k = self.lib.orc_get_plane_inliers(self.h, inl.ctypes.data, inl.size)  # unique, ascending
+        return np.array(list(coeffs), dtype=np.float32), inl[:k].copy()
+
+    def estimate_semantic_plane(self, label_image, labels, inlier_threshold: float):
+        """SemanticPlane::CalculateInliersPlane restated (see orc_estimate_semantic_plane); sets the frame's plane."""
+        arr = self._keep
+        img = np.ascontiguousarray(label_image, dtype=np.uint8)
+        lab = np.ascontiguousarray(labels, dtype=np.int32)
+        coeffs = (C.c_float * 4)()
+        n_inl = C.c_int64(0)
+        rc = self.lib.orc_estimate_semantic_plane(self.h, arr.ctypes.data, arr.shape[0], arr.shape[1] * 4, img.ctypes.data,
+                                                  img.shape[0], img.shape[1], img.strides[0], lab.ctypes.data, lab.size,
+                                                  float(inlier_threshold), coeffs, C.byref(n_inl))
+        if rc != 0:
+            raise RuntimeError(f"orc_estimate_semantic_plane: status {rc}")
+        inl = np.empty(n_inl.value, dtype=np.int32)
+        k = self.lib.orc_get_plane_inliers(self.h, inl.ctypes.data, inl.size)
         return np.array(list(coeffs), dtype=np.float32), inl[:k].copy()
 
     def calculate_depth(self, uv, n_threads: int = 1):

@@ -1,0 +1,134 @@
+"""SemanticPlane::CalculateInliersPlane (monolidar_fusion/src/RansacPlane.cpp:195-274): C++ restatement vs the NumPy
+restatement on CPU; HIP (through the C-ABI) vs the C++ restatement on the GPU."""
+import numpy as np
+import pytest
+
+from mono_lidar_depth_amd import GroundPlane, SemanticPlane, capi, synth
+from oracle import np_restatement
+
+from helpers import assert_depth_parity, kitti_camera, make_estimator, make_oracle
+
+LABELS = (6, 7, 8, 9)  # tracklet_depth_module.cpp:280
+
+
+def _frame(seed, scanner=synth.HDL64_KITTI):
+    cloud = synth.make_cloud(scanner, seed=seed, frame=1)
+    img = synth.make_label_image(cloud)
+    return cloud, img
+
+
+def _oracle_plane(cloud, img, thr, labels=LABELS):
+    ref = make_oracle(capi.params_c0())
+    ref.set_cloud(cloud)
+    coeffs, inl = ref.estimate_semantic_plane(img, labels, thr)
+    return ref, coeffs, inl
+
+
+@pytest.mark.parametrize("seed,thr", [(3, 0.1), (4, 0.3), (5, 0.05)])
+def test_oracle_matches_numpy_restatement(seed, thr):
+    cloud, img = _frame(seed)
+    _, coeffs, inl = _oracle_plane(cloud, img, thr)
+    cand, c1, inl_np, c2 = np_restatement.semantic_plane(cloud, synth.T_CAM_LIDAR, synth.KITTI_F, synth.KITTI_CU,
+                                                         synth.KITTI_CV, img, LABELS, thr)
+    assert cand.size > 1000
+    # different eigen-solvers (Jacobi / LAPACK): coefficients to float rounding, inlier sets up to borderline points
+    sgn = 1.0 if np.dot(coeffs[:3], c2[:3]) > 0 else -1.0
+    assert np.abs(coeffs - sgn * c2).max() < 2e-6
+    assert np.setxor1d(inl, inl_np).size <= 2
+    # the synthetic ground is z = -1.73 in the lidar frame; the reference's candidate set also holds the points behind
+    # the camera whose mirrored projection hits a ground pixel (no z > 0 test, RansacPlane.cpp:183-191) and its moments
+    # are float32, so the plane is only coarsely the true one
+    s = 1.0 if coeffs[2] > 0 else -1.0
+    assert abs(s * coeffs[2] - 1.0) < 1e-3 and abs(s * coeffs[3] - 1.73) < 0.15
+    assert inl.size > 2000
+
+
+def test_oracle_rejects_an_image_without_ground_labels():
+    cloud, img = _frame(6)
+    ref = make_oracle(capi.params_c0())
+    ref.set_cloud(cloud)
+    with pytest.raises(RuntimeError):
+        ref.estimate_semantic_plane(np.zeros_like(img), LABELS, 0.1)
+
+
+def test_oracle_fewer_than_four_candidates_returns_the_dummy_prior():
+    # three labelled points: the first fit returns (0,0,1,0) (optimizeModelCoefficients needs > 3 inliers), and the
+    # re-selection runs against that plane
+    cloud, img = _frame(7)
+    ref = make_oracle(capi.params_c0())
+    ref.set_cloud(cloud)
+    cam = ref.cloud_camera_cs().T
+    z = cam[:, 2]
+    u = np.trunc(cam[:, 0] / z * synth.KITTI_F + synth.KITTI_CU)
+    v = np.trunc(cam[:, 1] / z * synth.KITTI_F + synth.KITTI_CV)
+    ok = np.nonzero((z > 1) & (u >= 0) & (u < synth.KITTI_W) & (v >= 0) & (v < synth.KITTI_H))[0]
+    img2 = np.zeros_like(img)
+    px = set()
+    for i in ok:
+        key = (int(v[i]), int(u[i]))
+        if key not in px:
+            px.add(key)
+            img2[key] = 7
+        if len(px) == 3:
+            break
+    cand, c1, inl_np, c2 = np_restatement.semantic_plane(cloud, synth.T_CAM_LIDAR, synth.KITTI_F, synth.KITTI_CU,
+                                                         synth.KITTI_CV, img2, LABELS, 0.1)
+    if cand.size == 3:  # several points may share the three pixels
+        assert np.array_equal(c1, np.array([0, 0, 1, 0], dtype=np.float32))
+    coeffs, inl = ref.estimate_semantic_plane(img2, LABELS, 0.1)
+    assert np.array_equal(inl, inl_np)
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,thr,scanner", [(3, 0.1, synth.HDL64_KITTI), (4, 0.3, synth.HDL64), (5, 0.05, synth.VLP16)])
+def test_hip_matches_oracle(seed, thr, scanner):
+    cloud, img = _frame(seed, scanner)
+    _, coeffs, inl = _oracle_plane(cloud, img, thr)
+    est = make_estimator(capi.params_c0())
+    est.setInputCloud(cloud, None, plane_given=False)
+    c_hip, n_hip = est.estimateSemanticPlane(img, LABELS, thr)
+    assert np.array_equal(c_hip, coeffs)
+    assert n_hip == inl.size
+    assert np.array_equal(est.getGroundPlaneInliers(), inl)
+
+
+@pytest.mark.gpu
+def test_hip_device_image_and_strided_rows():
+    import torch
+    cloud, img = _frame(8)
+    wide = np.zeros((img.shape[0], img.shape[1] + 38), dtype=np.uint8)
+    wide[:, :img.shape[1]] = img
+    view = wide[:, :img.shape[1]]  # row stride > cols
+    _, coeffs, inl = _oracle_plane(cloud, np.ascontiguousarray(view), 0.1)
+    est = make_estimator(capi.params_c0())
+    est.setInputCloud(cloud, None, plane_given=False)
+    t = torch.from_numpy(wide).cuda()[:, :img.shape[1]]
+    c_hip, n_hip = est.estimateSemanticPlane(t, LABELS, 0.1)
+    assert np.array_equal(c_hip, coeffs) and n_hip == inl.size
+
+
+@pytest.mark.gpu
+def test_hip_rejects_an_image_without_ground_labels():
+    from mono_lidar_depth_amd import ExceptionPclInvalid
+    cloud, img = _frame(9)
+    est = make_estimator(capi.params_c0())
+    est.setInputCloud(cloud, None, plane_given=False)
+    with pytest.raises(ExceptionPclInvalid):
+        est.estimateSemanticPlane(np.zeros_like(img), LABELS, 0.1)
+
+
+@pytest.mark.gpu
+def test_depths_with_a_semantic_plane_match_the_oracle():
+    P = capi.params_c0()
+    cloud, img = _frame(10)
+    uv = synth.make_features(1500, seed=10)
+    ref, coeffs, inl = _oracle_plane(cloud, img, P.ransac_plane_refinement_treshold)
+    d0, t0 = ref.calculate_depth(uv)
+    est = make_estimator(P)
+    gp = SemanticPlane(img, LABELS, P.ransac_plane_refinement_treshold)
+    d, t = est.CalculateDepth(cloud, uv, gp)
+    assert gp.isSegmented() and np.array_equal(gp.getModelCoeffs(), coeffs)
+    assert_depth_parity(d, t, d0, t0)
+    assert (t0 == 16).sum() > 50

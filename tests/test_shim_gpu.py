@@ -51,3 +51,7 @@ def test_cpp_shim_matches_oracle(tmp_path, with_plane):
     assert n_interp == n_valid == int((d0 >= 0).sum())
     assert n_plane == (np.unique(inl).size if with_plane else 0)
     assert n_nb == 0 and n_cam == cloud.shape[0]
+    if with_plane:
+        m = re.search(r"semantic segmented (\d+) inliers (\d+) nz (\S+)", r.stdout)
+        assert m, r.stdout
+        assert int(m.group(1)) == 1 and int(m.group(2)) > 1000 and abs(abs(float(m.group(3))) - 1.0) < 0.05

@@ -66,3 +66,31 @@ def test_tracklet_module_sequence(scanner, n_tracks):
         h = mod.tracklet(int(ids[i_new]))
         assert len(h) == 2 and h[0][:2] == (int(u0[i_new]), int(v0[i_new])) and h[1][:2] == (int(u1[i_new]), int(v1[i_new]))
         ids_prev, ref_last = ids, ref_cur
+
+
+def test_tracklet_module_with_semantic_image():
+    """The 4-argument process overload (tracklet_depth_module.cpp:261-284): per-frame SemanticPlane from a label image,
+    the previous frame's semantic plane kept with its slot."""
+    P = capi.params_c0()
+    cam = kitti_camera()
+    mod = TrackletDepthModule(P, cam, synth.T_CAM_LIDAR)
+    rng = np.random.default_rng(5)
+    ids_prev, ref_last, known = None, None, set()
+    for frame in range(3):
+        cloud = synth.make_cloud(synth.HDL64_KITTI, seed=15, frame=frame * 2)
+        img = synth.make_label_image(cloud)
+        ids, u0, v0, u1, v1 = _tracks(rng, ids_prev, 2000, 0.10, cam.width, cam.height)
+        d_cur, d_last, is_new = mod.process(cloud, ids, u0, v0, u1, v1, None, img=img)
+        ref_cur = make_oracle(P)
+        ref_cur.set_cloud(cloud)
+        ref_cur.estimate_semantic_plane(img, (6, 7, 8, 9), P.ransac_plane_refinement_treshold)
+        exp_new = np.array([int(i) not in known for i in ids])
+        e_cur, e_last, et_cur, et_last = oracle.tracklets_depth(ref_cur, ref_last, u0, v0, u1, v1, exp_new, n_threads=8)
+        t_cur, t_last = mod.last_types
+        assert np.array_equal(t_cur, et_cur)
+        assert np.allclose(d_cur, e_cur, rtol=0, atol=1e-4, equal_nan=True)
+        assert np.array_equal(t_last[is_new], et_last[is_new])
+        assert np.allclose(d_last[is_new], e_last[is_new], rtol=0, atol=1e-4, equal_nan=True)
+        assert (t_cur == 16).sum() > 20
+        known = set(int(i) for i in ids)
+        ids_prev, ref_last = ids, ref_cur
