@@ -42,6 +42,8 @@ def parse_args():
     ap.add_argument("--unique-frames", type=int, default=16, help="distinct synthetic clouds generated per rank")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--latency-frames", type=int, default=200,
+                    help="frames of the one-frame-per-call host-pointer leg (PCIe-inclusive latency; 0 = skip)")
     ap.add_argument("--stat-slots", type=int, default=4, help="slots sampled for the algorithmic-byte statistics")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-every", type=int, default=4,
@@ -95,6 +97,36 @@ def cpu_baseline(P, cam_struct, T, clouds, planes, uvs, seconds):
                    f"{1e3 * t_a / frames:.2f} ms/frame, stage B (feature loop, {cores} OpenMP threads = fastest of "
                    f"{sorted(probe)} probed on {avail} available cores) {1e3 * t_b / frames:.2f} ms/frame"),
         "ms_per_frame": 1e3 * el / frames,
+        # the same path with a single-thread feature loop (stage A is serial in the reference anyway)
+        "one_thread": {"value": F / (t_a / frames + probe[1]), "ms_per_frame": 1e3 * (t_a / frames + probe[1])},
+        "stage_a_ms": 1e3 * t_a / frames,
+        "stage_b_ms": 1e3 * t_b / frames,
+    }
+
+
+def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
+    """One frame per call through the host-pointer entry points (the reference's ROS usage): H2D of the cloud, the
+    plane's inlier list and the features, kernels, D2H of depths/types, synchronise.  PCIe-inclusive; reported beside
+    the resident-throughput `value`, never as it."""
+    from mono_lidar_depth_amd import DepthEstimator, GroundPlane
+    est = DepthEstimator(device=device, max_points=clouds[0].shape[0], max_features=uvs[0].shape[0])
+    est.InitConfig(P)
+    est.Initialize(cam, T)
+    ts = []
+    for it in range(n_frames + 10):
+        i = it % len(clouds)
+        t0 = time.perf_counter()
+        est.CalculateDepth(clouds[i], uvs[i], GroundPlane(*planes[i]))
+        ts.append(time.perf_counter() - t0)
+    est.close()
+    ts = np.array(ts[10:]) * 1e3
+    return {
+        "path": "host pointers, one frame per call: setInputCloud (H2D 2.1 MB) + ground plane (inlier list H2D) + "
+                "CalculateDepth (uv H2D, kernels, depth/type D2H, sync)",
+        "frames": int(n_frames),
+        "ms_per_frame_median": float(np.median(ts)),
+        "ms_per_frame_p99": float(np.percentile(ts, 99)),
+        "associations_per_s": float(uvs[0].shape[0] / np.median(ts) * 1e3),
     }
 
 
@@ -283,6 +315,10 @@ def main():
     if world == 1 and args.cpu_seconds > 0:
         cpu = cpu_baseline(P, cam_struct, T, clouds_h, planes_h, uvs_h, args.cpu_seconds)
 
+    latency = None
+    if world == 1 and args.latency_frames > 0:
+        latency = latency_leg(P, cam, T, clouds_h, planes_h, uvs_h, args.latency_frames, local_rank)
+
     value = units / elapsed
     out = {
         "metric": "feature-depth associations/sec",
@@ -315,6 +351,7 @@ def main():
                         ("n_visible", "k1_mean", "k2_mean_fallback", "fallback_features")},
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "latency": latency,
     }
     print(json.dumps(out))
     if world > 1:
