@@ -205,7 +205,7 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     c.cvf = (float)c.cv;
     c.W = ctx->cam.width;
     c.H = ctx->cam.height;
-    c.bmStride = (ctx->cam.width + 31) / 32 + 2;
+    c.bmStride = (ctx->cam.height + 16 + 3) / 4 * 4;  // words per 32-pixel column: H rows + 16 rows of read slack
     // NeighborFinderPixel.cpp:67-68, scales (1,1) and (2.0f,1.5f) (DepthEstimator.cpp:509,585)
     c.halfX1 = (double)P.pixelarea_search_witdh * 0.5 * (double)1.0f;
     c.halfY1 = (double)P.pixelarea_search_height * 0.5 * (double)1.0f;
@@ -620,7 +620,7 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if ((e = hipMalloc((void**)&ctx->d_slots, sizeof(SlotDesc) * max_frames)) != hipSuccess)
         return hip_bail(e, "hipMalloc(slots)");
     size_t cells = (size_t)camera->width * camera->height + kMapPadCells;
-    ctx->bitmap_words = (size_t)ctx->calib.bmStride * (size_t)camera->height + 2;
+    ctx->bitmap_words = (size_t)ctx->calib.bmStride * (size_t)((camera->width + 31) / 32 + 1) + 4;  // + a slack column
     // one allocation: [queue lengths: max_frames road fallback + max_frames long-list overflow][bitmaps of the slots]
     const size_t cnt_words = 2 * (size_t)max_frames;
     if ((e = hipMalloc((void**)&ctx->road_counts, (cnt_words + ctx->bitmap_words * (size_t)max_frames) * sizeof(uint32_t))) != hipSuccess)

@@ -40,7 +40,7 @@ struct Calib {
     int useRoad;   // do_use_ransac_plane
     int roadMode;  // 0 = M-estimator, 1 = max spanning triangle
     int usePCA;
-    int bmStride;    // words per row of the occupancy bitmap: ceil(W/32) + 2 (8-byte reads never overrun a row)
+    int bmStride;    // words per 32-pixel column of the occupancy bitmap (word = (x >> 5) * bmStride + y): H + slack
     int k1max;       // thread path: neighbour list capacity per feature (entries in LDS)
     int splitRoad;   // 1: the thread path queues road-fallback candidates for k_feature_road instead of running them inline
     int xcdAware;    // 1: blocks of one slot are congruent mod 8 (same XCD under round-robin dispatch)
@@ -51,7 +51,7 @@ struct Calib {
 struct SlotDesc {
     const unsigned char* cloud;   // float32 records, `stride` bytes apart (x,y,z first)
     uint32_t* map;                // W*H keys
-    uint32_t* bitmap;             // occupancy bits of the map, bmStride words per image row (cleared per cloud)
+    uint32_t* bitmap;             // occupancy bits of the map, column-of-words layout (cleared per cloud)
     const double* uv;             // 2 x F column-major
     double* depth;                // F
     int32_t* type;                // F or nullptr

@@ -28,6 +28,7 @@ namespace mld {
 #define GPTR(T, p) ((const T __attribute__((address_space(1)))*)(p))
 #define GPTRW(T, p) ((T __attribute__((address_space(1)))*)(p))
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
 
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
             uint32_t key = (s.tag << kIdxBits) | (kIdxMask - (uint32_t)i);
             __hip_atomic_fetch_max(GPTRW(uint32_t, s.map) + ((size_t)xi + (size_t)yi * (size_t)c.W), key,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bmw[r] = yi * c.bmStride + (xi >> 5);
+            bmw[r] = (xi >> 5) * c.bmStride + yi;
             bmb[r] = 1u << (xi & 31);
         }
     }
@@ -1023,6 +1024,14 @@ constexpr int kK1MaxLimit = 64;  // upper bound of Calib::k1max, the per-feature
 constexpr int kK2Max = 16;  // longest list the per-thread O(n^2) triangle search accepts
 constexpr int kTriSmall = 8;
 constexpr int kZc = 12;      // list entries whose depth stays in registers over the histogram passes
+#ifndef MLD_KEY_BATCH
+#define MLD_KEY_BATCH 4
+#endif
+#ifndef MLD_ROAD_BATCH
+#define MLD_ROAD_BATCH 4
+#endif
+constexpr int kKeyBatch = MLD_KEY_BATCH;    // map keys fetched per round trip when cells become point indices
+constexpr int kRoadBatch = MLD_ROAD_BATCH;  // wide-window neighbours fetched per round trip by the road fallback
 constexpr int kBatch = 4;    // list entries fetched ahead of use in the per-lane list loops  // lists up to this length use the fully unrolled in-register triangle search
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -1078,25 +1087,36 @@ __device__ __forceinline__ int scan_window_bitmap(const Calib& c, const SlotDesc
     const auto* bm = GPTR(uint32_t, s.bitmap);
     const unsigned long long colmask = (nx >= 64) ? ~0ull : ((1ull << nx) - 1ull);
     int k = 0;
-    for (int r0 = 0; r0 < nymax; r0 += 4) {
-        unsigned long long bits[4];
+    // The bitmap stores one column of 32 pixels contiguously (word = (x >> 5) * bmStride + y), so the rows of a
+    // window are consecutive words: four rows per 16-byte load, from the two word columns the window can straddle.
+    const auto* col0 = bm + (size_t)(x0 >> 5) * (size_t)c.bmStride + (size_t)y0;
+    const auto* col1 = col0 + c.bmStride;
+    const int sh = x0 & 31;
+    for (int r0 = 0; r0 < nymax; r0 += 8) {
+        u32x4u a[2], b2[2];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const bool rowok = (r0 + q) < ny;
-            const size_t w = (size_t)(y0 + (rowok ? (r0 + q) : 0)) * (size_t)c.bmStride + (size_t)(x0 >> 5);
-            unsigned long long v = 0;
-            if (rowok) v = (unsigned long long)bm[w] | ((unsigned long long)bm[w + 1] << 32);
-            bits[q] = (v >> (x0 & 31)) & colmask;
+        for (int g = 0; g < 2; g++) {
+            a[g] = u32x4u{0u, 0u, 0u, 0u};
+            b2[g] = u32x4u{0u, 0u, 0u, 0u};
+            if (r0 + 4 * g < nymax) {  // wave-uniform
+                if (r0 + 4 * g < ny) {
+                    a[g] = *GPTR(u32x4u, col0 + r0 + 4 * g);
+                    b2[g] = *GPTR(u32x4u, col1 + r0 + 4 * g);
+                }
+            }
         }
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            unsigned long long b = bits[q];
-            const uint32_t rowbase = (uint32_t)((y0 + r0 + q) * c.W + x0);
-            while (b) {
-                const int col = __ffsll((long long)b) - 1;
-                b &= b - 1;
-                if (k < c.k1max) LST(k) = rowbase + (uint32_t)col;
-                k++;
+        for (int q = 0; q < 8; q++) {
+            if (r0 + q < nymax) {
+                const unsigned long long v = ((unsigned long long)b2[q >> 2][q & 3] << 32) | (unsigned long long)a[q >> 2][q & 3];
+                unsigned long long b = ((r0 + q) < ny) ? ((v >> sh) & colmask) : 0ull;
+                const uint32_t rowbase = (uint32_t)((y0 + r0 + q) * c.W + x0);
+                while (b) {
+                    const int col = __ffsll((long long)b) - 1;
+                    b &= b - 1;
+                    if (k < c.k1max) LST(k) = rowbase + (uint32_t)col;
+                    k++;
+                }
             }
         }
     }
@@ -1104,12 +1124,12 @@ __device__ __forceinline__ int scan_window_bitmap(const Calib& c, const SlotDesc
     const int kk = k <= c.k1max ? k : 0;  // overflowing lists (k > k1max) are redone by the wave path
     const int kmax = uniform(wave_max_i32(kk));
     const auto* mp = GPTR(uint32_t, s.map);
-    for (int e0 = 0; e0 < kmax; e0 += kBatch) {
-        uint32_t key[kBatch];
+    for (int e0 = 0; e0 < kmax; e0 += kKeyBatch) {
+        uint32_t key[kKeyBatch];
 #pragma unroll
-        for (int q = 0; q < kBatch; q++) key[q] = (e0 + q < kk) ? mp[LST(min(e0 + q, c.k1max - 1))] : 0u;
+        for (int q = 0; q < kKeyBatch; q++) key[q] = (e0 + q < kk) ? mp[LST(min(e0 + q, c.k1max - 1))] : 0u;
 #pragma unroll
-        for (int q = 0; q < kBatch; q++)
+        for (int q = 0; q < kKeyBatch; q++)
             if (e0 + q < kk) LST(e0 + q) = kIdxMask - (key[q] & kIdxMask);
     }
     return k;
@@ -1322,17 +1342,17 @@ __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, u
     double sw = 0, mx = 0, my = 0, mz = 0;
     double q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
     const V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
-    for (int e0 = 0; e0 < n2max; e0 += kBatch) {
-        RawP rp[kBatch];
-        uint32_t ids[kBatch], mw[kBatch];
+    for (int e0 = 0; e0 < n2max; e0 += kRoadBatch) {
+        RawP rp[kRoadBatch];
+        uint32_t ids[kRoadBatch], mw[kRoadBatch];
 #pragma unroll
-        for (int q = 0; q < kBatch; q++) {
+        for (int q = 0; q < kRoadBatch; q++) {
             ids[q] = LST_ID(e0 + q, n2);
             rp[q] = load_raw(s, ids[q]);
             mw[q] = GPTR(uint32_t, s.inlier_mask)[ids[q] >> 5];
         }
 #pragma unroll
-        for (int q = 0; q < kBatch; q++) {
+        for (int q = 0; q < kRoadBatch; q++) {
           if (e0 + q < n2) {
             const uint32_t id = ids[q];
             V3 p = raw_point(c, rp[q]);
