@@ -282,7 +282,7 @@ def main():
     # are the "+ 4*P2 + 25*k2" terms of the per-feature formula
     road_bytes = float(np.mean([s["road_bytes"] for s in stats])) * S
     main_bytes = feat_bytes - road_bytes if n_road else feat_bytes
-    cand = {"k_project_scatter": (k_proj_ms, proj_bytes), "k_feature_depth": (k_feat_ms, main_bytes)}
+    cand = {"k_project_scatter": (k_proj_ms, proj_bytes), "k_feature_main": (k_feat_ms, main_bytes)}
     if n_road:
         cand["k_feature_road"] = (k_road_ms, road_bytes)
     dominant = max(cand, key=lambda k: cand[k][0])
@@ -301,7 +301,7 @@ def main():
         "kernels": {
             "k_project_scatter": {"avg_ms": k_proj_ms, "launches": n_proj, "algorithmic_bytes_per_launch": proj_bytes,
                                   "GBps": (proj_bytes / (k_proj_ms * 1e-3)) / 1e9 if k_proj_ms > 0 else 0.0},
-            "k_feature_depth": {"avg_ms": k_feat_ms, "launches": n_feat, "algorithmic_bytes_per_launch": main_bytes,
+            "k_feature_main": {"avg_ms": k_feat_ms, "launches": n_feat, "algorithmic_bytes_per_launch": main_bytes,
                                 "GBps": (main_bytes / (k_feat_ms * 1e-3)) / 1e9 if k_feat_ms > 0 else 0.0},
             "k_feature_road": {"avg_ms": k_road_ms, "launches": n_road, "algorithmic_bytes_per_launch": road_bytes,
                                "GBps": (road_bytes / (k_road_ms * 1e-3)) / 1e9 if k_road_ms > 0 else 0.0},

@@ -77,6 +77,7 @@ struct mld_ctx {
     std::vector<SlotDesc> h_descs;
     size_t lds_bytes = 0;
     size_t lds_main = 0;  // k_feature_main: four per-wave index lists + the dealing table
+    int k_main = 24;      // list capacity of k_feature_main (narrow window); the road kernel keeps calib.k1max
     std::string err;
     // ground-plane estimation scratch (device)
     int32_t* rs_flags = nullptr;
@@ -256,7 +257,13 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     if (const char* k = std::getenv("MLD_K1MAX")) k1max = std::atoi(k);
     c.k1max = std::min(std::max(k1max, 8), kK1MaxLimit);
     if (c.threadPath) ctx->lds_bytes = std::max(ctx->lds_bytes, (size_t)c.k1max * kWave * sizeof(uint32_t));
-    ctx->lds_main = (size_t)(kMainThreads / kWave) * c.k1max * kWave * sizeof(uint32_t) + kMainThreads * sizeof(uint32_t) + 64;
+    // the narrow window rarely holds more than two dozen points, and k_feature_main's residency is bounded by its LDS
+    // (blocks keep their lists while the dealt wavefronts finish): a smaller capacity there lets more blocks in.
+    // MLD_KMAIN overrides (8..k1max).
+    int k_main = 24;
+    if (const char* k = std::getenv("MLD_KMAIN")) k_main = std::atoi(k);
+    ctx->k_main = std::min(std::max(k_main, 8), c.k1max);
+    ctx->lds_main = (size_t)(kMainThreads / kWave) * ctx->k_main * kWave * sizeof(uint32_t) + kMainThreads * sizeof(uint32_t) + 64;
 }
 
 int check_slot(mld_ctx* ctx, int slot) {
@@ -395,12 +402,14 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         if (split) {
             // 256 features per block; the block re-deals its live features to dense wavefronts
             const int pm = (int)((max_F + kMainThreads - 1) / kMainThreads);
+            Calib cm = calib;
+            cm.k1max = ctx->k_main;
             if (single) {
                 hipLaunchKernelGGL(k_feature_main, dim3(pm), dim3(kMainThreads), ctx->lds_main, ctx->stream, ctx->d_slots,
-                                   ctx->slots[slot].d, 1, calib, 1, pm, 0u);
+                                   ctx->slots[slot].d, 1, cm, 1, pm, 0u);
             } else {
                 hipLaunchKernelGGL(k_feature_main, dim3((unsigned)pm * n_slots), dim3(kMainThreads), ctx->lds_main,
-                                   ctx->stream, ctx->d_slots, SlotDesc{}, 0, calib, n_slots, pm, tag_all);
+                                   ctx->stream, ctx->d_slots, SlotDesc{}, 0, cm, n_slots, pm, tag_all);
             }
         } else if (single) {
             hipLaunchKernelGGL(k_feature_depth<false>, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream,

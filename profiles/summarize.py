@@ -46,7 +46,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
     if not f_:
         continue
     df = pd.read_csv(f_)
-    df = df[df.Kernel_Name.str.contains("k_feature_depth|k_project_scatter|k_feature_road|k_feature_wave")]
+    df = df[df.Kernel_Name.str.contains("k_feature_main|k_feature_depth|k_project_scatter|k_feature_road|k_feature_wave")]
     df["k"] = df.Kernel_Name.str.extract(r"(k_\w+)")
     g = df.groupby(["k", "Counter_Name"]).Counter_Value.mean()
     for (k, c), v in g.items():
@@ -54,7 +54,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
         lines.append(f"| `{k}` | {c} | {v:,.1f} |")
 lines += ["", "## derived", ""]
 traffic = {}
-for k in ("k_project_scatter", "k_feature_depth", "k_feature_road"):
+for k in ("k_project_scatter", "k_feature_main", "k_feature_road"):
     if (k, "FETCH_SIZE") in rows and (k, "WRITE_SIZE") in rows:
         f, w = rows[(k, "FETCH_SIZE")] * 1024, rows[(k, "WRITE_SIZE")] * 1024
         fc = 2 * f if k == "k_project_scatter" else f
