@@ -1,0 +1,123 @@
+"""Randomised configurations: random parameter sets, cameras and lidar->camera transforms (seeded), HIP against the
+oracle.  Catches assumptions that the fixed KITTI-like set-up of the other tests would hide (image size, rotated
+mounting, window sizes, every mode combination)."""
+import numpy as np
+import pytest
+
+from mono_lidar_depth_amd import CameraPinhole, GroundPlane, capi, synth
+
+from helpers import assert_depth_parity, make_estimator, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _rot(rx, ry, rz):
+    cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx
+
+
+def _random_setup(seed):
+    rng = np.random.default_rng(9100 + seed)
+    pick = lambda *a: a[int(rng.integers(len(a)))]  # noqa: E731
+    road_tri = rng.random() < 0.3
+    kw = dict(
+        pixelarea_search_witdh=int(rng.integers(2, 15)), pixelarea_search_height=int(rng.integers(2, 15)),
+        radiusSearch_count_min=int(rng.integers(1, 5)),
+        do_use_histogram_segmentation=int(rng.random() < 0.7),
+        histogram_segmentation_bin_witdh=pick(0.1, 0.3, 1.0), histogram_segmentation_min_pointcount=int(rng.integers(1, 5)),
+        treshold_depth_enabled=int(rng.random() < 0.8), treshold_depth_mode=int(rng.integers(0, 2)),
+        treshold_depth_min=int(rng.integers(0, 6)), treshold_depth_max=int(rng.integers(30, 101)),
+        treshold_depth_local_enabled=int(rng.random() < 0.8), treshold_depth_local_mode=int(rng.integers(0, 2)),
+        treshold_depth_local_valuetype=int(rng.integers(0, 2)), treshold_depth_local_value=pick(0.1, 0.5, 1.0),
+        do_use_PCA=int(rng.random() < 0.15),
+        do_use_triangle_size_maximation=int(rng.random() < 0.8),
+        do_check_triangleplanar_condition=int(rng.random() < 0.8), triangleplanar_crossnorm_treshold=pick(0.05, 0.1, 0.3),
+        viewray_plane_orthoganality_treshold=pick(0.0, 0.03, 0.2),
+        do_use_cut_behind_camera=int(rng.random() < 0.8),
+        do_use_ransac_plane=int(rng.random() < 0.85),
+        plane_estimator_use_triangle_maximation=int(road_tri), plane_estimator_use_mestimator=int(not road_tri),
+        plane_estimator_z_x_min_relation=pick(0.0, 0.2), ransac_plane_point_distance_treshold=pick(0.1, 0.2, 0.5),
+    )
+    P = capi.params_c0().replace(**kw)
+    W, H = pick((640, 480), (1242, 375), (1920, 1080), (800, 300))
+    f = float(rng.uniform(0.45, 1.1) * W)
+    cam = CameraPinhole(W, H, f, W / 2 + float(rng.uniform(-20, 20)), H / 2 + float(rng.uniform(-20, 20)))
+    base = synth.T_CAM_LIDAR[:, :3]
+    R = _rot(*np.deg2rad(rng.uniform(-6, 6, 3))) @ base
+    t = synth.T_CAM_LIDAR[:, 3] + rng.uniform(-0.3, 0.3, 3)
+    T = np.concatenate([R, t[:, None]], axis=1)
+    scanner = pick(synth.HDL64_KITTI, synth.VLP16, synth.HDL64)
+    return P, cam, T, scanner, kw
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_configuration(seed):
+    P, cam, T, scanner, kw = _random_setup(seed)
+    cloud = synth.make_cloud(scanner, seed=200 + seed, frame=seed % 5)
+    uv = synth.make_features(900, seed=300 + seed, width=cam.width, height=cam.height)
+    plane = synth.make_ground_plane(cloud)
+    est = make_estimator(P, camera=cam, T=T)
+    d, t = est.CalculateDepth(cloud, uv, GroundPlane(*plane))
+    _, (d0, t0) = run_oracle(P, cloud, uv, plane, camera=cam, T=T)
+    assert_depth_parity(d, t, d0, t0, exact_main=not P.do_use_PCA)
+    # visible bookkeeping is integer work: bit-exact for any camera / transform
+    ref, _ = run_oracle(P, cloud, uv[:1], plane, camera=cam, T=T)
+    assert np.array_equal(est.getPointIndex(), ref.point_index()), kw
+    assert np.array_equal(est.getPixelMap(), ref.pixel_map()), kw
+
+
+def test_cloud_with_non_finite_and_duplicate_points():
+    """NaN / inf coordinates, exact duplicates (pixel collisions: the first index must win), points on the camera plane
+    and behind it, inside an otherwise normal cloud."""
+    P = capi.params_c0()
+    cloud = synth.make_cloud(synth.HDL64_KITTI, seed=71, frame=1).copy()
+    rng = np.random.default_rng(71)
+    n = cloud.shape[0]
+    bad = rng.choice(n, 600, replace=False)
+    cloud[bad[:150], 0] = np.nan
+    cloud[bad[150:300], 1] = np.inf
+    cloud[bad[300:450], 2] = -np.inf
+    cloud[bad[450:500]] = 0.0                       # at the lidar origin
+    cloud[bad[500:550], 0] = 0.27                   # z_cam == 0 for the synthetic mounting
+    dup_src = rng.choice(n, 3000, replace=False)
+    dup_dst = rng.choice(n, 3000, replace=False)
+    cloud[dup_dst] = cloud[dup_src]
+    uv = synth.make_features(1500, seed=71)
+    plane = synth.make_ground_plane(cloud)
+    est = make_estimator(P)
+    d, t = est.CalculateDepth(cloud, uv, GroundPlane(*plane))
+    ref, (d0, t0) = run_oracle(P, cloud, uv, plane)
+    assert_depth_parity(d, t, d0, t0)
+    assert np.array_equal(est.getPointIndex(), ref.point_index())
+    assert np.array_equal(est.getPixelMap(), ref.pixel_map())
+
+
+def test_cloud_size_limit():
+    """24-bit point index in the pixel-map key: 16 777 215 points are accepted, one more is a capacity error."""
+    import torch
+    from mono_lidar_depth_amd import DepthEstimatorError
+    P = capi.params_c0().replace(do_use_ransac_plane=0)
+    est = make_estimator(P)
+    n_max = (1 << 24) - 1
+    big = torch.zeros((n_max + 1, 4), dtype=torch.float32, device="cuda:0")
+    # a handful of real points at the very end of the largest legal cloud: the highest indices must round-trip
+    tail = torch.from_numpy(synth.make_cloud(synth.VLP16, seed=5)[:20000]).to("cuda:0")
+    big[n_max - tail.shape[0]:n_max] = tail
+    torch.cuda.synchronize()
+    with pytest.raises(DepthEstimatorError) as ei:
+        est.setInputCloud(big, None, plane_given=False)
+    assert ei.value.code == capi.MLD_ERR_CAPACITY
+    est.setInputCloud(big[:n_max], None, plane_given=False)
+    pidx = est.getPointIndex()
+    small = make_estimator(P)
+    small.setInputCloud(tail, None, plane_given=False)
+    # the zero points in front project nowhere (z_cam <= 0 after the mounting offset), so the visible set is the tail's
+    assert np.array_equal(pidx - (n_max - tail.shape[0]), small.getPointIndex())
+    uv = synth.make_features(500, seed=5)
+    uvd = torch.from_numpy(uv).to("cuda:0")
+    d_big, t_big = est.CalculateDepth(uvd)
+    d_small, t_small = small.CalculateDepth(uvd)
+    assert torch.equal(t_big, t_small) and torch.equal(d_big, d_small)
