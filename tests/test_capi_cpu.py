@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, f"libmld_hip.so lacks: {missing}"
     assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
-    assert lib.mld_abi_version() == 3
+    assert lib.mld_abi_version() == capi.MLD_ABI_VERSION == 3
 
 
 def test_struct_layout_matches_header():
@@ -126,3 +126,11 @@ def test_product_package_never_imports_the_oracle():
         if path.suffix in (".py", ".hip", ".cpp", ".h", ".hpp") and path.is_file():
             text = path.read_text()
             assert "oracle" not in text.replace("TEST INFRASTRUCTURE", ""), f"{path} mentions the oracle"
+
+
+def test_abi_version_constant_matches_the_header():
+    import re
+    from pathlib import Path
+    hdr = (Path(__file__).resolve().parent.parent / "include" / "mld.h").read_text()
+    assert int(re.search(r"#define\s+MLD_ABI_VERSION\s+(\d+)", hdr).group(1)) == capi.MLD_ABI_VERSION
+    assert capi.load().mld_abi_version() == capi.MLD_ABI_VERSION
