@@ -44,6 +44,9 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--latency-frames", type=int, default=200,
                     help="frames of the one-frame-per-call host-pointer leg (PCIe-inclusive latency; 0 = skip)")
+    ap.add_argument("--streaming-batches", type=int, default=24,
+                    help="batches of the pipelined host->device leg (PCIe-inclusive throughput; 0 = skip)")
+    ap.add_argument("--streaming-frames", type=int, default=64, help="frames per batch of the streaming leg")
     ap.add_argument("--stat-slots", type=int, default=4, help="slots sampled for the algorithmic-byte statistics")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-every", type=int, default=4,
@@ -127,6 +130,97 @@ def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
         "ms_per_frame_median": float(np.median(ts)),
         "ms_per_frame_p99": float(np.percentile(ts, 99)),
         "associations_per_s": float(uvs[0].shape[0] / np.median(ts) * 1e3),
+    }
+
+
+def streaming_leg(P, cam, T, clouds, planes, uvs, device, frames_per_batch, n_batches):
+    """Frames streamed from pinned host memory: double-buffered H2D copies on a copy stream overlapped with the kernels
+    on the context's stream, results copied back.  PCIe-inclusive THROUGHPUT (the latency leg is the unpipelined
+    counterpart); reported beside `value`, never as it."""
+    import torch
+    from mono_lidar_depth_amd import DepthEstimator
+    dev = torch.device("cuda", device)
+    S, N, F = frames_per_batch, clouds[0].shape[0], uvs[0].shape[0]
+    U = len(clouds)
+    words = (N + 31) // 32
+
+    def mask_of(inl):
+        m = np.zeros(words, dtype=np.uint32)
+        np.bitwise_or.at(m, inl >> 5, (np.uint32(1) << (inl & 31).astype(np.uint32)))
+        return m.view(np.int32)
+
+    # pinned host batch (what a driver thread would fill from the sensor queue) and two device buffer sets
+    h_cloud = torch.empty((S, N, 4), dtype=torch.float32).pin_memory()
+    h_mask = torch.empty((S, words), dtype=torch.int32).pin_memory()
+    h_uv = torch.empty((S, F, 2), dtype=torch.float64).pin_memory()
+    coeffs = np.empty((S, 4), dtype=np.float32)
+    for b in range(S):
+        h_cloud[b] = torch.from_numpy(clouds[b % U])
+        h_mask[b] = torch.from_numpy(mask_of(planes[b % U][1]))
+        h_uv[b] = torch.from_numpy(uvs[b % len(uvs)])
+        coeffs[b] = planes[b % U][0]
+    h_depth = [torch.empty((S, F), dtype=torch.float64).pin_memory() for _ in range(2)]
+    h_type = [torch.empty((S, F), dtype=torch.int32).pin_memory() for _ in range(2)]
+    est = DepthEstimator(device=device, max_frames=S)
+    est.InitConfig(P)
+    est.Initialize(cam, T)
+    compute = torch.cuda.ExternalStream(est.stream, device=dev)
+    copy_in = torch.cuda.Stream(device=dev)
+    copy_out = torch.cuda.Stream(device=dev)
+    bufs, batches = [], []
+    for _ in range(2):
+        d = {"cloud": torch.empty((S, N, 4), dtype=torch.float32, device=dev),
+             "mask": torch.empty((S, words), dtype=torch.int32, device=dev),
+             "uv": torch.empty((S, F, 2), dtype=torch.float64, device=dev),
+             "depth": torch.empty((S, F), dtype=torch.float64, device=dev),
+             "type": torch.empty((S, F), dtype=torch.int32, device=dev)}
+        bufs.append(d)
+        batches.append(est.prepareBatch([d["cloud"][b] for b in range(S)], [d["uv"][b] for b in range(S)],
+                                        [d["depth"][b] for b in range(S)], [d["type"][b] for b in range(S)], coeffs,
+                                        [d["mask"][b] for b in range(S)]))
+    torch.cuda.synchronize()
+    copied = [None, None]
+    done = [None, None]
+
+    def submit(i):
+        k = i % 2
+        with torch.cuda.stream(copy_in):
+            if done[k] is not None:
+                copy_in.wait_event(done[k])  # the buffer set is free once its previous results are on the host
+            bufs[k]["cloud"].copy_(h_cloud, non_blocking=True)
+            bufs[k]["mask"].copy_(h_mask, non_blocking=True)
+            bufs[k]["uv"].copy_(h_uv, non_blocking=True)
+            copied[k] = copy_in.record_event()
+        compute.wait_event(copied[k])
+        est.runBatch(batches[k])
+        ev = torch.cuda.Event()
+        ev.record(compute)
+        # torch's allocators only ever see torch-owned streams (the context's stream is used for event traffic alone)
+        copy_out.wait_event(ev)
+        with torch.cuda.stream(copy_out):
+            h_depth[k].copy_(bufs[k]["depth"], non_blocking=True)
+            h_type[k].copy_(bufs[k]["type"], non_blocking=True)
+            done[k] = copy_out.record_event()
+
+    for i in range(2):
+        submit(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_batches):
+        submit(i)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    est.close()
+    frames = S * n_batches
+    h2d = frames * (N * 16 + words * 4 + F * 16)
+    return {
+        "path": "pinned host batches, double-buffered H2D on a copy stream overlapped with the kernels, depths/types "
+                "copied back",
+        "frames_per_batch": S, "batches": n_batches,
+        "frames_per_s": frames / el,
+        "associations_per_s": frames * F / el,
+        "ms_per_frame": 1e3 * el / frames,
+        "h2d_GBps": h2d / el / 1e9,
     }
 
 
@@ -324,6 +418,11 @@ def main():
     if world == 1 and args.latency_frames > 0:
         latency = latency_leg(P, cam, T, clouds_h, planes_h, uvs_h, args.latency_frames, local_rank)
 
+    streaming = None
+    if world == 1 and args.streaming_batches > 0:
+        streaming = streaming_leg(P, cam, T, clouds_h, planes_h, uvs_h, local_rank, args.streaming_frames,
+                                  args.streaming_batches)
+
     value = units / elapsed
     out = {
         "metric": "feature-depth associations/sec",
@@ -357,6 +456,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "latency": latency,
+        "streaming": streaming,
     }
     print(json.dumps(out))
     if world > 1:
