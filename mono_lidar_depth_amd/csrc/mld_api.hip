@@ -201,6 +201,11 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     c.cu = ctx->cam.principal_point_x;
     c.cv = ctx->cam.principal_point_y;
     for (int t = 0; t < 12; t++) c.Tf[t] = (float)T[t];
+    for (int r = 0; r < 3; r++) {
+        float m = 0.f;
+        for (int k = 0; k < 3; k++) m = std::max(m, std::fabs(c.Tf[4 * r + k]));
+        c.Tfmax[r] = m * 1.000001f;
+    }
     c.ff = (float)c.f;
     c.cuf = (float)c.cu;
     c.cvf = (float)c.cv;

@@ -19,6 +19,7 @@ struct Calib {
     double Kinv[9];   // inverse intrinsics, row-major
     double f, cu, cv;
     float Tf[12];           // single-precision copies for the conservative pre-cull of k_project_scatter
+    float Tfmax[3];  // max |Tf[r][0..2]| per row, rounded up (bounds of the f32 pre-cull)
     float ff, cuf, cvf;
     float padf_;
     double halfX1, halfY1;  // main search window half sizes  (scale 1.0, 1.0)

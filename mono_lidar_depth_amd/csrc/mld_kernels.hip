@@ -208,14 +208,16 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
         // within 1e-6 * S of its exact value, S being the sum of the absolute values of its terms; a point is
         // dropped only if it misses the image by more than 1e-5 * S, so no point the exact test would keep is lost.
         // NaN compares false: such points fall through to the exact path.
+        // (the sums S are bounded from above by rowmax * (|x|+|y|+|z|) + |t|: cheaper, still conservative)
         const float* T = c.Tf;
+        const float m1 = fabsf(x) + fabsf(y) + fabsf(z);
         const float zc = fmaf(T[8], x, fmaf(T[9], y, fmaf(T[10], z, T[11])));
-        const float sz = fabsf(T[8] * x) + fabsf(T[9] * y) + fabsf(T[10] * z) + fabsf(T[11]);
+        const float sz = fmaf(c.Tfmax[2], m1, fabsf(T[11]));
         if (zc < -1e-5f * sz) continue;
         const float xc = fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, T[3])));
         const float yc = fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, T[7])));
-        const float sx = fabsf(T[0] * x) + fabsf(T[1] * y) + fabsf(T[2] * z) + fabsf(T[3]);
-        const float sy = fabsf(T[4] * x) + fabsf(T[5] * y) + fabsf(T[6] * z) + fabsf(T[7]);
+        const float sx = fmaf(c.Tfmax[0], m1, fabsf(T[3]));
+        const float sy = fmaf(c.Tfmax[1], m1, fabsf(T[7]));
         const float qa = fmaf(c.ff, xc, c.cuf * zc), qb = fmaf(c.ff, yc, c.cvf * zc);  // ~ u*z, v*z
         const float ma = 1e-5f * (fabsf(c.ff) * sx + (fabsf(c.cuf) + Wf) * sz);
         const float mb = 1e-5f * (fabsf(c.ff) * sy + (fabsf(c.cvf) + Hf) * sz);
@@ -240,6 +242,13 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
     // word are OR-ed along the run and only the run's last lane issues the atomic (~10x fewer atomics).  Runs need
     // not be exact: every lane's bit reaches the last lane of its contiguous run (within its 16-lane row), which
     // always writes.
+    {
+        // three waves in four see no visible point at all (a 360-degree scan against an 81-degree camera)
+        uint32_t anyb = 0u;
+#pragma unroll
+        for (int r = 0; r < kProjPerThread; r++) anyb |= bmb[r];
+        if (!__any(anyb != 0u)) return;
+    }
 #pragma unroll
     for (int r = 0; r < kProjPerThread; r++) {
         int w = bmw[r];
