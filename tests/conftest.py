@@ -18,7 +18,14 @@ def _native_built():
     """Build libmld_hip.so / the oracle if they are missing (hipcc cross-compiles without a GPU)."""
     from mono_lidar_depth_amd import capi
     from oracle import oracle
-    if not capi.LIB_PATH.exists() or not oracle.LIB_PATH.exists():
+    stale = False
+    if capi.LIB_PATH.exists():
+        try:  # through capi.load(): torch's HIP runtime has to be in the process before this library
+            stale = capi.load().mld_abi_version() != capi.MLD_ABI_VERSION
+        except (OSError, AttributeError, RuntimeError):
+            stale = True
+    if stale or not capi.LIB_PATH.exists() or not oracle.LIB_PATH.exists():
         import __graft_entry__
         __graft_entry__.build()
+        capi._lib = None  # load the rebuilt library
     yield
