@@ -579,6 +579,12 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if (!params || !camera || !T_cam_lidar) return bail(MLD_ERR_INVALID_ARG, "null argument");
     if (max_frames < 1) return bail(MLD_ERR_INVALID_ARG, "max_frames must be >= 1");
     if (camera->width < 1 || camera->height < 1) return bail(MLD_ERR_INVALID_ARG, "bad image size");
+    // a singular or non-finite intrinsic matrix has no inverse (camera_pinhole.h:65 would produce NaN rays)
+    if (!std::isfinite(camera->focal_length) || camera->focal_length == 0.0 || !std::isfinite(camera->principal_point_x) ||
+        !std::isfinite(camera->principal_point_y))
+        return bail(MLD_ERR_INVALID_ARG, "bad camera intrinsics");
+    for (int t = 0; t < 12; t++)
+        if (!std::isfinite(T_cam_lidar[t])) return bail(MLD_ERR_INVALID_ARG, "non-finite lidar->camera transform");
     if (max_points > kMaxPoints) return bail(MLD_ERR_CAPACITY, "max_points exceeds 16 777 215");
     std::string why;
     int v = validate_params(*params, why);
