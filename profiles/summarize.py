@@ -21,7 +21,7 @@ stats = newest(f"{src}/trace/*/*kernel_stats.csv")
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 lines = [f"# rocprofv3 summary — {tag}", "",
          "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 "
-         "--cpu-seconds 0` (see profiles/run_profile.sh); PMC passes are separate runs with `--pmc`.", ""]
+         "--cpu-seconds 0 --latency-frames 0 --streaming-batches 0` (see profiles/run_profile.sh); PMC passes are separate runs with `--pmc`.", ""]
 ks = pd.read_csv(stats)
 ks = ks[ks.Name.str.contains("mld::")]
 lines += ["## kernel-trace --stats", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
