@@ -417,10 +417,10 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
                                    ctx->stream, ctx->d_slots, SlotDesc{}, 0, cm, n_slots, pm, tag_all);
             }
         } else if (single) {
-            hipLaunchKernelGGL(k_feature_depth<false>, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream,
+            hipLaunchKernelGGL(k_feature_depth, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream,
                                ctx->d_slots, ctx->slots[slot].d, 1, calib, 1, per_slot, 0u);
         } else {
-            hipLaunchKernelGGL(k_feature_depth<false>, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
+            hipLaunchKernelGGL(k_feature_depth, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
                                ctx->stream, ctx->d_slots, SlotDesc{}, 0, calib, n_slots, per_slot, tag_all);
         }
     }
@@ -622,7 +622,7 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
         if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute");
     }
     if (ctx->lds_bytes > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_depth<false>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_depth),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_road<0>),

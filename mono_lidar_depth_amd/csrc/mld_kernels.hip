@@ -7,7 +7,11 @@
 //   k_project_scatter : Transform_Cloud_LidarToCamera + getImagePoints + InitializeLidarProjection
 //                       (DepthEstimator.cpp:156-217, camera_pinhole.h:84-97, NeighborFinderPixel.cpp:29-58)
 //                       fused: one coalesced pass over the cloud, no intermediate arrays.
-//   k_feature_depth   : the per-feature loop (DepthEstimator.cpp:455-600) for 64 features per wavefront.
+//   k_feature_main    : the per-feature loop (DepthEstimator.cpp:455-576), lane = feature, 256-thread blocks that
+//                       re-deal their live features to dense wavefronts after the window scan.
+//   k_feature_road    : the road fallback (DepthEstimator.cpp:578-597) for the features k_feature_main queued.
+//   k_feature_wave    : wavefront-per-feature variant for lists beyond the thread kernels' capacities (and debug mode).
+//   k_feature_depth   : main path + road fallback in one 64-thread kernel (A/B switch MLD_NO_SPLIT_ROAD=1).
 //   k_project_full / k_scan_* / k_export_* : lazy debug getters (visible list, _pointIndex, pixel map).
 //
 // Pixel map encoding.  The reference map holds the VISIBLE index of the first point (in cloud order,
@@ -1714,8 +1718,8 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
     if (live) finish_main(c, pca, myu, myv, r, mytype, mydepth);
 }
 
-// SPLIT_ROAD: road-fallback candidates are queued for k_feature_road (the road code is not part of this kernel).
-template <bool SPLIT_ROAD>
+// Single-kernel variant of the thread path (MLD_NO_SPLIT_ROAD=1): scan, main path and road fallback inline, 64 features
+// per block; also the front end of the wave-only mode (threadPath = 0: every feature is queued for k_feature_wave).
 __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restrict__ slots, SlotDesc single,
                                                          int use_single, Calib c, int n_slots, int per_slot,
                                                          uint32_t tag_all) {
@@ -1764,17 +1768,12 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
                     (mytype != MLD_RadiusSearchInsufficientPoints);
         const unsigned long long cmask = __ballot(cand);
         if (cmask) {
-            if (SPLIT_ROAD) {
-                // hand the candidates to k_feature_road (dense lanes there instead of ~half-idle waves here)
-                enqueue_features(s.road_queue, s.road_count, cand, lane, f0 + lane, mytype);
-            } else {
-                const int resultOld = mytype;
-                bool ovf2 = false;
-                road_thread<-1>(c, s, lst, lane, cand, myu, myv, mytype, mydepth, ovf2);
-                if (ovf2) {  // long wide-window list: only the road part is redone by the wave kernel
-                    overflow = true;
-                    ovf_code = resultOld;
-                }
+            const int resultOld = mytype;
+            bool ovf2 = false;
+            road_thread<-1>(c, s, lst, lane, cand, myu, myv, mytype, mydepth, ovf2);
+            if (ovf2) {  // long wide-window list: only the road part is redone by the wave kernel
+                overflow = true;
+                ovf_code = resultOld;
             }
         }
     } else {
@@ -1888,7 +1887,7 @@ __global__ __launch_bounds__(kMainThreads) void k_feature_main(const SlotDesc* _
     enqueue_features(s.ovf_queue, s.ovf_count, has && ovf2, lane, f, -1);
 }
 
-// Road fallback for the features queued by k_feature_depth (thread path, splitRoad): one lane per queued feature.
+// Road fallback for the features queued by k_feature_main: one lane per queued feature.
 template <int ROAD_MODE>
 __global__ __launch_bounds__(kWave) void k_feature_road(const SlotDesc* __restrict__ slots, SlotDesc single, int use_single,
                                                         Calib c, int n_slots, int per_slot, uint32_t tag_all) {
