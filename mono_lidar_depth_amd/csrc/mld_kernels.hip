@@ -1056,11 +1056,6 @@ __device__ __forceinline__ V3 cam_point(const Calib& c, const SlotDesc& s, uint3
     load_point(s, (long long)orig, x, y, z);
     return lidar_to_cam(c, x, y, z);
 }
-__device__ __forceinline__ double cam_z(const Calib& c, const SlotDesc& s, uint32_t orig) {
-    double x, y, z;
-    load_point(s, (long long)orig, x, y, z);
-    return c.T[11] + ((c.T[8] * x + c.T[9] * y) + c.T[10] * z);
-}
 
 // Raw float point of the cloud and its camera-frame image (same arithmetic as load_point + lidar_to_cam).  The list
 // loops below fetch several raw points before consuming any of them, so that the L2 latency is paid once per
@@ -1091,7 +1086,7 @@ __device__ __forceinline__ V3 raw_point(const Calib& c, RawP r) { return lidar_t
 #define LST_ID(e, n) (((e) < (n)) ? (LST(min((e), c.k1max - 1)) & kIdxMask) : 0u)
 
 // Window scan through the occupancy bitmap: the key map has one occupied cell in ~30, so reading it row by row
-// drags almost every 128-byte line of the 1.86 MB map through HBM.  The bitmap (58 KB per frame, cache resident)
+// drags almost every 128-byte line of the 1.86 MB map through HBM.  The bitmap (63 KB per frame, cache resident)
 // tells which cells to fetch.  Pass 1 appends the CELL indices of the set bits (row-major order) to the lane's
 // list; pass 2 turns them into point indices with batched key loads.  Windows up to 32 cells wide.
 __device__ __forceinline__ int scan_window_bitmap(const Calib& c, const SlotDesc& s, int x0, int y0, int nx, int ny,
@@ -1173,18 +1168,11 @@ __device__ __forceinline__ int scan_window_thread(const Calib& c, const SlotDesc
             ny = 0;
         }
     }
-    const int nymax = uniform(wave_max_i32(ny)), nxmax = uniform(wave_max_i32(nx));
-    const auto* base = GPTR(uint32_t, s.map) + ((size_t)y0 * (size_t)c.W + (size_t)x0);
-    int k = 0;
-    // Rows are independent: the loads of a group of rows are issued before any of them is consumed, so that
-    // the map latency is paid once per group instead of once per row.
+    const int nxmax = uniform(wave_max_i32(nx));
     if (nxmax <= 32) return scan_window_bitmap(c, s, x0, y0, nx, ny, lst, lane);
     // windows wider than 32 cells (non-default parameters): every lane with a window reports an overflowing list,
     // which sends its feature to the wave-cooperative kernel
-    (void)base;
-    (void)nymax;
-    k = (nx > 0) ? c.k1max + 1 : 0;
-    return k;
+    return (nx > 0) ? c.k1max + 1 : 0;
 }
 
 // Max-spanning triangle for lists of at most M entries, fully unrolled: all M points are fetched in one batch and
