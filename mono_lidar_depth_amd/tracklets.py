@@ -57,6 +57,8 @@ class TrackletDepthModule:
         is_new = np.fromiter((int(i) not in known for i in ids), dtype=np.uint8, count=n)  # :31
         slot_cur = self._slot_cur
         slot_last = (1 - slot_cur) if self._have_last else -1
+        import time
+        t_abi = time.perf_counter()
         if img is not None:
             ground_plane = SemanticPlane(img, (6, 7, 8, 9), est.getParameters().ransac_plane_refinement_treshold)
         est.setInputCloud(cloud, ground_plane, slot=slot_cur)  # the only projection of this frame
@@ -70,6 +72,7 @@ class TrackletDepthModule:
                                            is_new.ctypes.data, n, d_cur.ctypes.data, d_last.ctypes.data,
                                            t_cur.ctypes.data, t_last.ctypes.data, C.byref(n_new)))
         self.last_types = (t_cur, t_last)
+        self.last_abi_seconds = time.perf_counter() - t_abi  # C-ABI calls only (copies, kernels, synchronise)
         # SaveFeatureDepths (:119-169) + TidyUpTracklets (:171-193)
         updated = {}
         ui0, vi0 = arrs[0].astype(np.int32), arrs[1].astype(np.int32)
