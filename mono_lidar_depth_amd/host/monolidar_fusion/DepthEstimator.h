@@ -182,7 +182,9 @@ public:
     using UniquePtr = std::unique_ptr<DepthEstimator>;
     using SharedPtr = std::shared_ptr<DepthEstimator>;
 
-    explicit DepthEstimator(int device = 0) : _device(device) {}
+    // max_frames > 1 exposes the C-ABI's frame slots (tracklets_depth keeps the previous frame resident in a second slot)
+    explicit DepthEstimator(int device = 0, int max_frames = 1) : _device(device), _maxFrames(max_frames) {}
+    mld_ctx* ctx() const { return _ctx; }
     ~DepthEstimator() {
         if (_ctx) mld_destroy(_ctx);
     }
@@ -214,7 +216,7 @@ public:
         }
         int status = 0;
         mld_camera cam = camera->asStruct();
-        _ctx = mld_create(_parameters.get(), &cam, _transform.data(), _device, 1, 0, 0, &status);
+        _ctx = mld_create(_parameters.get(), &cam, _transform.data(), _device, _maxFrames, 0, 0, &status);
         if (!_ctx) {
             if (status == MLD_ERR_NO_ROAD_ESTIMATOR) throw "No road depth estimator selected.";
             throw std::string(mld_create_error());
@@ -231,9 +233,9 @@ public:
     }
 #endif
 
-    void setInputCloud(const Cloud::ConstPtr& cloud, GroundPlane::Ptr& groundPlane) {
+    void setInputCloud(const Cloud::ConstPtr& cloud, GroundPlane::Ptr& groundPlane, int slot = 0) {
         if (!_isInitialized) throw "call of 'setInputCloud' without 'initialize'";
-        check(mld_set_cloud(_ctx, 0, cloud->points.data(), (int64_t)cloud->points.size(), (int)sizeof(PointXYZI)));
+        check(mld_set_cloud(_ctx, slot, cloud->points.data(), (int64_t)cloud->points.size(), (int)sizeof(PointXYZI)));
         _numPoints = (int64_t)cloud->points.size();
         _isInitializedPointCloud = true;
         if (_parameters->do_use_ransac_plane) {
@@ -248,23 +250,23 @@ public:
                     int64_t n_inl = 0;
                     static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
                     if (auto* sp = dynamic_cast<SemanticPlane*>(rp)) {
-                        check(mld_estimate_semantic_plane(_ctx, 0, sp->image().data(), sp->rows(), sp->cols(), sp->cols(),
+                        check(mld_estimate_semantic_plane(_ctx, slot, sp->image().data(), sp->rows(), sp->cols(), sp->cols(),
                                                           reinterpret_cast<const int32_t*>(sp->labels().data()),
                                                           (int)sp->labels().size(), sp->inlierThreshold(), coeffs, &n_inl));
                     } else {
-                        check(mld_estimate_ground_plane(_ctx, 0, rp->seed, coeffs, &n_inl));
+                        check(mld_estimate_ground_plane(_ctx, slot, rp->seed, coeffs, &n_inl));
                     }
                     std::vector<int> inl((size_t)n_inl);
-                    check(mld_get_ground_plane_inliers(_ctx, 0, reinterpret_cast<int32_t*>(inl.data()), n_inl, &n_inl));
+                    check(mld_get_ground_plane_inliers(_ctx, slot, reinterpret_cast<int32_t*>(inl.data()), n_inl, &n_inl));
                     rp->assign({coeffs[0], coeffs[1], coeffs[2], coeffs[3]}, std::move(inl));
                     return;  // the estimator already installed the plane on the device
                 }
             }
             const auto& c = groundPlane->getModelCoeffs();
             const auto& inl = groundPlane->getInlinersIndex();
-            check(mld_set_ground_plane(_ctx, 0, c.data(), inl.data(), (int64_t)inl.size()));
+            check(mld_set_ground_plane(_ctx, slot, c.data(), inl.data(), (int64_t)inl.size()));
         } else {
-            check(mld_set_ground_plane(_ctx, 0, nullptr, nullptr, 0));
+            check(mld_set_ground_plane(_ctx, slot, nullptr, nullptr, 0));
         }
     }
 
@@ -420,6 +422,7 @@ private:
     bool _debugMode = false;
     std::vector<double> _dbgCorners, _dbgUv, _dbgDepth;
     int _device;
+    int _maxFrames = 1;
     mld_ctx* _ctx = nullptr;
     bool _isInitialized = false, _isInitializedConfig = false, _isInitializedPointCloud = false;
     std::shared_ptr<DepthEstimatorParameters> _parameters;

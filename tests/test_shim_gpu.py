@@ -55,3 +55,65 @@ def test_cpp_shim_matches_oracle(tmp_path, with_plane):
         m = re.search(r"semantic segmented (\d+) inliers (\d+) nz (\S+)", r.stdout)
         assert m, r.stdout
         assert int(m.group(1)) == 1 and int(m.group(2)) > 1000 and abs(abs(float(m.group(3))) - 1.0) < 0.05
+
+
+TRACKLET_DEMO = ROOT / "mono_lidar_depth_amd" / "lib" / "mld_tracklet_demo"
+
+
+def test_tracklet_demo_is_built():
+    assert TRACKLET_DEMO.exists(), "run __graft_entry__.build()"
+
+
+@pytest.mark.gpu
+def test_cpp_tracklet_module_matches_oracle(tmp_path):
+    """tracklets_depth::TrackletDepthModule (C++ shim, plain-struct messages) over four frames: 10 % new tracks per
+    frame, previous frame served from its resident slot; against the oracle's restatement of the module's marshalling."""
+    from oracle import oracle
+    from helpers import make_oracle
+    P = capi.params_c0()
+    rng = np.random.default_rng(8)
+    n_tracks, n_frames = 3000, 4
+    ids = np.arange(n_tracks, dtype=np.uint64)
+    next_id = n_tracks
+    frames = []
+    for k in range(n_frames):
+        cloud = synth.make_cloud(synth.HDL64_KITTI, seed=21, frame=2 * k, stride_floats=8)
+        coeffs, inl = synth.make_ground_plane(cloud)
+        if k > 0:
+            repl = rng.choice(n_tracks, n_tracks // 10, replace=False)
+            ids = ids.copy()
+            ids[repl] = np.arange(next_id, next_id + repl.size, dtype=np.uint64)
+            next_id += repl.size
+        u0 = rng.uniform(-2, synth.KITTI_W + 2, n_tracks).astype(np.float32)
+        v0 = rng.uniform(100, synth.KITTI_H + 2, n_tracks).astype(np.float32)
+        u1 = (u0 + rng.normal(0, 3, n_tracks)).astype(np.float32)
+        v1 = (v0 + rng.normal(0, 2, n_tracks)).astype(np.float32)
+        rec = np.zeros(n_tracks, dtype=[("id", "<u8"), ("u0", "<f4"), ("v0", "<f4"), ("u1", "<f4"), ("v1", "<f4"), ("pad", "<f4"), ("pad2", "<f4")])
+        rec["id"], rec["u0"], rec["v0"], rec["u1"], rec["v1"] = ids, u0, v0, u1, v1
+        (tmp_path / f"cloud_{k}.bin").write_bytes(cloud.tobytes())
+        (tmp_path / f"tracks_{k}.bin").write_bytes(rec.tobytes())
+        (tmp_path / f"inl_{k}.bin").write_bytes(inl.tobytes())
+        frames.append((cloud, (coeffs, inl), ids.copy(), u0, v0, u1, v1))
+    r = subprocess.run([str(TRACKLET_DEMO), str(tmp_path), str(n_frames), "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    known, ref_last = set(), None
+    for k, (cloud, (coeffs, inl), fids, u0, v0, u1, v1) in enumerate(frames):
+        coeffs = coeffs.copy()
+        coeffs[3] = np.float32(1.73)
+        ref = make_oracle(P)
+        ref.set_cloud(cloud)
+        ref.set_ground_plane(coeffs, inl)
+        is_new = np.array([int(i) not in known for i in fids])
+        e_cur, e_last, _, _ = oracle.tracklets_depth(ref, ref_last, u0, v0, u1, v1, is_new, n_threads=8)
+        out = np.frombuffer((tmp_path / f"out_{k}.bin").read_bytes(),
+                            dtype=[("d0", "<f4"), ("d1", "<f4"), ("len", "<i4")])
+        assert out.shape[0] == n_tracks
+        assert np.allclose(out["d0"], e_cur, rtol=0, atol=1e-4)
+        assert np.allclose(out["d1"][is_new], e_last[is_new], rtol=0, atol=1e-4)
+        # a new tracklet holds two features; a continued one grows by one per frame (TidyUpTracklets drops the rest)
+        assert (out["len"][is_new] == 2).all() and (out["len"][~is_new] >= 2).all()
+        if k == 0:
+            assert (out["d1"] == -1).all()  # no previous cloud (tracklet_depth_module.cpp:93-96)
+        assert f"frame {k} tracks {n_tracks} stored {n_tracks}" in r.stdout
+        known = set(int(i) for i in fids)
+        ref_last = ref
