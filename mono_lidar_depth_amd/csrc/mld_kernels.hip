@@ -73,19 +73,24 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     return v;
 }
 
-// blockIdx -> (slot, block-within-slot).  With a multiple of 8 slots, all blocks of one slot are congruent
-// mod 8, i.e. land on the same XCD under round-robin dispatch: the slot's map and cloud stay in one L2.
+// blockIdx -> (slot, block-within-slot).  Slots are taken in groups of 8 whose blocks are interleaved, so that all
+// blocks of one slot are congruent mod 8, i.e. land on the same XCD under round-robin dispatch: the slot's map and
+// cloud stay in one L2.  The last n_slots % 8 slots (and batches of fewer than 8) use the plain slot-major order.
 // This is a speed-only mapping; nothing depends on placement.
-// (a negative n_slots selects the plain slot-major mapping: MLD_NO_XCD=1, for A/B measurements)
+// (a negative n_slots selects the plain mapping throughout: MLD_NO_XCD=1, for A/B measurements)
 __device__ __forceinline__ void decode_block(int b, int n_slots, int per_slot, int& slot, int& j) {
-    if (n_slots >= 8 && (n_slots & 7) == 0) {
+    const int n8 = n_slots > 0 ? (n_slots & ~7) : 0;
+    const int b8 = n8 * per_slot;
+    if (b < b8) {
         int x = b & 7, q = b >> 3;
         int sq = q / per_slot;
         j = q - sq * per_slot;
         slot = sq * 8 + x;
     } else {
-        slot = b / per_slot;
-        j = b - slot * per_slot;
+        const int r = b - b8;
+        const int sr = r / per_slot;
+        slot = n8 + sr;
+        j = r - sr * per_slot;
     }
 }
 

@@ -201,11 +201,13 @@ def test_usage_errors():
     assert ei.value.code == capi.MLD_ERR_NO_GROUND_PLANE
 
 
-def test_batched_slots_match_single_slot():
-    """Frame slots: 16 frames in one launch set (torch device tensors) == one frame at a time."""
+@pytest.mark.parametrize("B", [16, 13])
+def test_batched_slots_match_single_slot(B):
+    """Frame slots: B frames in one launch set (torch device tensors) == one frame at a time.  13 exercises the
+    slots beyond the last full group of 8 (plain block order after the XCD-interleaved groups)."""
     import torch
     P = capi.params_c0()
-    B, F = 16, 700
+    F = 700
     sc = synth.HDL64_KITTI
     est = make_estimator(P, max_frames=B)
     clouds = [synth.make_cloud(sc, seed=50 + (b % 3), frame=b) for b in range(B)]
