@@ -21,6 +21,10 @@
  *     micro-batch of sequences).  slot 0 alone gives the reference's one-frame-at-a-time use.
  *   - `*_device` entry points take device pointers (zero-copy: the cloud is read in place),
  *     are asynchronous on the context's stream, and never touch the host buffers.
+ *   - threading: like a reference instance (mutable `_points`, DepthEstimator.h:300-334), a context serves one call
+ *     at a time; different contexts are independent and may be driven from different host threads or processes
+ *     (one per GPU).  mld_last_error / mld_create_error return thread-unsafe static text.
+ *   - ordering with the caller's own GPU work: record/wait events on mld_get_stream() (see bench.py streaming_leg).
  */
 #ifndef MLD_H_
 #define MLD_H_
