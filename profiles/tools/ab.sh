@@ -1,7 +1,7 @@
 #!/bin/bash
-# runs bench.py for every scratch/libs/*.so, alternating; prints kernel times (us per 1024 frames)
+# runs bench.py for every profiles/tools/libs/*.so, alternating; prints kernel times (us per 1024 frames)
 for round in 1 2 3; do
-for lib in scratch/libs/*.so; do
+for lib in profiles/tools/libs/*.so; do
   echo -n "$(basename $lib .so) r$round: "
   MLD_HIP_LIBRARY=$PWD/$lib timeout 120 python bench.py --steps 20 --warmup 3 --cpu-seconds 0 --latency-frames 0 --streaming-batches 0 2>/dev/null | python -c "
 import json,sys
