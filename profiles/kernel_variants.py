@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times k_feature_depth under workload variants to see where the launch time goes (run on the GPU box)."""
+"""Times the feature kernels under workload variants to see where the launch time goes (run on the GPU box)."""
 import os
 import sys
 from pathlib import Path
