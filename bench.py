@@ -290,11 +290,25 @@ def main():
         return m.view(np.int32)
 
     masks_h = [mask_of(p[1]) for p in planes_h]
-    t_clouds = [torch.from_numpy(clouds_h[b % U]).to(dev).clone() for b in range(B)]  # distinct HBM per slot
-    t_masks = [torch.from_numpy(masks_h[b % U]).to(dev).clone() for b in range(B)]
-    t_uvs = [torch.from_numpy(uvs_h[b]).to(dev) for b in range(B)]
-    t_depth = [torch.empty(F, dtype=torch.float64, device=dev) for _ in range(B)]
-    t_type = [torch.empty(F, dtype=torch.int32, device=dev) for _ in range(B)]
+    # distinct HBM per slot, carved out of one allocation per kind (large, contiguous mappings instead of B small ones)
+    words = masks_h[0].shape[0]
+    all_clouds = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+    all_masks = torch.empty((B, words), dtype=torch.int32, device=dev)
+    all_uvs = torch.empty((B, F, 2), dtype=torch.float64, device=dev)
+    all_depth = torch.empty((B, F), dtype=torch.float64, device=dev)
+    all_type = torch.empty((B, F), dtype=torch.int32, device=dev)
+    d_unique = [torch.from_numpy(clouds_h[u]).to(dev) for u in range(U)]
+    m_unique = [torch.from_numpy(masks_h[u]).to(dev) for u in range(U)]
+    for b in range(B):
+        all_clouds[b].copy_(d_unique[b % U])
+        all_masks[b].copy_(m_unique[b % U])
+        all_uvs[b].copy_(torch.from_numpy(uvs_h[b]))
+    del d_unique, m_unique
+    t_clouds = [all_clouds[b] for b in range(B)]
+    t_masks = [all_masks[b] for b in range(B)]
+    t_uvs = [all_uvs[b] for b in range(B)]
+    t_depth = [all_depth[b] for b in range(B)]
+    t_type = [all_type[b] for b in range(B)]
     coeffs = np.stack([planes_h[b % U][0] for b in range(B)])
     torch.cuda.synchronize()
 
