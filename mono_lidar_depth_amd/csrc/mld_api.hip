@@ -69,6 +69,7 @@ struct mld_ctx {
     bool own_stream = true;
     std::vector<Slot> slots;
     SlotDesc* d_slots = nullptr;
+    unsigned char* dummy = nullptr;  // 256 zero bytes: the cloud of a slot without points (list loops pad with point 0)
     int32_t* road_counts = nullptr;  // per-slot queue lengths (road fallback, then long-list overflow), contiguous,
                                      // placed in front of the bitmaps so that one fill clears both
     bool counters_clean = false;
@@ -342,7 +343,9 @@ int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int strid
     } else {
         s.d.tag += 1;
     }
-    s.d.cloud = static_cast<const unsigned char*>(dev_ptr);
+    // an empty cloud may come with a null pointer (e.g. the data pointer of an empty tensor): the kernels' padding
+    // loads of "point 0" still need an address
+    s.d.cloud = (n > 0) ? static_cast<const unsigned char*>(dev_ptr) : ctx->dummy;
     s.d.n = n;
     s.d.stride = stride;
     s.d.has_plane = 0;
@@ -639,6 +642,8 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     ctx->h_descs.resize(max_frames);
     if ((e = hipMalloc((void**)&ctx->d_slots, sizeof(SlotDesc) * max_frames)) != hipSuccess)
         return hip_bail(e, "hipMalloc(slots)");
+    if ((e = hipMalloc((void**)&ctx->dummy, 256)) != hipSuccess) return hip_bail(e, "hipMalloc(dummy)");
+    if ((e = hipMemsetAsync(ctx->dummy, 0, 256, ctx->stream)) != hipSuccess) return hip_bail(e, "hipMemset(dummy)");
     size_t cells = (size_t)camera->width * camera->height + kMapPadCells;
     ctx->bitmap_words = (size_t)ctx->calib.bmStride * (size_t)((camera->width + 31) / 32 + 1) + 4;  // + a slack column
     // one allocation: [queue lengths: max_frames road fallback + max_frames long-list overflow][bitmaps of the slots]
@@ -688,6 +693,7 @@ void mld_destroy(mld_ctx* ctx) {
             if (p) (void)hipFree(p);
     }
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    if (ctx->dummy) (void)hipFree(ctx->dummy);
     if (ctx->road_counts) (void)hipFree(ctx->road_counts);  // also holds the bitmaps
     void* rsp[] = {ctx->rs_flags, ctx->rs_cand, ctx->rs_block, ctx->rs_M, ctx->rs_S, ctx->rs_sample, ctx->rs_sp,
                    ctx->rs_counts, ctx->rs_inl, ctx->rs_res, ctx->sem_img, ctx->sem_coeffs, ctx->sem_res};

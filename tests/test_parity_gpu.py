@@ -260,3 +260,44 @@ def test_full_size_properties_config2():
     ok = t1 == 1
     assert (d1[ok] >= 0).all() and (d1[ok] <= 100).all()
     assert ((t1 != 1) & (t1 != 16) == (d1 == -1)).all()
+
+
+def test_batch_with_empty_and_ragged_slots():
+    """One launch set with ragged slots: no features in one slot, an empty cloud in another, a slot without a ground
+    plane, different cloud sizes and feature counts everywhere else."""
+    import torch
+    P = capi.params_c0()
+    B = 8
+    dev = torch.device("cuda:0")
+    scanners = [synth.HDL64_KITTI, synth.VLP16, synth.HDL64, synth.HDL64_KITTI, synth.VLP16, synth.HDL64_KITTI,
+                synth.HDL64, synth.VLP16]
+    clouds = [synth.make_cloud(scanners[b], seed=90 + b, frame=b) for b in range(B)]
+    clouds[5] = np.zeros((0, 4), dtype=np.float32)
+    uvs = [synth.make_features(300 + 97 * b, seed=95 + b) for b in range(B)]
+    uvs[2] = np.zeros((0, 2), dtype=np.float64)
+    planes = [synth.make_ground_plane(c) if c.shape[0] else (np.array([0, 0, 1, 1.73], np.float32), np.zeros(0, np.int32))
+              for c in clouds]
+    est = make_estimator(P, max_frames=B)
+    t_clouds = [torch.from_numpy(c).to(dev) if c.shape[0] else torch.zeros((1, 4), dtype=torch.float32, device=dev)[:0]
+                for c in clouds]
+    t_uvs = [torch.from_numpy(u).to(dev) if u.shape[0] else torch.zeros((1, 2), dtype=torch.float64, device=dev)[:0]
+             for u in uvs]
+    t_depth = [torch.full((max(1, u.shape[0]),), 7.0, dtype=torch.float64, device=dev)[:u.shape[0]] for u in uvs]
+    t_type = [torch.full((max(1, u.shape[0]),), -7, dtype=torch.int32, device=dev)[:u.shape[0]] for u in uvs]
+    torch.cuda.synchronize()
+    est.setInputClouds(t_clouds, 16)
+    for b in range(B):
+        if b == 7:
+            est.setGroundPlane(NO_PLANE, slot=b)
+        else:
+            est.setGroundPlane(GroundPlane(planes[b][0], torch.from_numpy(planes[b][1]).to(dev)), slot=b)
+    est.CalculateDepths(t_uvs, t_depth, t_type)
+    est.synchronize()
+    for b in range(B):
+        if uvs[b].shape[0] == 0:
+            continue
+        if clouds[b].shape[0] == 0:
+            assert (t_type[b].cpu().numpy() == 2).all() and (t_depth[b].cpu().numpy() == -1).all()
+            continue
+        _, (d0, t0) = run_oracle(P, clouds[b], uvs[b], None if b == 7 else planes[b])
+        assert_depth_parity(t_depth[b].cpu().numpy(), t_type[b].cpu().numpy(), d0, t0)
