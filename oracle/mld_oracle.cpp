@@ -265,6 +265,9 @@ void init_lidar_projection(Frame& fr) {
 void get_neighbor_indices(const Frame& fr, double u, double v, float scaleW, float scaleH,
                           std::vector<int32_t>& out) {
     const int W = fr.cam.width, H = fr.cam.height;
+    // NaN / inf coordinates: the reference casts them to int and indexes the map with the result (undefined behaviour);
+    // defined here, as in the HIP path, as an empty window
+    if (!std::isfinite(u) || !std::isfinite(v)) return;
     double halfX = static_cast<double>(fr.P.pixelarea_search_witdh) * 0.5 * static_cast<double>(scaleW);
     double halfY = static_cast<double>(fr.P.pixelarea_search_height) * 0.5 * static_cast<double>(scaleH);
     double left = std::max(u - halfX, 0.);

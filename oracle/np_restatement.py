@@ -74,6 +74,8 @@ class NpDepthEstimator:
     # NeighborFinderPixel::getNeighbors (NeighborFinderPixel.cpp:60-95)
     def neighbours(self, u, v, sx, sy):
         P, W, H = self.P, self.cam.width, self.cam.height
+        if not (np.isfinite(u) and np.isfinite(v)):  # undefined in the reference; an empty window here
+            return [], []
         hx = float(P.pixelarea_search_witdh) * 0.5 * float(np.float32(sx))
         hy = float(P.pixelarea_search_height) * 0.5 * float(np.float32(sy))
         left, right = max(u - hx, 0.0), min(u + hx, float(W - 1))
