@@ -114,3 +114,19 @@ def test_reinitialise_with_other_parameters_and_camera():
     d, t = est.CalculateDepth(cloud, uv2, GroundPlane(*plane))
     _, (d0, t0) = run_oracle(P2, cloud, uv2, plane, camera=cam2)
     assert_depth_parity(d, t, d0, t0)
+
+
+def test_many_features_in_one_call():
+    """300 000 features in one CalculateDepth (150x a frame's worth): spot-checked against the oracle, and the
+    per-feature result must not depend on how many features share the call."""
+    P = capi.params_c0()
+    cloud = synth.make_cloud(synth.HDL64_KITTI, seed=56, frame=0)
+    plane = synth.make_ground_plane(cloud)
+    uv = synth.make_features(300000, seed=56)
+    est = make_estimator(P)
+    d, t = est.CalculateDepth(cloud, uv, GroundPlane(*plane))
+    sel = np.r_[0:700, 150000:150700, 299300:300000]
+    _, (d0, t0) = run_oracle(P, cloud, uv[sel], plane, n_threads=8)
+    assert_depth_parity(d[sel], t[sel], d0, t0)
+    d2, t2 = est.CalculateDepth(uv[sel])
+    assert np.array_equal(d2, d[sel]) and np.array_equal(t2, t[sel])
