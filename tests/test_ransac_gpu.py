@@ -93,3 +93,28 @@ def test_too_small_cloud_raises_pcl_invalid():
     nan_cloud = np.full((500, 4), np.nan, np.float32)
     with pytest.raises(ExceptionPclInvalid):
         est.setInputCloud(nan_cloud, RansacPlane())
+
+
+@pytest.mark.gpu
+def test_no_horizontal_plane_in_the_cloud():
+    """A vertical wall only: every hypothesis fails the perpendicular-plane test (axis z, 10 degrees), so PCL's
+    countWithinDistance returns 0 for each; its loop still adopts the first one (0 > -INT_MAX) and the reference ends
+    up with that plane's coefficients and no inliers.  Both sides reproduce this."""
+    rng = np.random.default_rng(3)
+    n = 5000
+    wall = np.stack([np.full(n, 10.0), rng.uniform(-20, 20, n), rng.uniform(-2, 3, n), np.zeros(n)], axis=1).astype(np.float32)
+    ref = make_oracle(capi.params_c0())
+    ref.set_cloud(wall)
+    c0, inl0 = ref.estimate_ground_plane(1)
+    assert inl0.size == 0 and abs(abs(c0[0]) - 1.0) < 1e-3
+    est = make_estimator(capi.params_c0())
+    gp = RansacPlane(seed=1)
+    est.setInputCloud(wall, gp)
+    assert np.array_equal(np.asarray(gp.getModelCoeffs(), dtype=np.float32), c0)
+    assert est.getGroundPlaneInliers().size == 0
+    # no inliers -> no road fallback succeeds; the main path is unaffected
+    uv = synth.make_features(300, seed=4)
+    d, t = est.CalculateDepth(uv)
+    d0, t0 = ref.calculate_depth(uv)
+    assert_depth_parity(d, t, d0, t0)
+    assert (t != 16).all()
