@@ -132,3 +132,18 @@ def test_depths_with_a_semantic_plane_match_the_oracle():
     assert gp.isSegmented() and np.array_equal(gp.getModelCoeffs(), coeffs)
     assert_depth_parity(d, t, d0, t0)
     assert (t0 == 16).sum() > 50
+
+
+@pytest.mark.gpu
+def test_hip_label_image_smaller_than_the_camera_and_odd_label_sets():
+    """The label image need not have the camera's size (the reference bounds-checks against the image, RansacPlane.cpp:
+    206-207); labels outside 0..255 can never match a uint8 pixel."""
+    cloud, img = _frame(11)
+    small = np.ascontiguousarray(img[40:340, 100:1000])  # 300 x 900: projections beyond it are invalid
+    labels = (7, 8, -3, 300, 7)
+    _, coeffs, inl = _oracle_plane(cloud, small, 0.2, labels)
+    est = make_estimator(capi.params_c0())
+    est.setInputCloud(cloud, None, plane_given=False)
+    c_hip, n_hip = est.estimateSemanticPlane(small, labels, 0.2)
+    assert np.array_equal(c_hip, coeffs) and n_hip == inl.size
+    assert np.array_equal(est.getGroundPlaneInliers(), inl)
