@@ -134,3 +134,22 @@ def test_abi_version_constant_matches_the_header():
     hdr = (Path(__file__).resolve().parent.parent / "include" / "mld.h").read_text()
     assert int(re.search(r"#define\s+MLD_ABI_VERSION\s+(\d+)", hdr).group(1)) == capi.MLD_ABI_VERSION
     assert capi.load().mld_abi_version() == capi.MLD_ABI_VERSION
+
+
+def test_params_from_file_tolerates_formatting(tmp_path):
+    """CRLF line ends, tabs, missing space after the colon, scientific notation, signs, inline comments, a real value
+    for an int field (cvRound), an unreadable file."""
+    y = tmp_path / "p.yaml"
+    y.write_bytes(b"%YAML:1.0\r\n---\r\npixelarea_search_witdh:8\r\n\tpixelarea_search_height:\t11 # rows\r\n"
+                  b"histogram_segmentation_bin_witdh: 2.5e-1\r\ntreshold_depth_local_value: +0.75\r\n"
+                  b"ransac_plane_min_z: -3.5\r\nradiusSearch_count_min: 2.6\r\ndo_use_PCA: 7\r\n"
+                  b"plane_estimator_use_mestimator: 1\r\nnot a key value line\r\n: 5\r\nsome_key:\r\n")
+    p = capi.params_from_file(str(y))
+    assert p.pixelarea_search_witdh == 8 and p.pixelarea_search_height == 11
+    assert p.histogram_segmentation_bin_witdh == 0.25 and p.treshold_depth_local_value == 0.75
+    assert p.ransac_plane_min_z == -3.5
+    assert p.radiusSearch_count_min == 3  # (int) of a real node rounds to nearest
+    assert p.do_use_PCA == 1              # bool member: any non-zero int
+    assert p.do_use_ransac_plane == 0     # absent key reads as 0
+    with pytest.raises(Exception, match="Cant find settings file"):
+        capi.params_from_file(str(tmp_path / "missing.yaml"))
