@@ -395,3 +395,113 @@ def semantic_plane(cloud: np.ndarray, T, f, cu, cv, img: np.ndarray, labels, thr
     inl = np.nonzero(dist.astype(np.float64) < thr)[0].astype(np.int32)
     c2 = ls_plane_fit(xyz32, inl, c1)
     return cand, c1, inl, c2
+
+
+# ---- RansacPlane::CalculateInliersPlane (monolidar_fusion/src/RansacPlane.cpp:41-140), second restatement ----------
+
+def _mix(a: int, b: int, c: int) -> int:
+    """Counter-based hash of the draws (shared convention of the C++ restatement and the HIP kernels)."""
+    M = 0xFFFFFFFF
+    h = (a * 0x9E3779B1) & M
+    h ^= (b + 0x85EBCA6B + ((h << 6) & M) + (h >> 2)) & M
+    h ^= (((c * 0xC2B2AE35) & M) + ((h << 6) & M) + (h >> 2)) & M
+    h ^= h >> 16
+    h = (h * 0x85EBCA6B) & M
+    h ^= h >> 13
+    h = (h * 0xC2B2AE35) & M
+    h ^= h >> 16
+    return h
+
+
+def _plane_from(p0, p1, p2):
+    """sac_model_plane computeModelCoefficients + sac_model_perpendicular_plane isModelValid, float32 throughout."""
+    f = np.float32
+    with np.errstate(all="ignore"):
+        a = (p1 - p0).astype(f)
+        b = (p2 - p0).astype(f)
+        r = a / b
+        degenerate = bool(r[0] == r[1] and r[2] == r[1])
+        n = np.array([a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]], dtype=f)
+        nn = np.sqrt(f(f(n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]))
+        n = (n / nn).astype(f)
+        d = f(-1.0) * f(f(n[0] * p0[0] + n[1] * p0[1]) + n[2] * p0[2])
+    if not (nn > 0) or not np.isfinite(nn):
+        degenerate = True
+    valid = (not degenerate) and abs(float(n[2])) >= 0.984807753012208
+    return np.array([n[0], n[1], n[2], d], dtype=f), degenerate, valid
+
+
+def _plane_dist(c, pts):
+    f = np.float32
+    return np.abs(((c[0] * pts[:, 0] + c[1] * pts[:, 1]).astype(f) + c[2] * pts[:, 2]).astype(f) + c[3]).astype(f)
+
+
+def ransac_plane(cloud: np.ndarray, P, seed: int):
+    """Returns (coefficients float32[4], ascending inlier indices) like OracleDepthEstimator.estimate_ground_plane."""
+    k_sample = 6000
+    xyz = np.ascontiguousarray(cloud[:, :3], dtype=np.float32)
+    n = xyz.shape[0]
+    if n < 3:
+        raise ValueError("In GroundPlane: Input pointcloud is invalid")
+    if P.ransac_plane_min_z > -1001.0:
+        lo, hi = np.float32(P.ransac_plane_min_z), np.float32(P.ransac_plane_max_z)
+        with np.errstate(invalid="ignore"):
+            ok = np.isfinite(xyz).all(axis=1) & ~(xyz[:, 2] < lo) & ~(xyz[:, 2] > hi)
+        cand = np.nonzero(ok)[0].astype(np.int64)
+    else:
+        cand = np.arange(n, dtype=np.int64)
+    M = cand.size
+    if M > k_sample:
+        sample = np.empty(k_sample, dtype=np.int64)
+        for j in range(k_sample):
+            u = _mix(seed, j, 0x5A17) * (1.0 / 4294967296.0)
+            pos = int((float(j) + u) * float(M) / float(k_sample))
+            sample[j] = cand[min(pos, M - 1)]
+    else:
+        sample = cand
+    S = sample.size
+    if S < 3:
+        raise ValueError("In GroundPlane: Input pointcloud is invalid")
+    sp = xyz[sample]
+
+    def draw(d):
+        a = _mix(seed, d, 1) % S
+        b = _mix(seed, d, 2) % S
+        c = _mix(seed, d, 3) % S
+        if b == a:
+            b = (b + 1) % S
+        while c == a or c == b:
+            c = (c + 1) % S
+        return _plane_from(sp[a], sp[b], sp[c])
+
+    thr = float(P.ransac_plane_distance_treshold)
+    max_it = int(P.ransac_plane_max_iterations)
+    iterations, best, best_draw, k = 0, -2147483647, -1, 1.0
+    log_probability = np.log(1.0 - P.ransac_plane_probability)
+    eps = np.finfo(np.float64).eps
+    d = 0
+    while d < max_it + 1 and iterations < k:
+        c, degenerate, valid = draw(d)
+        d += 1
+        if degenerate:
+            continue
+        cnt = int((_plane_dist(c, sp).astype(np.float64) < thr).sum()) if valid else 0
+        if cnt > best:
+            best, best_draw = cnt, d - 1
+            w = best / float(S)
+            p_no = min(1.0 - eps, max(eps, 1.0 - w * w * w))
+            k = log_probability / np.log(p_no)
+        iterations += 1
+        if iterations > max_it:
+            break
+    if best_draw < 0:
+        raise ValueError("In GroundPlane: Input pointcloud is invalid")
+    bm, _, bvalid = draw(best_draw)
+    coeffs = bm.copy()
+    inl = np.nonzero(_plane_dist(bm, sp).astype(np.float64) < thr)[0] if bvalid else np.zeros(0, dtype=np.int64)
+    if P.ransac_plane_use_refinement:
+        if inl.size > 3:
+            coeffs = ls_plane_fit(sp, inl.astype(np.int64), coeffs)
+        inl = (np.nonzero(_plane_dist(bm, sp).astype(np.float64) < P.ransac_plane_refinement_treshold)[0]
+               if bvalid else np.zeros(0, dtype=np.int64))
+    return coeffs, np.unique(sample[inl]).astype(np.int32)
