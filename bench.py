@@ -317,7 +317,7 @@ def main():
     assert B % (S * NC) == 0, "--frames-per-step must be a multiple of --slots x --contexts"
     ests = []
     for _ in range(NC):
-        e = DepthEstimator(device=local_rank, max_frames=S)
+        e = DepthEstimator(device=local_rank, max_frames=S, max_features=F)  # queues allocated up front
         e.InitConfig(P)
         e.Initialize(cam, T)
         ests.append(e)

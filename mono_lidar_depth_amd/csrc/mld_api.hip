@@ -674,6 +674,8 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
             if ((e = hipMalloc((void**)&s.depth_buf, F * sizeof(double))) != hipSuccess) return hip_bail(e, "hipMalloc(depth)");
             if ((e = hipMalloc((void**)&s.type_buf, F * sizeof(int32_t))) != hipSuccess) return hip_bail(e, "hipMalloc(type)");
             s.feat_cap = F;
+            // work queues of the feature kernels: no allocation in the first CalculateDepth
+            if (ensure_road_queue(ctx, s, (int64_t)F) != MLD_OK) return hip_bail(hipErrorOutOfMemory, "hipMalloc(queues)");
         }
     }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return hip_bail(e, "hipStreamSynchronize");
