@@ -295,6 +295,12 @@ bool calculate_neighbors(const Frame& fr, double u, double v, float sx, float sy
     return true;
 }
 
+// Histogram::AddElement (Histogram.cpp:19-33): the bin a value falls into
+inline int histogram_bin_index(double value, double binW, int binCount) {
+    value = std::min(value, 1e10);  // :29
+    return static_cast<int>(std::min(std::abs(value / binW), static_cast<double>(binCount) - 1.));  // :30
+}
+
 // PointHistogram::FilterPointsMinDistBlob (HistogramPointDepth.cpp:15-123) + Histogram (Histogram.cpp:14-49).
 // Returns false / true; out = positions (into the input list) of the kept points, in order.
 bool filter_points_min_dist_blob(const double* depths, int n, double binW, int minimalMaximumSize,
@@ -307,12 +313,7 @@ bool filter_points_min_dist_blob(const double* depths, int n, double binW, int m
     int binCount = static_cast<int>((maxDist) / binW + 1);                           // :43
     if (binCount <= 1) return false;                                                // :53
     std::vector<int> bins(binCount, 0);
-    for (int i = 0; i < n; i++) {
-        double value = std::min(depths[i], 1e10);  // Histogram.cpp:29
-        int binIndex =
-            static_cast<int>(std::min(std::abs(value / binW), static_cast<double>(bins.size()) - 1.));  // :30
-        bins[binIndex]++;
-    }
+    for (int i = 0; i < n; i++) bins[histogram_bin_index(depths[i], binW, binCount)]++;
     int binMaxId = -1, binMaxVal = -1, binValue = 0;
     for (int i = 0; i < binCount; i++) {  // HistogramPointDepth.cpp:70-85
         float lastBinValue = static_cast<float>(binValue);
@@ -1322,6 +1323,13 @@ int orc_intersect_triangle(const double p1[3], const double p2[3], const double 
 }
 
 int orc_threshold_global(const mld_params* P, double* depth) { return threshold_global(*P, *depth); }
+
+// Histogram::AddElement for every value, then the bin sizes (Histogram.cpp:14-49) — the binning expression
+// filter_points_min_dist_blob uses, exposed for the check against the reference's own Histogram class
+void orc_histogram_counts(const double* values, int n, double binW, int binCount, int32_t* counts) {
+    for (int b = 0; b < binCount; b++) counts[b] = 0;
+    for (int i = 0; i < n; i++) counts[histogram_bin_index(values[i], binW, binCount)]++;
+}
 
 int orc_threshold_local(const mld_params* P, const double* pts, int n, double* depth) {
     std::vector<V3> p(n);

@@ -62,6 +62,8 @@ def load() -> C.CDLL:
     lib.orc_tracklets_depth.argtypes = [C.c_void_p, C.c_void_p] + [C.c_void_p] * 5 + [C.c_int64] + [C.c_void_p] * 4 + [C.c_int]
     lib.orc_filter_points_min_dist_blob.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p,
                                                     P(C.c_int32), P(C.c_double), P(C.c_double)]
+    lib.orc_histogram_counts.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
+    lib.orc_histogram_counts.restype = None
     lib.orc_get_nearest_point.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     lib.orc_max_spanning_triangle.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_void_p]
     lib.orc_check_planar.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
@@ -303,3 +305,24 @@ def pca(params, points):
     n, m = np.empty(3), np.empty(3)
     r = load().orc_pca(C.byref(params), p.ctypes.data, p.shape[0], n.ctypes.data, m.ctypes.data)
     return int(r), n, m
+
+
+def histogram_counts(values, bin_width, bin_count):
+    v = _f64(values)
+    out = np.zeros(bin_count, dtype=np.int32)
+    load().orc_histogram_counts(v.ctypes.data, v.size, float(bin_width), int(bin_count), out.ctypes.data)
+    return out
+
+
+REF_LIB_PATH = _HERE / "_ref" / "libmld_ref.so"
+
+
+def load_reference_parts():
+    """oracle/_ref/libmld_ref.so: Histogram.cpp and TresholdDepthGlobal.cpp of the reference, compiled from
+    /root/reference by `make -C oracle ref` (only where that tree exists).  None if it has not been built."""
+    if not REF_LIB_PATH.exists():
+        return None
+    lib = C.CDLL(str(REF_LIB_PATH))
+    lib.ref_histogram_counts.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
+    lib.ref_threshold_global.argtypes = [C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]
+    return lib
