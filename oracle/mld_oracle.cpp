@@ -10,8 +10,10 @@
  * (monolidar_fusion/src/DepthEstimator.cpp:455).  Every function cites the reference lines it follows.
  *
  * PARITY STATUS
- *   - The reference cannot be compiled here (Eigen, PCL, OpenCV absent), so there is
- *     no oracle/_ref build.
+ *   - The reference as a whole cannot be compiled here (Eigen, PCL, OpenCV absent).  Its two
+ *     dependency-free units of the path, Histogram.cpp and TresholdDepthGlobal.cpp, are compiled from
+ *     /root/reference into oracle/_ref/libmld_ref.so (oracle/ref_shim.cpp, `make ref`) and the corresponding
+ *     functions here are checked against that object code (tests/test_reference_parts.py).
  *   - Pinned by the reference's own tests for this path: Histogram.FilterPointsMinDistBlob (exact
  *     KAT), Histogram.GetNearestPoint, NeigborFinder.findByPixel (property bounds)
  *     (monolidar_fusion/test/test_monolidar_fusion.cpp:82-171,277-374) — see tests/test_oracle_kat.py.
