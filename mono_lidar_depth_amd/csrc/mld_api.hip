@@ -477,6 +477,7 @@ int upload_descs(mld_ctx* ctx, int n_slots) {
 int precheck_calc(mld_ctx* ctx, Slot& s, int64_t F) {
     if (!s.cloud_set) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "call of 'CalculateDepth' without 'SetInputCloud'");
     if (F < 0) return fail(ctx, MLD_ERR_INVALID_ARG, "negative feature count");
+    if (F > 0x7FFFFFFFLL) return fail(ctx, MLD_ERR_CAPACITY, "more than 2^31-1 features in one call");  // queues hold int32 indices
     if (ctx->P.do_use_ransac_plane && !s.plane_decided && !ctx->P.set_all_depths_to_zero)
         return fail(ctx, MLD_ERR_NO_GROUND_PLANE,
                     "do_use_ransac_plane is set but no ground plane was supplied for this cloud "
