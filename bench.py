@@ -366,6 +366,7 @@ def main():
     k_feat_ms, n_feat = est.kernelTimeMs(1) if timing else (0.0, 0)
     k_road_ms, n_road = est.kernelTimeMs(2) if timing else (0.0, 0)
     k_wave_ms, n_wave = est.kernelTimeMs(3) if timing else (0.0, 0)
+    k_sort_ms, n_sort = est.kernelTimeMs(5) if timing else (0.0, 0)
     est.timingEnable(False)
 
     if rank != 0:
@@ -420,6 +421,7 @@ def main():
                                "GBps": (road_bytes / (k_road_ms * 1e-3)) / 1e9 if k_road_ms > 0 else 0.0},
         },
         "k_feature_wave_ms": k_wave_ms,  # long-list overflow kernel (queue normally empty in this workload)
+        "k_sort_features_ms": k_sort_ms,  # row-order permutation of the features (counting sort per frame)
         "feature_kernels_GBps": (feat_bytes / ((k_feat_ms + k_road_ms) * 1e-3)) / 1e9 if k_feat_ms > 0 else 0.0,
         "whole_step_GBps": ((proj_bytes + feat_bytes) * (B // S) * args.steps / elapsed) / 1e9,
     }

@@ -79,6 +79,7 @@ struct mld_ctx {
     size_t lds_bytes = 0;
     size_t lds_main = 0;  // k_feature_main: four per-wave index lists + the dealing table
     int k_main = 24;      // list capacity of k_feature_main (narrow window); the road kernel keeps calib.k1max
+    bool sort_features = true;  // k_sort_features before k_feature_main (MLD_NO_SORT=1 switches it off)
     std::string err;
     // ground-plane estimation scratch (device)
     int32_t* rs_flags = nullptr;
@@ -269,7 +270,11 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     int k_main = 24;
     if (const char* k = std::getenv("MLD_KMAIN")) k_main = std::atoi(k);
     ctx->k_main = std::min(std::max(k_main, 8), c.k1max);
-    ctx->lds_main = (size_t)(kMainThreads / kWave) * ctx->k_main * kWave * sizeof(uint32_t) + kMainThreads * sizeof(uint32_t) + 64;
+    {
+        const char* nosort = std::getenv("MLD_NO_SORT");
+        ctx->sort_features = !(nosort && nosort[0] == '1');
+    }
+    ctx->lds_main = (size_t)(kMainThreads / kWave) * ctx->k_main * kWave * sizeof(uint32_t) + 2 * kMainThreads * sizeof(uint32_t) + 64;
 }
 
 int check_slot(mld_ctx* ctx, int slot) {
@@ -387,10 +392,13 @@ int ensure_road_queue(mld_ctx* ctx, Slot& s, int64_t F) {
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (s.d.road_queue) HIP_TRY(ctx, hipFree(s.d.road_queue));
     if (s.d.ovf_queue) HIP_TRY(ctx, hipFree(s.d.ovf_queue));
+    if (s.d.perm) HIP_TRY(ctx, hipFree(s.d.perm));
     s.d.road_queue = nullptr;
     s.d.ovf_queue = nullptr;
+    s.d.perm = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&s.d.road_queue, (size_t)F * 2 * sizeof(int32_t)));
     HIP_TRY(ctx, hipMalloc((void**)&s.d.ovf_queue, (size_t)F * 2 * sizeof(int32_t)));
+    if (ctx->sort_features && ctx->calib.splitRoad) HIP_TRY(ctx, hipMalloc((void**)&s.d.perm, (size_t)F * sizeof(int32_t)));
     s.road_cap = (size_t)F;
     return MLD_OK;
 }
@@ -405,6 +413,17 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     if (!ctx->counters_clean)
         HIP_TRY(ctx, hipMemsetAsync(ctx->road_counts, 0, sizeof(int32_t) * 2 * ctx->slots.size(), ctx->stream));
     ctx->counters_clean = false;
+    if (split && ctx->sort_features) {
+        // features in row order first (MLD_NO_SORT=1 keeps the caller's order: no SlotDesc::perm is allocated then)
+        ScopedTimer ts(ctx, 5);
+        if (single) {
+            hipLaunchKernelGGL(k_sort_features, dim3(1), dim3(kSortThreads), 0, ctx->stream, ctx->d_slots, ctx->slots[slot].d, 1,
+                               calib);
+        } else {
+            hipLaunchKernelGGL(k_sort_features, dim3((unsigned)n_slots), dim3(kSortThreads), 0, ctx->stream, ctx->d_slots,
+                               SlotDesc{}, 0, calib);
+        }
+    }
     {
         ScopedTimer tm(ctx, 1);
         if (split) {
@@ -690,6 +709,7 @@ void mld_destroy(mld_ctx* ctx) {
     for (Slot& s : ctx->slots) {
         if (s.d.road_queue) (void)hipFree(s.d.road_queue);
         if (s.d.ovf_queue) (void)hipFree(s.d.ovf_queue);
+        if (s.d.perm) (void)hipFree(s.d.perm);
         void* ptrs[] = {s.d.map,  s.cloud_buf, s.uv_buf, s.depth_buf, s.type_buf, s.inl_buf,    s.mask_buf, s.cam,
                         s.img,    s.vis,       s.rank,   s.pidx,      s.img_vis,  s.block_sums, s.d_total};
         for (void* p : ptrs)

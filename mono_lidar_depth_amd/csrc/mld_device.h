@@ -61,6 +61,7 @@ struct SlotDesc {
     int32_t* road_count;          // number of queued pairs (zeroed before every CalculateDepth launch)
     int32_t* ovf_queue;           // (feature index, code) pairs queued for k_feature_wave (long lists)
     int32_t* ovf_count;
+    int32_t* perm;                // feature order of k_feature_main (features sorted by image row), or nullptr = as given
     double* corners;              // debug mode only: 9 x F triangle corners (NaN = none), written by k_feature_wave
     const long long* F_dev;       // optional device-side feature count (<= F); used when the count is produced on the GPU
     long long n;                  // points

@@ -7,6 +7,7 @@
 //   k_project_scatter : Transform_Cloud_LidarToCamera + getImagePoints + InitializeLidarProjection
 //                       (DepthEstimator.cpp:156-217, camera_pinhole.h:84-97, NeighborFinderPixel.cpp:29-58)
 //                       fused: one coalesced pass over the cloud, no intermediate arrays.
+//   k_sort_features   : row-order permutation of a frame's features (locality of the window scans and gathers).
 //   k_feature_main    : the per-feature loop (DepthEstimator.cpp:455-576), lane = feature, 256-thread blocks that
 //                       re-deal their live features to dense wavefronts after the window scan.
 //   k_feature_road    : the road fallback (DepthEstimator.cpp:578-597) for the features k_feature_main queued.
@@ -1782,6 +1783,81 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
     }
 }
 
+// Processing order of the features: sorted by image row (counting sort, one block per frame slot).  The result of a
+// feature does not depend on the order, but its memory traffic does: features are independent random pixels, and
+// handing the lanes of a wavefront features of the same rows makes their window scans, key lookups and point gathers
+// fall into the same DRAM pages and cache lines (measured: -6 % on k_feature_main, -12 % on k_feature_road).
+// perm[i] = index of the i-th feature in row order; ties in arbitrary order.
+constexpr int kSortThreads = 256;
+constexpr int kSortBuckets = 1024;
+constexpr int kSortKeep = 8;  // buckets per thread kept in registers between the two passes (2048 features per slot)
+__global__ __launch_bounds__(kSortThreads) void k_sort_features(const SlotDesc* __restrict__ slots, SlotDesc single,
+                                                                int use_single, Calib c) {
+    __shared__ int hist[kSortBuckets];
+    __shared__ int wsum[kSortThreads / kWave];
+    SlotDesc s = use_single ? single : slots[blockIdx.x];
+    if (!s.perm) return;
+    long long Fn = s.F;
+    if (s.F_dev) {
+        const long long fd = *GPTR(long long, s.F_dev);
+        Fn = fd < Fn ? fd : Fn;
+    }
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    for (int b = tid; b < kSortBuckets; b += kSortThreads) hist[b] = 0;
+    __syncthreads();
+    const auto* uv = GPTR(double, s.uv);
+    // bucket = image row scaled to the bucket count; non-finite / out-of-image rows go to the ends
+    const double scale = (double)kSortBuckets / (double)c.H;
+    auto bucket_of = [&](long long i) {
+        const double v = uv[2 * i + 1];
+        int b = 0;
+        if (v > 0.0) b = (v < (double)c.H) ? (int)(v * scale) : kSortBuckets - 1;
+        return b < kSortBuckets ? b : kSortBuckets - 1;
+    };
+    // the first kSortKeep buckets of a thread stay in registers for the scatter pass (a frame's worth of features)
+    int kept[kSortKeep];
+#pragma unroll
+    for (int q = 0; q < kSortKeep; q++) {
+        const long long i = tid + (long long)q * kSortThreads;
+        kept[q] = (i < Fn) ? bucket_of(i) : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < kSortKeep; q++)
+        if (kept[q] >= 0) atomicAdd(&hist[kept[q]], 1);
+    for (long long i = tid + (long long)kSortKeep * kSortThreads; i < Fn; i += kSortThreads) atomicAdd(&hist[bucket_of(i)], 1);
+    __syncthreads();
+    // exclusive scan of the bucket counts: 4 buckets per thread, wave scan, block offsets
+    constexpr int kPer = kSortBuckets / kSortThreads;
+    int loc[kPer], sum = 0;
+#pragma unroll
+    for (int q = 0; q < kPer; q++) {
+        loc[q] = hist[tid * kPer + q];
+        sum += loc[q];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == kWave - 1) wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int q = 0; q < wave; q++) base += wsum[q];
+#pragma unroll
+    for (int q = 0; q < kPer; q++) {
+        hist[tid * kPer + q] = base;
+        base += loc[q];
+    }
+    __syncthreads();
+    auto* perm = GPTRW(int32_t, s.perm);
+#pragma unroll
+    for (int q = 0; q < kSortKeep; q++)
+        if (kept[q] >= 0) perm[atomicAdd(&hist[kept[q]], 1)] = (int32_t)(tid + q * kSortThreads);
+    for (long long i = tid + (long long)kSortKeep * kSortThreads; i < Fn; i += kSortThreads)
+        perm[atomicAdd(&hist[bucket_of(i)], 1)] = (int32_t)i;
+}
+
 // Main kernel of the default configuration: 256 features per block.  After the window scan only the features that
 // still need work (enough neighbours for the histogram) are LIVE — about a third in a KITTI-like frame, where the
 // sky has no LiDAR returns — so the block re-deals them to dense wavefronts before the histogram / triangle / tail
@@ -1807,12 +1883,15 @@ __global__ __launch_bounds__(kMainThreads) void k_feature_main(const SlotDesc* _
     constexpr int kWaves = kMainThreads / kWave;
     uint32_t* lst_all = reinterpret_cast<uint32_t*>(smem);
     uint32_t* info = lst_all + kWaves * c.k1max * kWave;  // [kMainThreads] dealt slot -> (origin thread | k << 16)
-    int* wsum = reinterpret_cast<int*>(info + kMainThreads);
+    int32_t* fidx = reinterpret_cast<int32_t*>(info + kMainThreads);  // [kMainThreads] feature index of the scanning thread
+    int* wsum = reinterpret_cast<int*>(fidx + kMainThreads);
     uint32_t* lst = lst_all + wave * c.k1max * kWave;
     const bool active = f0 + tid < Fn;
+    // the feature this thread scans: the (f0 + tid)-th in row order
+    const long long fme = (active && s.perm) ? (long long)GPTR(int32_t, s.perm)[f0 + tid] : f0 + tid;
     double myu = 0, myv = 0;
     if (active) {
-        const auto* q = GPTR(double, s.uv) + 2 * (f0 + tid);
+        const auto* q = GPTR(double, s.uv) + 2 * fme;
         myu = q[0];
         myv = q[1];
     }
@@ -1844,21 +1923,22 @@ __global__ __launch_bounds__(kMainThreads) void k_feature_main(const SlotDesc* _
         nlive += t;
     }
     if (live) info[base + prefix_count(lm)] = (uint32_t)tid | ((uint32_t)k << 16);
+    fidx[tid] = (int32_t)fme;
     __syncthreads();
     // features finished (or handed on) by the scanning lane itself
     if (active && !live) {
-        GPTRW(double, s.depth)[f0 + tid] = -1.0;
-        if (s.type) GPTRW(int32_t, s.type)[f0 + tid] = mytype;
+        GPTRW(double, s.depth)[fme] = -1.0;
+        if (s.type) GPTRW(int32_t, s.type)[fme] = mytype;
     }
     enqueue_features(s.road_queue, s.road_count, road_on && active && !live && !overflow && mytype == MLD_HistogramNoLocalMax,
-                     lane, f0 + tid, mytype);
-    enqueue_features(s.ovf_queue, s.ovf_count, overflow, lane, f0 + tid, -1);
+                     lane, fme, mytype);
+    enqueue_features(s.ovf_queue, s.ovf_count, overflow, lane, fme, -1);
     if (wave * kWave >= nlive) return;  // nothing dealt to this wavefront (no barrier follows)
     // ---------------- dealt features: histogram, triangle, tail ----------------
     const bool has = tid < nlive;
     const uint32_t inf = has ? info[tid] : 0u;
     const int origin = (int)(inf & 0xFFFFu), kd = (int)(inf >> 16);
-    const long long f = f0 + origin;
+    const long long f = has ? (long long)fidx[origin] : 0;
     double u = 0, v = 0;
     if (has) {
         const auto* q = GPTR(double, s.uv) + 2 * f;
