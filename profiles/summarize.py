@@ -46,7 +46,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
     if not f_:
         continue
     df = pd.read_csv(f_)
-    df = df[df.Kernel_Name.str.contains("k_feature_main|k_feature_depth|k_project_scatter|k_feature_road|k_feature_wave")]
+    df = df[df.Kernel_Name.str.contains("k_feature_main|k_feature_depth|k_project_scatter|k_feature_road|k_feature_wave|k_sort_features")]
     df["k"] = df.Kernel_Name.str.extract(r"(k_\w+)")
     g = df.groupby(["k", "Counter_Name"]).Counter_Value.mean()
     for (k, c), v in g.items():
