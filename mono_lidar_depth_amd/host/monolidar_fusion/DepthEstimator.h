@@ -97,6 +97,43 @@ public:
     }
 };
 
+// DepthCalculationStatistics (DepthCalculationStatistics.h:11-260): per-call counters of the result types (cleared by
+// every CalculateDepth, DepthEstimator.cpp:445-446, counted by LogDepthCalcStats, :1039-1090) — same getter names.
+class DepthCalculationStatistics {
+public:
+    void Clear() { _c.fill(0); }
+    void SetFromTypes(const int32_t* types, int64_t n) {
+        _pointCount = (int)n;
+        mld_result_histogram(types, n, _c.data());
+    }
+    int getPointCount() const { return _pointCount; }
+    int getUnspecified() const { return (int)_c[Unspecified]; }
+    int getSuccess() const { return (int)_c[Success]; }
+    int getRadiusSearchInsufficientPoints() const { return (int)_c[RadiusSearchInsufficientPoints]; }
+    int getHistogramNoLocalMax() const { return (int)_c[HistogramNoLocalMax]; }
+    int getTresholdDepthGlobalGreaterMax() const { return (int)_c[TresholdDepthGlobalGreaterMax]; }
+    int getTresholdDepthGlobalSmallerMin() const { return (int)_c[TresholdDepthGlobalSmallerMin]; }
+    int getTresholdDepthLocalGreaterMax() const { return (int)_c[TresholdDepthLocalGreaterMax]; }
+    int getTresholdDepthLocalSmallerMin() const { return (int)_c[TresholdDepthLocalSmallerMin]; }
+    int getTriangleNotPlanar() const { return (int)_c[TriangleNotPlanar]; }
+    int getTriangleNotPlanarInsufficientPoints() const { return (int)_c[TriangleNotPlanarInsufficientPoints]; }
+    int getCornerBehindCamera() const { return (int)_c[CornerBehindCamera]; }
+    int getPlaneViewrayNotOrthogonal() const { return (int)_c[PlaneViewrayNotOrthogonal]; }
+    int getPCAIsPoint() const { return (int)_c[PcaIsPoint]; }
+    int getPCAIsLine() const { return (int)_c[PcaIsLine]; }
+    int getPCAIsCubic() const { return (int)_c[PcaIsCubic]; }
+    int getInsufficientRoadPoints() const { return (int)_c[InsufficientRoadPoints]; }
+    int getSuccessRoad() const { return (int)_c[SuccessRoad]; }
+    int getRegionGrowingNearestSeedNotAvailable() const { return (int)_c[RegionGrowingNearestSeedNotAvailable]; }
+    int getRegionGrowingSeedsOutOfRange() const { return (int)_c[RegionGrowingSeedsOutOfRange]; }
+    int getRegionGrowingInsufficientPoints() const { return (int)_c[RegionGrowingInsufficientPoints]; }
+    int getSuccessRegionGrowing() const { return (int)_c[SuccessRegionGrowing]; }
+
+private:
+    int _pointCount = 0;
+    std::array<int64_t, MLD_RESULT_TYPE_COUNT> _c{};
+};
+
 class GroundPlane {
 public:
     using Ptr = std::shared_ptr<GroundPlane>;
@@ -369,10 +406,12 @@ public:
                                             reinterpret_cast<int32_t*>(resultType.data()), _dbgCorners.data()));
             _dbgUv = points_image_cs;
             _dbgDepth = points_depths;
+            _depthCalcStats.SetFromTypes(reinterpret_cast<const int32_t*>(resultType.data()), F);
             return;
         }
         check(mld_calculate_depth(_ctx, 0, points_image_cs.data(), F, points_depths.data(),
                                   reinterpret_cast<int32_t*>(resultType.data())));
+        _depthCalcStats.SetFromTypes(reinterpret_cast<const int32_t*>(resultType.data()), F);
     }
     std::pair<DepthResultType, double> CalculateDepth(const std::array<double, 2>& point_image_cs,
                                                       const GroundPlane::Ptr& ransacPlane) {
@@ -394,10 +433,13 @@ public:
         points_depths.resize(F);
         resultType.resize(F);
         check(mld_calculate_depth(_ctx, 0, points_image_cs.data(), F, points_depths.data(), resultType.data()));
+        _depthCalcStats.SetFromTypes(resultType.data(), F);
     }
 #endif
 
-    // DepthCalculationStatistics counterpart
+    // getDepthCalcStats (DepthEstimator.cpp:400-402): the counters of the last CalculateDepth call
+    const DepthCalculationStatistics& getDepthCalcStats() { return _depthCalcStats; }
+    // histogram of an arbitrary result-type array
     static std::array<int64_t, MLD_RESULT_TYPE_COUNT> getDepthCalcStats(const std::vector<int>& resultType) {
         std::array<int64_t, MLD_RESULT_TYPE_COUNT> c{};
         mld_result_histogram(reinterpret_cast<const int32_t*>(resultType.data()), (int64_t)resultType.size(), c.data());
@@ -419,6 +461,7 @@ private:
         q.intensity = 1;
         cloud.points.push_back(q);
     }
+    DepthCalculationStatistics _depthCalcStats;
     bool _debugMode = false;
     std::vector<double> _dbgCorners, _dbgUv, _dbgDepth;
     int _device;

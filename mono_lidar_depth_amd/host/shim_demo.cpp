@@ -62,6 +62,11 @@ int main(int argc, char** argv) {
         out.write(reinterpret_cast<const char*>(depths.data()), (std::streamsize)(depths.size() * sizeof(double)));
         out.write(reinterpret_cast<const char*>(types.data()), (std::streamsize)(types.size() * sizeof(int)));
         auto stats = DepthEstimator::getDepthCalcStats(types);
+        const DepthCalculationStatistics& st = est.getDepthCalcStats();
+        if (st.getPointCount() != (int)types.size() || st.getSuccess() != (int)stats[Success] ||
+            st.getSuccessRoad() != (int)stats[SuccessRoad] ||
+            st.getRadiusSearchInsufficientPoints() != (int)stats[RadiusSearchInsufficientPoints])
+            throw std::runtime_error("getDepthCalcStats() disagrees with the result types");
         std::cout << "features " << types.size() << " success " << stats[Success] << " road " << stats[SuccessRoad]
                   << " insufficient " << stats[RadiusSearchInsufficientPoints] << "\n";
         // debug mode: same results, plus the debug clouds of the reference's getters

@@ -215,6 +215,11 @@ public:
         return std::make_pair(success, failed);
     }
 
+    // tracklet_depth_module.h:109-123
+    const Mono_Lidar::DepthCalculationStatistics& getDepthCalcStats() { return _depthEstimator.getDepthCalcStats(); }
+    void getCloudCameraCs(Cloud::Ptr& pointCloud_cam_cs) { _depthEstimator.getCloudCameraCs(pointCloud_cam_cs); }
+    void getCloudInterpolated(Cloud::Ptr& pointCloud_interpolated) { _depthEstimator.getCloudInterpolated(pointCloud_interpolated); }
+    void getPointsCloudImageCs(std::vector<double>& visiblePointsImageCs) { _depthEstimator.getPointsCloudImageCs(visiblePointsImageCs); }
     size_t trackletCount() const { return _trackletMap.size(); }
     Mono_Lidar::DepthEstimator& depthEstimator() { return _depthEstimator; }
 
