@@ -136,6 +136,7 @@ class DepthEstimator:
         self._keepalive = {}
         self._debug = False
         self._debug_last = None
+        self._last_types = None
 
     # ------------------------------------------------------------------ lifecycle
     def InitConfig(self, parameters=None, printparams: bool = False) -> bool:
@@ -410,6 +411,7 @@ class DepthEstimator:
         else:
             self._check(self._lib.mld_calculate_depth(self._ctx, slot, uvh.ctypes.data, F, depth.ctypes.data,
                                                       types.ctypes.data))
+        self._last_types = types
         return (depth, types) if return_types else depth
 
     # ------------------------------------------------------------------ debug mode
@@ -535,6 +537,16 @@ class DepthEstimator:
         counts = (C.c_int64 * capi.MLD_RESULT_TYPE_COUNT)()
         capi.load().mld_result_histogram(t.ctypes.data, int(t.size), counts)
         return np.array(list(counts), dtype=np.int64)
+
+    def getDepthCalcStats(self) -> dict:
+        """getDepthCalcStats (DepthEstimator.cpp:400-402): result-type counters of the last host-input CalculateDepth
+        call, keyed by the DepthResultType names, plus "PointCount"."""
+        if self._last_types is None:
+            return {"PointCount": 0}
+        counts = self.resultHistogram(self._last_types)
+        out = {capi.RESULT_TYPE_NAMES[i]: int(c) for i, c in enumerate(counts)}
+        out["PointCount"] = int(self._last_types.size)
+        return out
 
     # ------------------------------------------------------------------ measurement hooks
     def timingEnable(self, on: bool = True):

@@ -103,3 +103,17 @@ def test_ground_plane_cloud_without_plane_is_empty():
     est = make_estimator(P)
     est.setInputCloud(cloud, NO_PLANE)
     assert est.getCloudRansacPlane().shape == (3, 0)
+
+
+def test_depth_calc_stats_follow_the_last_call():
+    P = capi.params_c0()
+    cloud, uv, plane = _frame(35)
+    est = make_estimator(P)
+    assert est.getDepthCalcStats() == {"PointCount": 0}
+    d, t = est.CalculateDepth(cloud, uv, GroundPlane(*plane))
+    st = est.getDepthCalcStats()
+    assert st["PointCount"] == uv.shape[0]
+    assert st["Success"] == int((t == 1).sum()) and st["SuccessRoad"] == int((t == 16).sum())
+    assert sum(v for k, v in st.items() if k != "PointCount") == uv.shape[0]
+    d, t = est.CalculateDepth(uv[:37])
+    assert est.getDepthCalcStats()["PointCount"] == 37
