@@ -435,6 +435,26 @@ public:
         check(mld_calculate_depth(_ctx, 0, points_image_cs.data(), F, points_depths.data(), resultType.data()));
         _depthCalcStats.SetFromTypes(resultType.data(), F);
     }
+    // feature-only overloads (DepthEstimator.cpp:421-488)
+    void CalculateDepth(const Eigen::Matrix2Xd& featurePoints_image_cs, Eigen::VectorXd& points_depths,
+                        const GroundPlane::Ptr& ransacPlane) {
+        Eigen::VectorXi types;
+        CalculateDepth(featurePoints_image_cs, points_depths, types, ransacPlane);
+    }
+    void CalculateDepth(const Eigen::Matrix2Xd& featurePoints_image_cs, Eigen::VectorXd& points_depths,
+                        Eigen::VectorXi& resultType, const GroundPlane::Ptr& ransacPlane) {
+        if (!_isInitializedPointCloud) throw "call of 'CalculateDepth' without 'SetInputCloud'";
+        if (ransacPlane == nullptr && _parameters->do_use_ransac_plane)
+            check(mld_set_ground_plane(_ctx, 0, nullptr, nullptr, 0));
+        const int64_t F = featurePoints_image_cs.cols();
+        points_depths.resize(F);
+        resultType.resize(F);
+        check(mld_calculate_depth(_ctx, 0, featurePoints_image_cs.data(), F, points_depths.data(), resultType.data()));
+        _depthCalcStats.SetFromTypes(resultType.data(), F);
+    }
+    std::pair<DepthResultType, double> CalculateDepth(const Eigen::Vector2d& point_image_cs, const GroundPlane::Ptr& ransacPlane) {
+        return CalculateDepth(std::array<double, 2>{point_image_cs.x(), point_image_cs.y()}, ransacPlane);
+    }
 #endif
 
     // getDepthCalcStats (DepthEstimator.cpp:400-402): the counters of the last CalculateDepth call
