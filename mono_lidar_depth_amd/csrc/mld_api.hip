@@ -39,6 +39,7 @@ struct Slot {
     uint32_t* mask_buf = nullptr;
     size_t mask_words = 0;
     size_t road_cap = 0;  // entries of d.road_queue
+    bool queues_in_slab = false;  // road_queue / ovf_queue / perm are carved out of mld_ctx::queue_slab
     // lazy PointcloudData for the debug getters
     bool full_valid = false;
     size_t dbg_cap = 0;
@@ -73,12 +74,21 @@ struct mld_ctx {
     int32_t* road_counts = nullptr;  // per-slot queue lengths (road fallback, then long-list overflow), contiguous,
                                      // placed in front of the bitmaps so that one fill clears both
     bool counters_clean = false;
+    // One allocation per kind for all slots instead of one per slot: a 1024-slot context would otherwise hold 4096
+    // small mappings, and the gathers of the feature kernels would walk as many page-table fragments.
+    uint32_t* map_slab = nullptr;    // pixel maps of all slots
+    int32_t* queue_slab = nullptr;   // per slot: road queue (2F), overflow queue (2F), perm (F)
     uint32_t* bitmaps = nullptr;  // occupancy bitmaps of all slots, contiguous
     size_t bitmap_words = 0;      // per slot
     std::vector<SlotDesc> h_descs;
     size_t lds_bytes = 0;
     size_t lds_main = 0;  // k_feature_main: four per-wave index lists + the dealing table
     int k_main = 24;      // list capacity of k_feature_main (narrow window); the road kernel keeps calib.k1max
+    size_t lds_fused = 0;     // k_feature_fused: wide list + narrow list per wave
+    size_t lds_classify = 0;  // k_classify: bucket counters + the slot's bitmap
+    bool classify_staged = true;  // the bitmap fits the LDS budget of k_classify
+    int bm_ncol = 0, bm_ncolp = 0;  // bitmap word columns (incl. the slack column) / padded LDS row length
+    bool legacy_split = false;    // A/B builds only: k_sort_features + k_feature_main + k_feature_road
     bool sort_features = true;  // k_sort_features before k_feature_main (MLD_NO_SORT=1 switches it off)
     std::string err;
     // ground-plane estimation scratch (device)
@@ -275,6 +285,18 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
         ctx->sort_features = !(nosort && nosort[0] == '1');
     }
     ctx->lds_main = (size_t)(kMainThreads / kWave) * ctx->k_main * kWave * sizeof(uint32_t) + 2 * kMainThreads * sizeof(uint32_t) + 64;
+    c.kMain = ctx->k_main;
+    ctx->lds_fused = (size_t)(c.k1max + c.kMain) * kWave * sizeof(uint32_t);
+    ctx->bm_ncol = (ctx->cam.width + 31) / 32 + 1;
+    ctx->bm_ncolp = ctx->bm_ncol | 1;
+    const size_t cls_fixed = (size_t)(kClsBuckets + kClsThreads / kWave + 4) * sizeof(int);
+    const size_t cls_bitmap = (size_t)c.bmStride * (size_t)ctx->bm_ncolp * sizeof(uint32_t);
+    ctx->classify_staged = cls_fixed + cls_bitmap <= 128 * 1024;
+    ctx->lds_classify = cls_fixed + (ctx->classify_staged ? cls_bitmap : 0);
+    {
+        const char* leg = std::getenv("MLD_LEGACY_SPLIT");
+        ctx->legacy_split = leg && leg[0] == '1';
+    }
 }
 
 int check_slot(mld_ctx* ctx, int slot) {
@@ -390,14 +412,20 @@ int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int sl
 int ensure_road_queue(mld_ctx* ctx, Slot& s, int64_t F) {
     if ((size_t)F <= s.road_cap) return MLD_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (s.d.road_queue) HIP_TRY(ctx, hipFree(s.d.road_queue));
-    if (s.d.ovf_queue) HIP_TRY(ctx, hipFree(s.d.ovf_queue));
-    if (s.d.perm) HIP_TRY(ctx, hipFree(s.d.perm));
+    if (!s.queues_in_slab) {
+        if (s.d.road_queue) HIP_TRY(ctx, hipFree(s.d.road_queue));
+        if (s.d.ovf_queue) HIP_TRY(ctx, hipFree(s.d.ovf_queue));
+        if (s.d.perm) HIP_TRY(ctx, hipFree(s.d.perm));
+        if (s.d.live_queue) HIP_TRY(ctx, hipFree(s.d.live_queue));
+    }
+    s.queues_in_slab = false;
+    s.d.live_queue = nullptr;
     s.d.road_queue = nullptr;
     s.d.ovf_queue = nullptr;
     s.d.perm = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&s.d.road_queue, (size_t)F * 2 * sizeof(int32_t)));
     HIP_TRY(ctx, hipMalloc((void**)&s.d.ovf_queue, (size_t)F * 2 * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&s.d.live_queue, (size_t)F * sizeof(int32_t)));
     if (ctx->sort_features && ctx->calib.splitRoad) HIP_TRY(ctx, hipMalloc((void**)&s.d.perm, (size_t)F * sizeof(int32_t)));
     s.road_cap = (size_t)F;
     return MLD_OK;
@@ -409,6 +437,36 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     int per_slot = (int)((max_F + kWave - 1) / kWave);
     const bool split = calib.splitRoad != 0;
     const uint32_t tag_all = single ? 0u : common_tag(ctx, n_slots);
+    if (!ctx->legacy_split) {
+        // classify (per slot) -> fused dense kernel over the live queues -> wave kernel over the overflow queues;
+        // k_classify sets both queue lengths, so no counter needs clearing
+        ctx->counters_clean = false;
+        {
+            ScopedTimer ts(ctx, 5);
+            auto kc = ctx->classify_staged ? mld::k_classify<true> : mld::k_classify<false>;
+            hipLaunchKernelGGL(kc, dim3(single ? 1u : (unsigned)n_slots), dim3(kClsThreads), ctx->lds_classify, ctx->stream,
+                               ctx->d_slots, single ? ctx->slots[slot].d : SlotDesc{}, single ? 1 : 0, calib, ctx->bm_ncol,
+                               ctx->bm_ncolp);
+        }
+        if (calib.threadPath) {
+            ScopedTimer tm(ctx, 1);
+            auto kf = calib.roadMode ? mld::k_feature_fused<1> : mld::k_feature_fused<0>;
+            const unsigned grid = single ? (unsigned)per_slot : (unsigned)per_slot * (unsigned)n_slots;
+            hipLaunchKernelGGL(kf, dim3(grid), dim3(kWave), ctx->lds_fused, ctx->stream, ctx->d_slots,
+                               single ? ctx->slots[slot].d : SlotDesc{}, single ? 1 : 0, calib, single ? 1 : n_slots, per_slot,
+                               tag_all);
+        }
+        {
+            ScopedTimer tm(ctx, 3);
+            // a batch gets 4 blocks per slot, a single slot up to 256: each block strides over the slot's queue
+            const int pw = single ? std::min(per_slot, 256) : std::min(per_slot, 4);
+            hipLaunchKernelGGL(k_feature_wave, dim3(single ? (unsigned)pw : (unsigned)pw * n_slots), dim3(kWave), ctx->lds_bytes,
+                               ctx->stream, ctx->d_slots, single ? ctx->slots[slot].d : SlotDesc{}, single ? 1 : 0, calib,
+                               single ? 1 : n_slots, pw, tag_all);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+        return MLD_OK;
+    }
     // queue lengths must be zero at launch; a batched setInputCloud has just cleared them with the bitmaps
     if (!ctx->counters_clean)
         HIP_TRY(ctx, hipMemsetAsync(ctx->road_counts, 0, sizeof(int32_t) * 2 * ctx->slots.size(), ctx->stream));
@@ -658,6 +716,19 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
         if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute");
     }
+    if (ctx->lds_classify > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_classify<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_classify);
+        if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute(k_classify)");
+    }
+    if (ctx->lds_fused > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_feature_fused<0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_fused);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_feature_fused<1>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_fused);
+        if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute(k_feature_fused)");
+    }
     ctx->slots.resize(max_frames);
     ctx->h_descs.resize(max_frames);
     if ((e = hipMalloc((void**)&ctx->d_slots, sizeof(SlotDesc) * max_frames)) != hipSuccess)
@@ -676,13 +747,33 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     for (size_t si = 0; si < ctx->slots.size(); si++) ctx->slots[si].d.bitmap = ctx->bitmaps + si * ctx->bitmap_words;
     for (size_t si = 0; si < ctx->slots.size(); si++) {
         ctx->slots[si].d.road_count = ctx->road_counts + si;
+        ctx->slots[si].d.live_count = ctx->road_counts + si;  // the legacy road queue and the live queue never coexist
         ctx->slots[si].d.ovf_count = ctx->road_counts + (size_t)max_frames + si;
     }
-    for (Slot& s : ctx->slots) {
-        if ((e = hipMalloc((void**)&s.d.map, cells * sizeof(uint32_t))) != hipSuccess) return hip_bail(e, "hipMalloc(map)");
-        if ((e = hipMemsetAsync(s.d.map, 0, cells * sizeof(uint32_t), ctx->stream)) != hipSuccess)
-            return hip_bail(e, "hipMemset(map)");
+    const size_t map_stride = (cells + 63) & ~(size_t)63;  // words; slots start on 256-byte boundaries
+    if ((e = hipMalloc((void**)&ctx->map_slab, map_stride * (size_t)max_frames * sizeof(uint32_t))) != hipSuccess)
+        return hip_bail(e, "hipMalloc(maps)");
+    if ((e = hipMemsetAsync(ctx->map_slab, 0, map_stride * (size_t)max_frames * sizeof(uint32_t), ctx->stream)) != hipSuccess)
+        return hip_bail(e, "hipMemset(maps)");
+    const size_t qF = max_features > 0 ? (((size_t)max_features + 63) & ~(size_t)63) : 0;  // queue entries per slot
+    const bool want_perm = ctx->sort_features && ctx->calib.splitRoad;
+    const size_t q_stride = qF * (want_perm ? 6 : 5);  // int32 words per slot
+    if (qF && (e = hipMalloc((void**)&ctx->queue_slab, q_stride * (size_t)max_frames * sizeof(int32_t))) != hipSuccess)
+        return hip_bail(e, "hipMalloc(queues)");
+    for (size_t si = 0; si < ctx->slots.size(); si++) {
+        Slot& s = ctx->slots[si];
+        s.d.map = ctx->map_slab + si * map_stride;
         s.d.tag = 0;
+        if (qF) {
+            // work queues of the feature kernels: no allocation in the first CalculateDepth
+            int32_t* q = ctx->queue_slab + si * q_stride;
+            s.d.road_queue = q;
+            s.d.ovf_queue = q + 2 * qF;
+            s.d.live_queue = q + 4 * qF;
+            s.d.perm = want_perm ? q + 5 * qF : nullptr;
+            s.road_cap = qF;
+            s.queues_in_slab = true;
+        }
         if (max_points > 0) {
             if ((e = hipMalloc((void**)&s.cloud_buf, (size_t)max_points * 32)) != hipSuccess)
                 return hip_bail(e, "hipMalloc(cloud)");
@@ -694,8 +785,6 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
             if ((e = hipMalloc((void**)&s.depth_buf, F * sizeof(double))) != hipSuccess) return hip_bail(e, "hipMalloc(depth)");
             if ((e = hipMalloc((void**)&s.type_buf, F * sizeof(int32_t))) != hipSuccess) return hip_bail(e, "hipMalloc(type)");
             s.feat_cap = F;
-            // work queues of the feature kernels: no allocation in the first CalculateDepth
-            if (ensure_road_queue(ctx, s, (int64_t)F) != MLD_OK) return hip_bail(hipErrorOutOfMemory, "hipMalloc(queues)");
         }
     }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return hip_bail(e, "hipStreamSynchronize");
@@ -707,14 +796,19 @@ void mld_destroy(mld_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (Slot& s : ctx->slots) {
-        if (s.d.road_queue) (void)hipFree(s.d.road_queue);
-        if (s.d.ovf_queue) (void)hipFree(s.d.ovf_queue);
-        if (s.d.perm) (void)hipFree(s.d.perm);
-        void* ptrs[] = {s.d.map,  s.cloud_buf, s.uv_buf, s.depth_buf, s.type_buf, s.inl_buf,    s.mask_buf, s.cam,
-                        s.img,    s.vis,       s.rank,   s.pidx,      s.img_vis,  s.block_sums, s.d_total};
+        if (!s.queues_in_slab) {
+            if (s.d.road_queue) (void)hipFree(s.d.road_queue);
+            if (s.d.ovf_queue) (void)hipFree(s.d.ovf_queue);
+            if (s.d.perm) (void)hipFree(s.d.perm);
+            if (s.d.live_queue) (void)hipFree(s.d.live_queue);
+        }
+        void* ptrs[] = {s.cloud_buf, s.uv_buf, s.depth_buf, s.type_buf, s.inl_buf,    s.mask_buf, s.cam,
+                        s.img,       s.vis,    s.rank,      s.pidx,     s.img_vis,    s.block_sums, s.d_total};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
     }
+    if (ctx->map_slab) (void)hipFree(ctx->map_slab);
+    if (ctx->queue_slab) (void)hipFree(ctx->queue_slab);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->dummy) (void)hipFree(ctx->dummy);
     if (ctx->road_counts) (void)hipFree(ctx->road_counts);  // also holds the bitmaps
@@ -1461,3 +1555,16 @@ int mld_kernel_time_ms(mld_ctx* ctx, int which, double* avg_ms, int64_t* launche
 }
 
 }  // extern "C"
+
+#ifdef MLD_STAMPS
+// Diagnostic build only: read and clear the per-wave phase stamps of the feature kernels (2 x 32768 x 16 uint32).
+extern "C" int mld_debug_read_stamps(unsigned* out) {
+    const size_t bytes = sizeof(unsigned) * 2 * mld::kStampWaves * 16;
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(mld::g_stamps), bytes);
+    void* sym = nullptr;
+    if (e == hipSuccess) e = hipGetSymbolAddress(&sym, HIP_SYMBOL(mld::g_stamps));
+    if (e == hipSuccess) e = hipMemset(sym, 0, bytes);
+    return e == hipSuccess ? 0 : -7;
+}
+#endif

@@ -43,6 +43,7 @@ struct Calib {
     int usePCA;
     int bmStride;    // words per 32-pixel column of the occupancy bitmap (word = (x >> 5) * bmStride + y): H + slack
     int k1max;       // thread path: neighbour list capacity per feature (entries in LDS)
+    int kMain;       // fused kernel: capacity of the narrow-window list
     int splitRoad;   // 1: the thread path queues road-fallback candidates for k_feature_road instead of running them inline
     int xcdAware;    // 1: blocks of one slot are congruent mod 8 (same XCD under round-robin dispatch)
     int threadPath;  // 1: thread-per-feature fast path with wave-cooperative overflow; 0: wave path only
@@ -62,6 +63,8 @@ struct SlotDesc {
     int32_t* ovf_queue;           // (feature index, code) pairs queued for k_feature_wave (long lists)
     int32_t* ovf_count;
     int32_t* perm;                // feature order of k_feature_main (features sorted by image row), or nullptr = as given
+    int32_t* live_queue;          // indices of the features k_classify found live, sorted by image row
+    int32_t* live_count;          // their number
     double* corners;              // debug mode only: 9 x F triangle corners (NaN = none), written by k_feature_wave
     const long long* F_dev;       // optional device-side feature count (<= F); used when the count is produced on the GPU
     long long n;                  // points

@@ -35,6 +35,50 @@ namespace mld {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
 
+// Diagnostic build only (-DMLD_STAMPS, profiles/tools): s_memtime stamps around the phases of the feature kernels,
+// summed over all wavefronts into g_stamps[kernel][phase].  The product build compiles none of this.
+#ifdef MLD_STAMPS
+constexpr int kStampWaves = 32768;  // per-wave slots (no atomics: contended adds would distort what they measure)
+__device__ unsigned g_stamps[2][kStampWaves][16];
+struct Stamps {
+    unsigned long long last;
+    unsigned acc[16];
+    int kern;
+    __device__ __forceinline__ void begin(int k) {
+        kern = k;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = 0;
+        last = __builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void mark(int i) {
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        acc[i] += (unsigned)(t - last);
+        last = t;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void flush() {
+        const unsigned w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63) == 0 && kern < 2 && w < (unsigned)kStampWaves) {
+#pragma unroll
+            for (int i = 0; i < 15; i++) g_stamps[kern][w][i] += acc[i];
+            g_stamps[kern][w][15] += 1u;
+        }
+    }
+};
+#define ST_ARG , Stamps& st
+#define ST_PASS , st
+#define ST_MARK(i) st.mark(i)
+#define ST_USE_F64(x) asm volatile("" ::"v"(x))
+#define ST_USE_U32(x) asm volatile("" ::"v"(x))
+#else
+#define ST_ARG
+#define ST_PASS
+#define ST_MARK(i)
+#define ST_USE_F64(x)
+#define ST_USE_U32(x)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
 // ------------------------------------------------------------------------------------------------
@@ -585,6 +629,96 @@ __device__ void jacobi_eig3(const double s[6], double ev[3], V3& n0) {
     n0.z = (i0 == 0) ? v[2][0] : ((i0 == 1) ? v[2][1] : v[2][2]);
 }
 
+// ---- reduced-cost arithmetic for the ROAD path only ------------------------------------------------------------
+// The road / PCA results are held to the 1e-4 m tolerance, not to bit-exactness (their sums are reordered anyway), so
+// the M-estimator replaces IEEE divisions and square roots (30-40 instructions each in f64) by the hardware
+// reciprocal / reciprocal-square-root estimates refined with two Newton steps (relative error ~1e-16).
+__device__ __forceinline__ double fast_rcp(double d) {
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    return x;
+}
+__device__ __forceinline__ double fast_rsq(double d) {  // d in (0, inf)
+    double y = __builtin_amdgcn_rsq(d);
+    double h = 0.5 * d;
+    double e = fma(-h * y, y, 0.5);  // 0.5 - 0.5 d y^2
+    y = fma(y, e, y);
+    e = fma(-h * y, y, 0.5);
+    y = fma(y, e, y);
+    return y;
+}
+__device__ __forceinline__ V3 fast_normalized(V3 a) {
+    const double z = vsqnorm(a);
+    if (z > 0.0) return vscale(a, fast_rsq(z));
+    return a;
+}
+
+// Cyclic Jacobi as jacobi_eig3 below, with the rotation angles from fast_rcp / fast_rsq: the rotations stay
+// orthogonal to rounding, the sweeps converge as before.
+__device__ void jacobi_eig3_fast(const double s[6], double ev[3], V3& n0) {
+    double a[3][3] = {{s[0], s[1], s[2]}, {s[1], s[3], s[4]}, {s[2], s[4], s[5]}};
+    double v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 64; sweep++) {
+        double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
+        double diag = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
+        if (!(off > 1e-300) || off <= 1e-30 * diag) break;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+#pragma unroll
+            for (int q = p + 1; q < 3; q++) {
+                const double apq = a[p][q];
+                const bool rot = apq != 0.0;
+                const double theta = (a[q][q] - a[p][p]) * 0.5 * fast_rcp(rot ? apq : 1.0);
+                const double r = fabs(theta);
+                // sqrt(theta^2 + 1) = |theta| to double precision beyond 1e8 (and theta^2 may overflow)
+                const double x = fma(r < 1e100 ? r : 1.0, r < 1e100 ? r : 1.0, 1.0);
+                const double root = r < 1e100 ? x * fast_rsq(x) : r;
+                double t = fast_rcp(r + root);
+                t = theta >= 0 ? t : -t;
+                double cs = fast_rsq(fma(t, t, 1.0)), sn = t * cs;
+                cs = rot ? cs : 1.0;
+                sn = rot ? sn : 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double akp = a[k][p], akq = a[k][q];
+                    a[k][p] = cs * akp - sn * akq;
+                    a[k][q] = sn * akp + cs * akq;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double apk = a[p][k], aqk = a[q][k];
+                    a[p][k] = cs * apk - sn * aqk;
+                    a[q][k] = sn * apk + cs * aqk;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double vkp = v[k][p], vkq = v[k][q];
+                    v[k][p] = cs * vkp - sn * vkq;
+                    v[k][q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    double d0 = a[0][0], d1 = a[1][1], d2 = a[2][2];
+    int i0 = 0;
+    if (d1 < d0) {
+        d0 = d1;
+        i0 = 1;
+    }
+    if (d2 < d0) {
+        d0 = d2;
+        i0 = 2;
+    }
+    ev[0] = d0;
+    ev[1] = 0;
+    ev[2] = 0;
+    n0.x = (i0 == 0) ? v[0][0] : ((i0 == 1) ? v[0][1] : v[0][2]);
+    n0.y = (i0 == 0) ? v[1][0] : ((i0 == 1) ? v[1][1] : v[1][2]);
+    n0.z = (i0 == 0) ? v[2][0] : ((i0 == 1) ? v[2][1] : v[2][2]);
+}
+
 struct Plane {
     V3 n;
     double offset;
@@ -809,6 +943,36 @@ __device__ __forceinline__ void finish_road(const Calib& c, bool triangle, doubl
     int type = MLD_SuccessRoad;
     int t = apply_thresholds(c, r[9], r[10], depth);
     if (t) type = t;
+    out_type = type;
+    out_depth = (type == MLD_SuccessRoad) ? depth : -1.0;
+}
+
+// The M-estimator tail of finish_road with the reduced-cost arithmetic (thread path; results within the road
+// tolerance of the exact form).  r[0..2]: weighted centre, r[3..8]: weighted scatter, r[9], r[10]: min / max z.
+__device__ __forceinline__ void finish_road_fast(const Calib& c, double u, double v, const double r[kRecFields],
+                                                 int& out_type, double& out_depth) {
+    // CameraPinhole::getViewingRays + flip (camera_pinhole.h:52-69, DepthEstimator.cpp:938-939)
+    V3 d = {(c.Kinv[0] * u + c.Kinv[1] * v) + c.Kinv[2], (c.Kinv[3] * u + c.Kinv[4] * v) + c.Kinv[5],
+            (c.Kinv[6] * u + c.Kinv[7] * v) + c.Kinv[8]};
+    d = fast_normalized(d);
+    if (d.z < 0) d = vscale(d, -1.0);
+    const V3 center = {r[0], r[1], r[2]};
+    double ev[3];
+    V3 n0;
+    jacobi_eig3_fast(&r[3], ev, n0);
+    if (isnan(center.x) || isnan(center.y) || isnan(center.z)) {
+        const double qn = __builtin_nan("");
+        n0 = {qn, qn, qn};
+    }
+    n0 = fast_normalized(n0);
+    const double offset = -vdot(n0, center);
+    // ParametrizedLine::Through(n0 = direction, n1 = support = 0): origin d, direction (0 - d).normalized()
+    const V3 dir = fast_normalized(vscale(d, -1.0));
+    const double t = -(offset + vdot(n0, d)) * fast_rcp(vdot(n0, dir));
+    double depth = d.z + dir.z * t;
+    int type = MLD_SuccessRoad;
+    const int th = apply_thresholds(c, r[9], r[10], depth);
+    if (th) type = th;
     out_type = type;
     out_depth = (type == MLD_SuccessRoad) ? depth : -1.0;
 }
@@ -1096,7 +1260,7 @@ __device__ __forceinline__ V3 raw_point(const Calib& c, RawP r) { return lidar_t
 // tells which cells to fetch.  Pass 1 appends the CELL indices of the set bits (row-major order) to the lane's
 // list; pass 2 turns them into point indices with batched key loads.  Windows up to 32 cells wide.
 __device__ __forceinline__ int scan_window_bitmap(const Calib& c, const SlotDesc& s, int x0, int y0, int nx, int ny,
-                                                  uint32_t* lst, int lane) {
+                                                  uint32_t* lst, int lane ST_ARG) {
     const int nymax = uniform(wave_max_i32(ny));
     const auto* bm = GPTR(uint32_t, s.bitmap);
     const unsigned long long colmask = (nx >= 64) ? ~0ull : ((1ull << nx) - 1ull);
@@ -1119,6 +1283,11 @@ __device__ __forceinline__ int scan_window_bitmap(const Calib& c, const SlotDesc
                 }
             }
         }
+        ST_USE_U32(a[0][0]);
+        ST_USE_U32(b2[0][0]);
+        ST_USE_U32(a[1][0]);
+        ST_USE_U32(b2[1][0]);
+        ST_MARK(2);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             if (r0 + q < nymax) {
@@ -1135,6 +1304,7 @@ __device__ __forceinline__ int scan_window_bitmap(const Calib& c, const SlotDesc
         }
     }
     // cell index -> original point index (every set bit has a key of the current tag)
+    ST_MARK(3);
     const int kk = k <= c.k1max ? k : 0;  // overflowing lists (k > k1max) are redone by the wave path
     const int kmax = uniform(wave_max_i32(kk));
     const auto* mp = GPTR(uint32_t, s.map);
@@ -1146,13 +1316,14 @@ __device__ __forceinline__ int scan_window_bitmap(const Calib& c, const SlotDesc
         for (int q = 0; q < kKeyBatch; q++)
             if (e0 + q < kk) LST(e0 + q) = kIdxMask - (key[q] & kIdxMask);
     }
+    ST_MARK(4);
     return k;
 }
 
 // Row-major window scan by one thread (NeighborFinderPixel.cpp:60-95): appends the original indices of the
 // occupied cells to the thread's LDS list.  Returns the count (may exceed c.k1max: overflow).
 __device__ __forceinline__ int scan_window_thread(const Calib& c, const SlotDesc& s, double u, double v, double halfX, double halfY,
-                                  bool active, uint32_t* lst, int lane) {
+                                  bool active, uint32_t* lst, int lane ST_ARG) {
     int x0 = 0, y0 = 0, nx = 0, ny = 0;
     if (active && isfinite(u) && isfinite(v)) {
         double a;
@@ -1175,7 +1346,7 @@ __device__ __forceinline__ int scan_window_thread(const Calib& c, const SlotDesc
         }
     }
     const int nxmax = uniform(wave_max_i32(nx));
-    if (nxmax <= 32) return scan_window_bitmap(c, s, x0, y0, nx, ny, lst, lane);
+    if (nxmax <= 32) return scan_window_bitmap(c, s, x0, y0, nx, ny, lst, lane ST_PASS);
     // windows wider than 32 cells (non-default parameters): every lane with a window reports an overflowing list,
     // which sends its feature to the wave-cooperative kernel
     return (nx > 0) ? c.k1max + 1 : 0;
@@ -1322,12 +1493,25 @@ __device__ __forceinline__ void enqueue_features(int32_t* queue, int32_t* count,
 // path's result (resultOld) on entry.  Lanes whose wide-window list exceeds the capacities set `overflow`.
 // ROAD_MODE: 0 = M-estimator, 1 = max-spanning triangle, -1 = decided at run time (c.roadMode).
 template <int ROAD_MODE>
+__device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, bool cand,
+                                                const int k2, const double myu, const double myv, int& mytype,
+                                                double& mydepth, bool& overflow ST_ARG);
+
+template <int ROAD_MODE>
 __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, bool cand,
                                             const double myu, const double myv, int& mytype, double& mydepth,
-                                            bool& overflow) {
+                                            bool& overflow ST_ARG) {
+    const int k2 = scan_window_thread(c, s, myu, myv, c.halfX2, c.halfY2, cand, lst, lane ST_PASS);
+    road_after_scan<ROAD_MODE>(c, s, lst, lane, cand, k2, myu, myv, mytype, mydepth, overflow ST_PASS);
+}
+
+// The road fallback once the wide-window list (k2 entries, original point indices in the low 24 bits) is in `lst`.
+template <int ROAD_MODE>
+__device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, bool cand,
+                                                const int k2, const double myu, const double myv, int& mytype,
+                                                double& mydepth, bool& overflow ST_ARG) {
     const int roadMode = ROAD_MODE >= 0 ? ROAD_MODE : c.roadMode;
     const int resultOld = mytype;
-    int k2 = scan_window_thread(c, s, myu, myv, c.halfX2, c.halfY2, cand, lst, lane);
     if (cand && k2 > c.k1max) {
         overflow = true;
         cand = false;
@@ -1345,7 +1529,9 @@ __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, u
     double zmn = 1.7976931348623157e308, zmx = -1.7976931348623157e308;
     double xmn = zmn, xmx = zmx;
     // weighted mean / scatter of the inliers, updated point by point in list order (West's one-pass update: no second
-    // sweep over the list, no cancellation)
+    // sweep over the list, no cancellation, and every increment of the scatter is a positive semi-definite term, so
+    // degenerate (collinear) inlier sets keep their exactly-zero eigenvalues); the two divisions per point are
+    // reciprocal estimates + Newton steps (road tolerance)
     double sw = 0, mx = 0, my = 0, mz = 0;
     double q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
     const V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
@@ -1378,26 +1564,29 @@ __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, u
                 if (p.x < xmn) xmn = p.x;
                 if (p.x > xmx) xmx = p.x;
                 if (roadMode == 0) {
-                    const double w = 1 / fabs(vdot(pn, p) + s.prior_off);  // PlaneEstimationMEstimator.cpp:32
+                    const double w = fast_rcp(fabs(vdot(pn, p) + s.prior_off));  // PlaneEstimationMEstimator.cpp:32
                     const double swn = sw + w;
-                    const double r = w / swn;
+                    const double r = w * fast_rcp(swn);
                     const double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
-                    mx += dx * r;
-                    my += dy * r;
-                    mz += dz * r;
+                    mx = fma(dx, r, mx);
+                    my = fma(dy, r, my);
+                    mz = fma(dz, r, mz);
                     const double ex = p.x - mx, ey = p.y - my, ez = p.z - mz;
-                    q0 += w * dx * ex;
-                    q1 += w * dx * ey;
-                    q2 += w * dx * ez;
-                    q3 += w * dy * ey;
-                    q4 += w * dy * ez;
-                    q5 += w * dz * ez;
+                    const double wdx = w * dx, wdy = w * dy, wdz = w * dz;
+                    q0 = fma(wdx, ex, q0);
+                    q1 = fma(wdx, ey, q1);
+                    q2 = fma(wdx, ez, q2);
+                    q3 = fma(wdy, ey, q3);
+                    q4 = fma(wdy, ez, q4);
+                    q5 = fma(wdz, ez, q5);
                     sw = swn;
                 }
             }
           }
         }
     }
+    ST_USE_F64(sw);
+    ST_MARK(8);
     if (cand && (far || kk < 3)) {
         mytype = resultOld;  // :591
         mydepth = -1.0;
@@ -1409,9 +1598,12 @@ __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, u
     rr[9] = zmn;
     rr[10] = zmx;
     if (roadMode == 0) {
+        // weighted centre (PlaneEstimationMEstimator.cpp:31-37) and scatter about it (:39-46)
         rr[0] = mx; rr[1] = my; rr[2] = mz;
         rr[3] = q0; rr[4] = q1; rr[5] = q2; rr[6] = q3; rr[7] = q4; rr[8] = q5;
-        if (cand) finish_road(c, false, myu, myv, rr, mytype, mydepth);
+        if (cand) finish_road_fast(c, myu, myv, rr, mytype, mydepth);
+        ST_USE_F64(mydepth);
+        ST_MARK(11);
     } else {
         // RoadDepthEstimatorMaxSpanningTriangle::CalculateDepth (:24-75)
         if (cand && kk > kK2Max) {
@@ -1455,7 +1647,7 @@ __device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, u
 // the executing wave's own region: k_feature_main re-deals the live features of a block to dense wavefronts).
 __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane,
                                                 const int k, bool live, const double myu, const double myv,
-                                                int& mytype, double& mydepth, bool& overflow) {
+                                                int& mytype, double& mydepth, bool& overflow ST_ARG) {
     int ks = live ? k : 0;
     double minZ = 1.7976931348623157e308, maxZ = -1.7976931348623157e308;
     if (c.useHist) {
@@ -1493,6 +1685,8 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
                 dmin = (ok && d < dmin) ? d : dmin;
             }
         }
+        ST_USE_U32(md);
+        ST_MARK(8);
         const int binCount = (int)((double)md / c.binW + 1.0);
         bool hfail = binCount <= 1;
         const double lim = (double)binCount - 1.;
@@ -1634,6 +1828,8 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
         }
     }
 
+    ST_USE_U32(ks);
+    ST_MARK(9);
     // ---- CalculateDepthSegmented (DepthEstimator.cpp:903-1037) ----
     double r[kRecFields];
 #pragma unroll
@@ -1709,7 +1905,12 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
     }
     r[9] = minZ;
     r[10] = maxZ;
+    ST_USE_F64(r[0]);
+    ST_USE_F64(r[8]);
+    ST_MARK(10);
     if (live) finish_main(c, pca, myu, myv, r, mytype, mydepth);
+    ST_USE_F64(mydepth);
+    ST_MARK(11);
 }
 
 // Single-kernel variant of the thread path (MLD_NO_SPLIT_ROAD=1): scan, main path and road fallback inline, 64 features
@@ -1747,14 +1948,18 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
 
     if (c.threadPath) {
         // ---------------- main window (DepthEstimator.cpp:509-576) ----------------
-        int k = scan_window_thread(c, s, myu, myv, c.halfX1, c.halfY1, active, lst, lane);
+#ifdef MLD_STAMPS
+        Stamps st;
+        st.begin(3);
+#endif
+        int k = scan_window_thread(c, s, myu, myv, c.halfX1, c.halfY1, active, lst, lane ST_PASS);
         overflow = k > c.k1max;
         bool live = active && !overflow;  // still being computed by this path
         if (live && (unsigned)k < c.countMin) {
             mytype = MLD_RadiusSearchInsufficientPoints;
             live = false;
         }
-        main_after_scan(c, s, lst, lane, k, live, myu, myv, mytype, mydepth, overflow);
+        main_after_scan(c, s, lst, lane, k, live, myu, myv, mytype, mydepth, overflow ST_PASS);
 
         // ---------------- road fallback (DepthEstimator.cpp:578-597) ----------------
         const bool road_on = c.useRoad && s.has_plane;
@@ -1764,7 +1969,7 @@ __global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restr
         if (cmask) {
             const int resultOld = mytype;
             bool ovf2 = false;
-            road_thread<-1>(c, s, lst, lane, cand, myu, myv, mytype, mydepth, ovf2);
+            road_thread<-1>(c, s, lst, lane, cand, myu, myv, mytype, mydepth, ovf2 ST_PASS);
             if (ovf2) {  // long wide-window list: only the road part is redone by the wave kernel
                 overflow = true;
                 ovf_code = resultOld;
@@ -1868,6 +2073,10 @@ __global__ __launch_bounds__(kMainThreads) void k_feature_main(const SlotDesc* _
                                                                int use_single, Calib c, int n_slots, int per_slot,
                                                                uint32_t tag_all) {
     extern __shared__ __align__(16) unsigned char smem[];
+#ifdef MLD_STAMPS
+    Stamps st;
+    st.begin(0);
+#endif
     int slot, j;
     decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
     SlotDesc s = use_single ? single : slots[slot];
@@ -1895,8 +2104,11 @@ __global__ __launch_bounds__(kMainThreads) void k_feature_main(const SlotDesc* _
         myu = q[0];
         myv = q[1];
     }
+    ST_USE_F64(myu);
+    ST_USE_F64(myv);
+    ST_MARK(1);
     // ---------------- main window (DepthEstimator.cpp:509-510) ----------------
-    const int k = scan_window_thread(c, s, myu, myv, c.halfX1, c.halfY1, active, lst, lane);
+    const int k = scan_window_thread(c, s, myu, myv, c.halfX1, c.halfY1, active, lst, lane ST_PASS);
     const bool overflow = active && (k > c.k1max);
     int mytype = MLD_Unspecified;
     bool live = active && !overflow;
@@ -1925,6 +2137,7 @@ __global__ __launch_bounds__(kMainThreads) void k_feature_main(const SlotDesc* _
     if (live) info[base + prefix_count(lm)] = (uint32_t)tid | ((uint32_t)k << 16);
     fidx[tid] = (int32_t)fme;
     __syncthreads();
+    ST_MARK(5);
     // features finished (or handed on) by the scanning lane itself
     if (active && !live) {
         GPTRW(double, s.depth)[fme] = -1.0;
@@ -1933,6 +2146,10 @@ __global__ __launch_bounds__(kMainThreads) void k_feature_main(const SlotDesc* _
     enqueue_features(s.road_queue, s.road_count, road_on && active && !live && !overflow && mytype == MLD_HistogramNoLocalMax,
                      lane, fme, mytype);
     enqueue_features(s.ovf_queue, s.ovf_count, overflow, lane, fme, -1);
+    ST_MARK(6);
+#ifdef MLD_STAMPS
+    if (wave * kWave >= nlive) st.flush();
+#endif
     if (wave * kWave >= nlive) return;  // nothing dealt to this wavefront (no barrier follows)
     // ---------------- dealt features: histogram, triangle, tail ----------------
     const bool has = tid < nlive;
@@ -1946,10 +2163,13 @@ __global__ __launch_bounds__(kMainThreads) void k_feature_main(const SlotDesc* _
         v = q[1];
     }
     uint32_t* olst = lst_all + (origin >> 6) * c.k1max * kWave;
+    ST_USE_F64(u);
+    ST_USE_F64(v);
+    ST_MARK(7);
     int type2 = MLD_Unspecified;
     double depth2 = -1.0;
     bool ovf2 = false;
-    main_after_scan(c, s, olst, origin & (kWave - 1), kd, has, u, v, type2, depth2, ovf2);
+    main_after_scan(c, s, olst, origin & (kWave - 1), kd, has, u, v, type2, depth2, ovf2 ST_PASS);
     if (has) {
         GPTRW(double, s.depth)[f] = depth2;
         if (s.type) GPTRW(int32_t, s.type)[f] = type2;
@@ -1958,6 +2178,10 @@ __global__ __launch_bounds__(kMainThreads) void k_feature_main(const SlotDesc* _
                      road_on && has && !ovf2 && (type2 != MLD_Success) && (type2 != MLD_RadiusSearchInsufficientPoints), lane,
                      f, type2);
     enqueue_features(s.ovf_queue, s.ovf_count, has && ovf2, lane, f, -1);
+    ST_MARK(12);
+#ifdef MLD_STAMPS
+    st.flush();
+#endif
 }
 
 // Road fallback for the features queued by k_feature_main: one lane per queued feature.
@@ -1973,6 +2197,10 @@ __global__ __launch_bounds__(kWave) void k_feature_road(const SlotDesc* __restri
     const int count = *GPTR(int32_t, s.road_count);
     const int e0 = j * kWave;
     if (e0 >= count) return;
+#ifdef MLD_STAMPS
+    Stamps st;
+    st.begin(1);
+#endif
     const int lane = threadIdx.x;
     const bool active = e0 + lane < count;
     uint32_t* lst = reinterpret_cast<uint32_t*>(smem);
@@ -1988,12 +2216,19 @@ __global__ __launch_bounds__(kWave) void k_feature_road(const SlotDesc* __restri
     }
     bool overflow = false;
     const int resultOld = mytype;
-    road_thread<ROAD_MODE>(c, s, lst, lane, active, myu, myv, mytype, mydepth, overflow);
+    ST_USE_F64(myu);
+    ST_USE_F64(myv);
+    ST_MARK(1);
+    road_thread<ROAD_MODE>(c, s, lst, lane, active, myu, myv, mytype, mydepth, overflow ST_PASS);
     enqueue_features(s.ovf_queue, s.ovf_count, overflow && active, lane, f, resultOld);
     if (active) {
         GPTRW(double, s.depth)[f] = mydepth;
         if (s.type) GPTRW(int32_t, s.type)[f] = mytype;
     }
+    ST_MARK(12);
+#ifdef MLD_STAMPS
+    st.flush();
+#endif
 }
 
 // Wave-cooperative kernel for the features the thread kernels could not hold (lists longer than their capacities).
@@ -2037,6 +2272,448 @@ __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restri
                 for (int t = 0; t < 9; t++) GPTRW(double, s.corners)[9 * f + t] = corners[t];
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Classification + dense fused feature kernel (the default path).
+//
+// What bounds the per-feature work on MI355X is the rate of DIVERGENT gathers (one lane = one cache line): about
+// 0.45 lanes/clk/CU from L2 and 0.08 from HBM (profiles/tools/randgather.hip), whatever the occupancy.  So the path is
+// organised to issue as few of them as possible:
+//   k_classify      one block per frame slot.  The slot's occupancy bitmap (63 KB) is staged in LDS with coalesced
+//                   loads and every feature's narrow window is counted there: features without enough neighbours
+//                   (RadiusSearchInsufficientPoints, 43 % of a KITTI-like frame) get their result at once and never
+//                   touch global memory again; the others are written, sorted by image row, to the slot's LIVE queue.
+//   k_feature_fused one lane per live feature (dense wavefronts, no dealing, no barrier).  ONE scan of the wide
+//                   (road) window serves both the main path and the road fallback: its entries carry a flag "inside
+//                   the narrow window"; the flagged sub-list (same row-major order) feeds histogram / triangle / tail,
+//                   the whole list the road estimator.  Keys and points of a window are fetched once.
+// ------------------------------------------------------------------------------------------------
+
+// Integer window bounds exactly as NeighborFinderPixel::getNeighbors (NeighborFinderPixel.cpp:67-76): clamped doubles,
+// truncation.  false: no window (non-finite feature — undefined behaviour in the reference — or empty).
+__device__ __forceinline__ bool window_bounds(const Calib& c, double u, double v, double halfX, double halfY, int& x0,
+                                              int& y0, int& nx, int& ny) {
+    x0 = 0;
+    y0 = 0;
+    nx = 0;
+    ny = 0;
+    if (!(isfinite(u) && isfinite(v))) return false;
+    double a;
+    a = u - halfX;
+    const double left = (a < 0.) ? 0. : a;
+    a = u + halfX;
+    const double right = ((double)(c.W - 1) < a) ? (double)(c.W - 1) : a;
+    a = v - halfY;
+    const double top = (a < 0.) ? 0. : a;
+    a = v + halfY;
+    const double bottom = ((double)(c.H - 1) < a) ? (double)(c.H - 1) : a;
+    const int xa = (int)left, ya = (int)top, xb = (int)right, yb = (int)bottom;
+    const int wx = xb - xa + 1, wy = yb - ya + 1;
+    if (wx <= 0 || wy <= 0 || xa < 0 || ya < 0 || xb >= c.W || yb >= c.H) return false;
+    x0 = xa;
+    y0 = ya;
+    nx = wx;
+    ny = wy;
+    return true;
+}
+
+constexpr int kClsThreads = 1024;  // the LDS image of the bitmap allows two blocks per CU: 16 waves each fill it
+constexpr int kClsBuckets = 1024;
+constexpr int kClsKeep = 2;  // features per thread whose class stays in registers between the two passes
+enum : int { CLS_DEAD = -1, CLS_OVF = -2, CLS_NONE = -3 };
+
+// STAGED: the slot's bitmap is copied to LDS (row-major there: word [y * ncolp + column], ncolp odd) and read from
+// it; otherwise (bitmap larger than the LDS budget: very large images) it is read in place.
+template <bool STAGED>
+__global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __restrict__ slots, SlotDesc single,
+                                                          int use_single, Calib c, int ncol, int ncolp) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int* hist = reinterpret_cast<int*>(smem);           // [kClsBuckets]
+    int* wsum = hist + kClsBuckets;                     // [kClsThreads / kWave]
+    int* ctr = wsum + kClsThreads / kWave;              // [0] overflow-queue cursor
+    uint32_t* lbm = reinterpret_cast<uint32_t*>(ctr + 4);  // staged bitmap
+    SlotDesc s = use_single ? single : slots[blockIdx.x];
+    long long Fn = s.F;
+    if (s.F_dev) {
+        const long long fd = *GPTR(long long, s.F_dev);
+        Fn = fd < Fn ? fd : Fn;
+    }
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    for (int b = tid; b < kClsBuckets; b += kClsThreads) hist[b] = 0;
+    if (tid == 0) ctr[0] = 0;
+    const auto* bm = GPTR(uint32_t, s.bitmap);
+    if (STAGED) {
+        // global layout: word = column * bmStride + y (bmStride a multiple of 4): 16-byte pieces of four rows
+        const int q4 = c.bmStride >> 2, n4 = ncol * q4;
+        const float rq = 1.0f / (float)q4;
+        constexpr int kStage = 4;  // 16-byte loads in flight per thread
+        for (int g0 = tid; g0 < n4; g0 += kClsThreads * kStage) {
+            u32x4u w[kStage];
+            int col[kStage], y[kStage];
+#pragma unroll
+            for (int t = 0; t < kStage; t++) {
+                const int g = g0 + t * kClsThreads;
+                col[t] = (int)(((float)g + 0.5f) * rq);
+                y[t] = (g - col[t] * q4) << 2;
+                w[t] = u32x4u{0u, 0u, 0u, 0u};
+                if (g < n4) w[t] = *GPTR(u32x4u, bm + (size_t)col[t] * c.bmStride + y[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < kStage; t++) {
+                if (g0 + t * kClsThreads < n4) {
+                    lbm[(y[t] + 0) * ncolp + col[t]] = w[t][0];
+                    lbm[(y[t] + 1) * ncolp + col[t]] = w[t][1];
+                    lbm[(y[t] + 2) * ncolp + col[t]] = w[t][2];
+                    lbm[(y[t] + 3) * ncolp + col[t]] = w[t][3];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const bool road_on = c.useRoad && s.has_plane && s.inlier_mask;
+    const auto* uv = GPTR(double, s.uv);
+    const double scale = (double)kClsBuckets / (double)c.H;
+    // class of feature i: CLS_DEAD (fewer than radiusSearch_count_min neighbours, DepthEstimator.cpp:680), CLS_OVF
+    // (a window wider than 32 cells, or the wave-only mode: handled by k_feature_wave), or its row bucket (live)
+    auto classify = [&](double u, double v) -> int {
+        if (!c.threadPath) return CLS_OVF;
+        int x0, y0, nx, ny;
+        int k1 = 0;
+        if (window_bounds(c, u, v, c.halfX1, c.halfY1, x0, y0, nx, ny)) {
+            if (nx > 32) return CLS_OVF;
+            if (road_on) {
+                int a0, a1, anx, any_;
+                if (window_bounds(c, u, v, c.halfX2, c.halfY2, a0, a1, anx, any_) && anx > 32) return CLS_OVF;
+            }
+            const int cx = x0 >> 5, sh = x0 & 31;
+            const unsigned long long colmask = (1ull << nx) - 1ull;
+            for (int r = 0; r < ny; r++) {
+                const int y = y0 + r;
+                uint32_t lo, hi;
+                if (STAGED) {
+                    lo = lbm[y * ncolp + cx];
+                    hi = lbm[y * ncolp + cx + 1];
+                } else {
+                    lo = bm[(size_t)cx * c.bmStride + y];
+                    hi = bm[(size_t)(cx + 1) * c.bmStride + y];
+                }
+                const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+                k1 += __popcll((w >> sh) & colmask);
+            }
+        }
+        if ((unsigned)k1 < c.countMin) return CLS_DEAD;
+        int b = 0;
+        if (v > 0.0) b = (v < (double)c.H) ? (int)(v * scale) : kClsBuckets - 1;
+        return b < kClsBuckets ? b : kClsBuckets - 1;
+    };
+    auto settle = [&](long long i, int cls) {  // results / overflow entries of the features that are not live
+        if (cls == CLS_DEAD) {
+            GPTRW(double, s.depth)[i] = -1.0;
+            if (s.type) GPTRW(int32_t, s.type)[i] = MLD_RadiusSearchInsufficientPoints;
+        } else if (cls == CLS_OVF) {
+            const int pos = atomicAdd(&ctr[0], 1);
+            GPTRW(int32_t, s.ovf_queue)[2 * (size_t)pos] = (int32_t)i;
+            GPTRW(int32_t, s.ovf_queue)[2 * (size_t)pos + 1] = -1;
+        }
+    };
+    int kept[kClsKeep];
+    {
+        // the features of the first pass are fetched before the barrier-free classification loop starts
+        double fu[kClsKeep], fv[kClsKeep];
+#pragma unroll
+        for (int q = 0; q < kClsKeep; q++) {
+            const long long i = tid + (long long)q * kClsThreads;
+            fu[q] = 0.0;
+            fv[q] = 0.0;
+            if (i < Fn) {
+                fu[q] = uv[2 * i];
+                fv[q] = uv[2 * i + 1];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kClsKeep; q++) {
+            const long long i = tid + (long long)q * kClsThreads;
+            kept[q] = (i < Fn) ? classify(fu[q], fv[q]) : (int)CLS_NONE;
+            if (kept[q] >= 0) atomicAdd(&hist[kept[q]], 1);
+            if (i < Fn) settle(i, kept[q]);
+        }
+    }
+    for (long long i = tid + (long long)kClsKeep * kClsThreads; i < Fn; i += kClsThreads) {
+        const int cls = classify(uv[2 * i], uv[2 * i + 1]);
+        if (cls >= 0) atomicAdd(&hist[cls], 1);
+        settle(i, cls);
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts: kPer buckets per thread, wave scan, block offsets
+    constexpr int kPer = kClsBuckets / kClsThreads;
+    static_assert(kPer >= 1 && kPer * kClsThreads == kClsBuckets, "bucket count must be a multiple of the block size");
+    int loc[kPer], sum = 0;
+#pragma unroll
+    for (int q = 0; q < kPer; q++) {
+        loc[q] = hist[tid * kPer + q];
+        sum += loc[q];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == kWave - 1) wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int q = 0; q < wave; q++) base += wsum[q];
+    if (tid == kClsThreads - 1) {
+        *GPTRW(int32_t, s.live_count) = base + sum;  // number of live features
+        *GPTRW(int32_t, s.ovf_count) = ctr[0];       // the later kernels append with atomics
+    }
+#pragma unroll
+    for (int q = 0; q < kPer; q++) {
+        hist[tid * kPer + q] = base;
+        base += loc[q];
+    }
+    __syncthreads();
+    auto* live = GPTRW(int32_t, s.live_queue);
+#pragma unroll
+    for (int q = 0; q < kClsKeep; q++)
+        if (kept[q] >= 0) live[atomicAdd(&hist[kept[q]], 1)] = (int32_t)(tid + q * kClsThreads);
+    for (long long i = tid + (long long)kClsKeep * kClsThreads; i < Fn; i += kClsThreads) {
+        const int cls = classify(uv[2 * i], uv[2 * i + 1]);
+        if (cls >= 0) live[atomicAdd(&hist[cls], 1)] = (int32_t)i;
+    }
+}
+
+constexpr int kKeyBatchF = 8;  // map keys fetched per round trip by the fused kernel
+
+// One scan of the window (x0, y0, nx, ny) through the occupancy bitmap; entries in the reference's row-major order,
+// bit 31 set for the cells that also lie inside the narrow window (xn0, yn0, nxn, nyn).  The lane's list ends up
+// holding ORIGINAL POINT INDICES (low 24 bits) | flag.  Returns the entry count (may exceed c.k1max: overflow), the
+// number of flagged entries in kflag.
+__device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDesc& s, int x0, int y0, int nx, int ny,
+                                                   int xn0, int yn0, int nxn, int nyn, uint32_t* lst, int lane,
+                                                   int& kflag ST_ARG) {
+    const int nymax = uniform(wave_max_i32(ny));
+    const auto* bm = GPTR(uint32_t, s.bitmap);
+    // windows are at most 32 cells wide here (k_classify routes wider ones to the wave kernel): 32-bit row masks
+    const uint32_t colmask = (nx >= 32) ? ~0u : ((1u << nx) - 1u);
+    // columns of the narrow window relative to x0
+    const uint32_t nmask = (nxn > 0) ? (((nxn >= 32) ? ~0u : ((1u << nxn) - 1u)) << (xn0 - x0)) : 0u;
+    int k = 0, kf = 0;
+    const auto* col0 = bm + (size_t)(x0 >> 5) * (size_t)c.bmStride + (size_t)y0;
+    const auto* col1 = col0 + c.bmStride;
+    const int sh = x0 & 31;
+    const int nxmax = uniform(wave_max_i32(nx));
+    for (int r0 = 0; r0 < nymax; r0 += 16) {
+        // sixteen rows (four 16-byte pieces from each of the two word columns) in ONE round trip
+        u32x4u a[4], b2[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            a[g] = u32x4u{0u, 0u, 0u, 0u};
+            b2[g] = u32x4u{0u, 0u, 0u, 0u};
+            if (r0 + 4 * g < nymax) {  // wave-uniform
+                if (r0 + 4 * g < ny) {
+                    a[g] = *GPTR(u32x4u, col0 + r0 + 4 * g);
+                    b2[g] = *GPTR(u32x4u, col1 + r0 + 4 * g);
+                }
+            }
+        }
+        ST_USE_U32(a[0][0]);
+        ST_USE_U32(b2[0][0]);
+        ST_USE_U32(a[3][0]);
+        ST_USE_U32(b2[3][0]);
+        ST_MARK(2);
+        if (nxmax <= 16) {
+            // Windows up to 16 cells wide (the C0 parameter set: 7 and 13): two rows are packed into one 32-bit word
+            // (16 bits each) and the set bits of a word are walked in one loop.  A wavefront iterates to the largest
+            // bit count among its lanes, and lanes hit the LiDAR rings in different rows: per pair of rows that maximum
+            // is about the points of one ring, per single row it is the same, so this halves the iterations.
+#pragma unroll
+            for (int h = 0; h < 8; h++) {
+                if (r0 + 2 * h < nymax) {  // wave-uniform
+                    const int qa = 2 * h, qb = 2 * h + 1;
+                    const uint32_t va = __builtin_amdgcn_alignbit(b2[qa >> 2][qa & 3], a[qa >> 2][qa & 3], (uint32_t)sh);
+                    const uint32_t vb = __builtin_amdgcn_alignbit(b2[qb >> 2][qb & 3], a[qb >> 2][qb & 3], (uint32_t)sh);
+                    const uint32_t ba = ((r0 + qa) < ny) ? (va & colmask) : 0u;
+                    const uint32_t bb = ((r0 + qb) < ny) ? (vb & colmask) : 0u;
+                    uint32_t b = ba | (bb << 16);
+                    const int rowa = y0 + r0 + qa;
+                    const uint32_t fa = (rowa >= yn0 && rowa < yn0 + nyn) ? nmask : 0u;
+                    const uint32_t fb = (rowa + 1 >= yn0 && rowa + 1 < yn0 + nyn) ? nmask : 0u;
+                    const uint32_t flags = fa | (fb << 16);
+                    const uint32_t rowbase = (uint32_t)(rowa * c.W + x0);
+                    while (b) {
+                        const uint32_t p = (uint32_t)__ffs((int)b) - 1u;
+                        b &= b - 1u;
+                        const uint32_t fl = (flags >> p) & 1u;
+                        const uint32_t cell = rowbase + ((p & 16u) ? (uint32_t)c.W : 0u) + (p & 15u);
+                        if (k < c.k1max) LST(k) = cell | (fl << 31);
+                        k++;
+                        kf += (int)fl;
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            if (r0 + q < nymax) {
+                // (hi:lo) >> sh, low 32 bits: the window's cells of this row
+                const uint32_t v = __builtin_amdgcn_alignbit(b2[q >> 2][q & 3], a[q >> 2][q & 3], (uint32_t)sh);
+                uint32_t b = ((r0 + q) < ny) ? (v & colmask) : 0u;
+                const int row = y0 + r0 + q;
+                const uint32_t rowbase = (uint32_t)(row * c.W + x0);
+                const uint32_t rowflags = (row >= yn0 && row < yn0 + nyn) ? nmask : 0u;
+                while (b) {
+                    const uint32_t col = (uint32_t)__ffs((int)b) - 1u;
+                    b &= b - 1u;
+                    const uint32_t fl = (rowflags >> col) & 1u;
+                    if (k < c.k1max) LST(k) = (rowbase + col) | (fl << 31);
+                    k++;
+                    kf += (int)fl;
+                }
+            }
+        }
+        }
+    }
+    ST_MARK(3);
+    // cell index -> original point index (every set bit has a key of the current tag)
+    const int kk = k <= c.k1max ? k : 0;
+    const int kmax = uniform(wave_max_i32(kk));
+    const auto* mp = GPTR(uint32_t, s.map);
+    for (int e0 = 0; e0 < kmax; e0 += kKeyBatchF) {
+        uint32_t cell[kKeyBatchF], key[kKeyBatchF];
+#pragma unroll
+        for (int q = 0; q < kKeyBatchF; q++) cell[q] = (e0 + q < kk) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
+#pragma unroll
+        for (int q = 0; q < kKeyBatchF; q++) key[q] = (e0 + q < kk) ? mp[cell[q] & 0x7FFFFFFFu] : 0u;
+#pragma unroll
+        for (int q = 0; q < kKeyBatchF; q++)
+            if (e0 + q < kk) LST(e0 + q) = (kIdxMask - (key[q] & kIdxMask)) | (cell[q] & 0x80000000u);
+    }
+    ST_MARK(4);
+    kflag = kf;
+    return k;
+}
+
+// One lane per LIVE feature (queue written by k_classify).  LDS per wave: the wide list (c.k1max entries) followed by
+// the narrow list (c.kMain entries), both transposed [entry][lane].
+#ifndef MLD_FUSED_WAVES
+#define MLD_FUSED_WAVES 3
+#endif
+template <int ROAD_MODE>
+__global__ __launch_bounds__(kWave, MLD_FUSED_WAVES) void k_feature_fused(const SlotDesc* __restrict__ slots, SlotDesc single,
+                                                         int use_single, Calib c, int n_slots, int per_slot,
+                                                         uint32_t tag_all) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int total = n_slots * per_slot;
+    for (int w = (int)blockIdx.x; w < total; w += (int)gridDim.x) {
+        int slot, j;
+        decode_block(w, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
+        SlotDesc s = use_single ? single : slots[slot];
+        if (tag_all) s.tag = tag_all;
+        const int count = *GPTR(int32_t, s.live_count);
+        const int e0 = j * kWave;
+        if (e0 >= count) continue;
+#ifdef MLD_STAMPS
+        Stamps st;
+        st.begin(0);
+#endif
+        const int lane = threadIdx.x;
+        const bool active = e0 + lane < count;
+        uint32_t* lst = reinterpret_cast<uint32_t*>(smem);  // wide list
+        uint32_t* nl = lst + c.k1max * kWave;               // narrow list
+        long long f = 0;
+        double myu = 0, myv = 0;
+        if (active) {
+            f = (long long)GPTR(int32_t, s.live_queue)[e0 + lane];
+            const auto* q = GPTR(double, s.uv) + 2 * f;
+            myu = q[0];
+            myv = q[1];
+        }
+        ST_USE_F64(myu);
+        ST_USE_F64(myv);
+        ST_MARK(1);
+        const bool road_on = c.useRoad && s.has_plane && s.inlier_mask;
+        // narrow window (DepthEstimator.cpp:509, scale 1 x 1) and the window that is scanned: the road window
+        // (:585, scale 2.0 x 1.5), a superset, when the fallback is on
+        int xn0, yn0, nxn, nyn, x0, y0, nx, ny;
+        const bool hasn = active && window_bounds(c, myu, myv, c.halfX1, c.halfY1, xn0, yn0, nxn, nyn);
+        if (!hasn) {
+            nxn = 0;
+            nyn = 0;
+        }
+        if (road_on) {
+            if (!(active && window_bounds(c, myu, myv, c.halfX2, c.halfY2, x0, y0, nx, ny))) {
+                nx = 0;
+                ny = 0;
+            }
+        } else {
+            x0 = xn0;
+            y0 = yn0;
+            nx = nxn;
+            ny = nyn;
+        }
+        int k1 = 0;
+        const int k2 = scan_window_flagged(c, s, x0, y0, nx, ny, xn0, yn0, nxn, nyn, lst, lane, k1 ST_PASS);
+        // (k_classify keeps windows wider than 32 cells out of the live queue)
+        bool overflow = active && (k2 > c.k1max || k1 > c.kMain);
+        int ovf_code = -1;
+        // narrow list = the flagged entries, same order
+        {
+            const int n2 = (active && !overflow) ? k2 : 0;
+            const int n2max = uniform(wave_max_i32(n2));
+            int kk = 0;
+            for (int e = 0; e < n2max; e++) {
+                const uint32_t v = LST(min(e, c.k1max - 1));
+                if (e < n2 && (v >> 31)) {
+                    nl[kk * kWave + lane] = v & kIdxMask;
+                    kk++;
+                }
+            }
+        }
+        ST_MARK(5);
+        int mytype = MLD_Unspecified;
+        double mydepth = -1.0;
+        bool live = active && !overflow;
+        if (live && (unsigned)k1 < c.countMin) {  // DepthEstimator.cpp:680 (k_classify has filtered these out already)
+            mytype = MLD_RadiusSearchInsufficientPoints;
+            live = false;
+        }
+        // fewer neighbours than the histogram's minimum bin count: no bin can become a maximum, FilterPointsMinDistBlob
+        // returns false on every path (HistogramPointDepth.cpp:53,84,95)
+        if (live && c.useHist && c.minCount >= 1 && k1 < c.minCount) {
+            mytype = MLD_HistogramNoLocalMax;
+            live = false;
+        }
+        {
+            Calib cm = c;
+            cm.k1max = c.kMain;
+            bool ovf1 = false;
+            main_after_scan(cm, s, nl, lane, k1, live, myu, myv, mytype, mydepth, ovf1 ST_PASS);
+            if (live && ovf1) overflow = true;  // segmented list too long for the per-thread triangle search: wave kernel
+        }
+        // ---------------- road fallback (DepthEstimator.cpp:578-597) on the list already scanned ----------------
+        const bool cand = road_on && active && !overflow && (mytype != MLD_Success) &&
+                          (mytype != MLD_RadiusSearchInsufficientPoints);
+        if (__any(cand)) {
+            const int resultOld = mytype;
+            bool ovf2 = false;
+            road_after_scan<ROAD_MODE>(c, s, lst, lane, cand, k2, myu, myv, mytype, mydepth, ovf2 ST_PASS);
+            if (ovf2) {  // only the road part is redone by the wave kernel
+                overflow = true;
+                ovf_code = resultOld;
+            }
+        }
+        enqueue_features(s.ovf_queue, s.ovf_count, overflow && active, lane, f, ovf_code);
+        if (active) {
+            GPTRW(double, s.depth)[f] = mydepth;
+            if (s.type) GPTRW(int32_t, s.type)[f] = mytype;
+        }
+        ST_MARK(12);
+#ifdef MLD_STAMPS
+        st.flush();
+#endif
     }
 }
 

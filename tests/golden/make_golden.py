@@ -11,6 +11,10 @@ Cases (small camera 320x96, f=180; 32x512 cloud; features chosen so that every l
   tight         global depth window [6, 20] m, absolute local tolerance 0.02 m  -> types 4, 5, 6, 7
   no_thresholds thresholds off, cut-behind-camera on                            -> type 10 (intersection behind the camera)
   find_by_pixel the reference's NeigborFinder.findByPixel layout (100x100, f=600, window 3x5, 50 points)
+  vlp16_int     BASELINE config 3 in small: 16-ring cloud (rows of points 10+ pixels apart), integer-pixel features as the
+                tracklet caller passes them (tracklet_depth_module.cpp:75-76), thresholds in Adjust mode, relative local
+  dense_int     BASELINE config 5 in small: 128-ring cloud cropped to the forward sector, integer-pixel features: windows
+                with dozens of neighbours (the long-list path of the HIP build), many points per pixel (first-wins map)
 """
 import json
 import sys
@@ -102,6 +106,16 @@ def main():
     cl = np.zeros((50, 4), np.float32)
     cl[:, :3] = rays * dep[:, None]
     data.update(run_case("find_by_pixel", Pf, camf, Tf, cl, None, pix, per_type=50, max_features=50))
+    # config 3 / config 5 shaped mini-cases (integer-pixel features)
+    candi = np.floor(np.stack([rng.uniform(0, CAM.width, 3000), rng.uniform(0, CAM.height, 3000)], axis=1))
+    cv = synth.make_cloud(synth.Scanner(16, 450, 15.0, -15.0), seed=5, frame=1)
+    Pv = P0.replace(treshold_depth_mode=1, treshold_depth_local_mode=1, treshold_depth_local_valuetype=1,
+                    treshold_depth_min=3, treshold_depth_max=40)
+    data.update(run_case("vlp16_int", Pv, CAM, synth.T_CAM_LIDAR, cv, synth.make_ground_plane(cv), candi))
+    cd = synth.make_cloud(synth.Scanner(128, 1536, 15.0, -25.0), seed=6, frame=0)
+    fwd = np.nan_to_num(cd[:, 0], nan=-1.0) > np.abs(np.nan_to_num(cd[:, 1], nan=1e9)) * 0.6  # forward sector, order kept
+    cd = np.ascontiguousarray(cd[fwd])
+    data.update(run_case("dense_int", P0, CAM, synth.T_CAM_LIDAR, cd, synth.make_ground_plane(cd), candi, per_type=8))
     out = Path(__file__).resolve().parent / "golden_frames.npz"
     np.savez_compressed(out, **data)
     print("wrote", out, out.stat().st_size, "bytes")

@@ -34,11 +34,63 @@ def test_histogram_binning_equals_the_reference_class(bin_width, bin_count):
     assert np.array_equal(oracle.histogram_counts(values, bin_width, bin_count), _ref_counts(values, bin_width, bin_count))
 
 
+# The input list of the reference's own test Histogram.FilterPointsMinDistBlob (test_monolidar_fusion.cpp:310-322).
+_REF_KAT_DEPTHS = [2.2, 3.5, 4.2, 5.2, 5.2, 6.2, 7.2, 8.2, 8.3, 8.4, 9.2, 10.2, 10.5]
+
+
+def _first_local_maximum(counts, min_count):
+    """The bin scan of PointHistogram::FilterPointsMinDistBlob (HistogramPointDepth.cpp:65-95) over given bin counts:
+    index of the first local-maximum bin, or -1 ("return false")."""
+    bin_max_id, bin_max_val, value = -1, -1, 0
+    for i, c in enumerate(counts):
+        last, value = value, int(c)
+        if value > bin_max_val and value >= min_count:
+            bin_max_val, bin_max_id = value, i
+        elif value < bin_max_val:
+            break
+        if last > 0 and value == 0:
+            return -1
+    return bin_max_id
+
+
 def test_histogram_kat_through_the_reference_class():
-    """The depth list of the reference's own test Histogram.FilterPointsMinDistBlob (test_monolidar_fusion.cpp:306-374),
-    binned by the reference's class and by the restatement."""
-    depths = [1.1, 1.2, 1.3, 4.1, 4.2, 4.3, 4.4, 8.0, 8.1]
-    assert np.array_equal(oracle.histogram_counts(depths, 1.0, 10), _ref_counts(depths, 1.0, 10))
+    """The reference's KAT (test_monolidar_fusion.cpp:306-374) with the binning done by the reference's own Histogram
+    object code: bin width 1, minimal maximum size 3 (:333-334), bin count = ceil(max depth) / width + 1
+    (HistogramPointDepth.cpp:37-43).  The counts must equal the restatement's, and the scan over the REFERENCE's counts
+    must select the bin [8, 9) whose members are the asserted output {8.2, 8.3, 8.4} (:370-373) - the same answer the
+    oracle's FilterPointsMinDistBlob gives end to end."""
+    depths, bin_width, min_count = _REF_KAT_DEPTHS, 1.0, 3
+    bin_count = int(int(np.ceil(max(depths))) / bin_width + 1)
+    assert bin_count == 12
+    ref_counts = _ref_counts(depths, bin_width, bin_count)
+    assert list(ref_counts) == [0, 0, 1, 1, 1, 2, 1, 1, 3, 1, 2, 0]
+    assert np.array_equal(oracle.histogram_counts(depths, bin_width, bin_count), ref_counts)
+    b = _first_local_maximum(ref_counts, min_count)
+    assert b == 8
+    lower, higher = b * bin_width, b * bin_width + bin_width
+    assert [d for d in depths if lower <= d < higher] == [8.2, 8.3, 8.4]
+    ok, keep, lo, hi = oracle.filter_points_min_dist_blob(depths, bin_width, min_count)
+    assert ok and (lo, hi) == (lower, higher) and [depths[k] for k in keep] == [8.2, 8.3, 8.4]
+
+
+def test_bin_scan_on_reference_counts_agrees_with_the_oracle_on_random_lists():
+    """Same construction on seeded random depth lists: reference binning + literal bin scan == oracle end to end."""
+    rng = np.random.default_rng(7)
+    for trial in range(300):
+        n = int(rng.integers(1, 24))
+        bw = float(rng.choice([0.3, 0.5, 1.0]))
+        mc = int(rng.integers(0, 5))
+        depths = np.round(rng.uniform(1.0, 12.0, n) if trial % 3 else rng.normal(6.0, 0.4, n).clip(0.5), 3)
+        bin_count = int(int(np.ceil(depths.max())) / bw + 1)
+        ok, keep, lo, hi = oracle.filter_points_min_dist_blob(depths, bw, mc)
+        if bin_count <= 1:
+            assert not ok
+            continue
+        b = _first_local_maximum(_ref_counts(depths, bw, bin_count), mc)
+        assert ok == (b >= 0), (trial, depths, bw, mc)
+        if ok:
+            assert (lo, hi) == (b * bw, b * bw + bw)
+            assert list(keep) == [i for i, d in enumerate(depths) if lo <= d < hi]
 
 
 @pytest.mark.parametrize("mode", [0, 1])
