@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MLD_ABI_VERSION 3
+#define MLD_ABI_VERSION 4
 
 typedef enum mld_status {
     MLD_OK = 0,
@@ -46,7 +46,7 @@ typedef enum mld_status {
     MLD_ERR_NO_GROUND_PLANE = -5,    /* do_use_ransac_plane set but no plane supplied for the slot     */
     MLD_ERR_CLOUD_TOO_SMALL = -6,    /* GroundPlane::ExceptionPclInvalid (RansacPlane.cpp:44-50)       */
     MLD_ERR_HIP = -7,                /* a HIP runtime call failed; text in mld_last_error              */
-    MLD_ERR_CAPACITY = -8            /* n / F / window larger than the context was created for         */
+    MLD_ERR_CAPACITY = -8            /* n / F / window larger than the context was created for (clouds: 8 388 607 points) */
 } mld_status;
 
 /* DepthResultType — monolidar_fusion/include/monolidar_fusion/eDepthResultType.h:8-30 (same values). */
@@ -175,6 +175,17 @@ int mld_set_clouds_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev,
                           int stride_bytes);
 
 /*
+ * setInputCloud(cloud, groundPlane) with an already segmented plane (DepthEstimator.cpp:220-312, :281: nothing to
+ * estimate) for slots [0, n_slots) in ONE launch: coeffs is n_slots x 4 (host), mask_dev a host array of device
+ * bitmask pointers (bit i of word i/32 = point i is an inlier, the device form of `_pointIsInPlane`,
+ * RansacPlane.h:116-122).  Because the plane is known when the cloud is projected, every pixel-map entry carries
+ * its point's inlier flag and the road fallback needs no mask lookups.  Equivalent to mld_set_clouds_device +
+ * mld_set_ground_planes_mask_device, which remain for planes that arrive after the cloud.
+ */
+int mld_set_clouds_planes_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev, const int64_t* n,
+                                 int stride_bytes, const float* coeffs, const uint32_t* const* mask_dev);
+
+/*
  * The GroundPlane object handed to setInputCloud/CalculateDepth (RansacPlane.h:38-123):
  * coefficients a,b,c,d in the LIDAR frame + the inlier index set keyed by ORIGINAL cloud index
  * (`_pointIsInPlane`, RansacPlane.h:116-122).  coeffs == NULL: "ransacPlane == nullptr"
@@ -299,8 +310,8 @@ int mld_result_histogram(const int32_t* types, int64_t F, int64_t counts[MLD_RES
 
 /*
  * Measurement hooks for bench.py (HIP events on the context's stream).
- *   mld_kernel_time_ms: average duration in ms of the `which` kernel (0 = project/scatter,
- *   1 = feature depth, 2 = road fallback, 3 = long-list wave kernel) over the launches since mld_timing_reset, measured with hipEvents recorded
+ *   mld_kernel_time_ms: average duration in ms of the `which` kernel (0 = k_project_scatter, 1 = k_feature_fused,
+ *   3 = k_feature_wave, 5 = k_classify) over the launches since mld_timing_reset, measured with hipEvents recorded
  *   around each launch when timing is enabled.
  */
 int mld_timing_enable(mld_ctx* ctx, int enable);

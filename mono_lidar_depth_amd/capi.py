@@ -12,7 +12,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libmld_hip.so"
 
-MLD_ABI_VERSION = 3  # include/mld.h
+MLD_ABI_VERSION = 4  # include/mld.h
 MLD_OK = 0
 MLD_ERR_INVALID_ARG = -1
 MLD_ERR_NOT_INITIALIZED = -2
@@ -122,6 +122,8 @@ _SIGNATURES = [
     ("mld_set_cloud", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     ("mld_set_cloud_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     ("mld_set_clouds_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64), C.c_int]),
+    ("mld_set_clouds_planes_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64), C.c_int,
+                                               _P(C.c_float), _P(C.c_void_p)]),
     ("mld_set_ground_plane", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p, C.c_int64]),
     ("mld_set_ground_plane_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p, C.c_int64]),
     ("mld_estimate_ground_plane", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, _P(C.c_float), _P(C.c_int64)]),
@@ -157,13 +159,11 @@ _SIGNATURES = [
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 
 _lib = None
+_lib_ab = None
+LIB_AB_PATH = _HERE / "lib" / "libmld_hip_ab.so"
 
 
-def load() -> C.CDLL:
-    """Load libmld_hip.so.  Raises (never falls back) when the HIP extension has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
+def _bind(path: Path) -> C.CDLL:
     # PyTorch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP runtimes in one process cannot
     # both own the GPU, so when torch is installed it is imported FIRST: the dynamic loader then resolves this
     # library's libamdhip64.so.7 dependency to the runtime torch already loaded.  (A C++ caller without torch
@@ -172,7 +172,6 @@ def load() -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    path = Path(os.environ.get("MLD_HIP_LIBRARY", LIB_PATH))
     if not path.exists():
         raise RuntimeError(
             f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
@@ -182,8 +181,25 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes
-    _lib = lib
     return lib
+
+
+def load() -> C.CDLL:
+    """Load libmld_hip.so.  Raises (never falls back) when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        _lib = _bind(Path(os.environ.get("MLD_HIP_LIBRARY", LIB_PATH)))
+    return _lib
+
+
+def load_ab() -> C.CDLL:
+    """The test / measurement build of the same sources (-DMLD_AB_SWITCHES, see csrc/Makefile): its mld_create reads
+    MLD_FORCE_WAVE_PATH etc. from the environment.  Used by the GPU parity suite and the A/B tools, never by the
+    product path."""
+    global _lib_ab
+    if _lib_ab is None:
+        _lib_ab = _bind(LIB_AB_PATH)
+    return _lib_ab
 
 
 def params_c0() -> MldParams:

@@ -38,8 +38,8 @@ struct Slot {
     size_t inl_cap = 0;
     uint32_t* mask_buf = nullptr;
     size_t mask_words = 0;
-    size_t road_cap = 0;  // entries of d.road_queue
-    bool queues_in_slab = false;  // road_queue / ovf_queue / perm are carved out of mld_ctx::queue_slab
+    size_t road_cap = 0;  // capacity (features) of d.live_queue / d.ovf_queue
+    bool queues_in_slab = false;  // they are carved out of mld_ctx::queue_slab
     // lazy PointcloudData for the debug getters
     bool full_valid = false;
     size_t dbg_cap = 0;
@@ -71,25 +71,20 @@ struct mld_ctx {
     std::vector<Slot> slots;
     SlotDesc* d_slots = nullptr;
     unsigned char* dummy = nullptr;  // 256 zero bytes: the cloud of a slot without points (list loops pad with point 0)
-    int32_t* road_counts = nullptr;  // per-slot queue lengths (road fallback, then long-list overflow), contiguous,
+    int32_t* queue_counts = nullptr;  // per-slot queue lengths (live features, then long-list overflow), contiguous,
                                      // placed in front of the bitmaps so that one fill clears both
-    bool counters_clean = false;
     // One allocation per kind for all slots instead of one per slot: a 1024-slot context would otherwise hold 4096
     // small mappings, and the gathers of the feature kernels would walk as many page-table fragments.
     uint32_t* map_slab = nullptr;    // pixel maps of all slots
-    int32_t* queue_slab = nullptr;   // per slot: road queue (2F), overflow queue (2F), perm (F)
+    int32_t* queue_slab = nullptr;   // per slot: overflow queue (2F), live queue (F)
     uint32_t* bitmaps = nullptr;  // occupancy bitmaps of all slots, contiguous
     size_t bitmap_words = 0;      // per slot
     std::vector<SlotDesc> h_descs;
-    size_t lds_bytes = 0;
-    size_t lds_main = 0;  // k_feature_main: four per-wave index lists + the dealing table
-    int k_main = 24;      // list capacity of k_feature_main (narrow window); the road kernel keeps calib.k1max
+    size_t lds_bytes = 0;     // k_feature_wave: xyz list of one window
     size_t lds_fused = 0;     // k_feature_fused: wide list + narrow list per wave
     size_t lds_classify = 0;  // k_classify: bucket counters + the slot's bitmap
     bool classify_staged = true;  // the bitmap fits the LDS budget of k_classify
     int bm_ncol = 0, bm_ncolp = 0;  // bitmap word columns (incl. the slack column) / padded LDS row length
-    bool legacy_split = false;    // A/B builds only: k_sort_features + k_feature_main + k_feature_road
-    bool sort_features = true;  // k_sort_features before k_feature_main (MLD_NO_SORT=1 switches it off)
     std::string err;
     // ground-plane estimation scratch (device)
     int32_t* rs_flags = nullptr;
@@ -259,33 +254,22 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     c.pcaRelMax = P.pca_treshold_3_2_rel_max;
     c.pcaRelMin = P.pca_treshold_2_1_rel_min;
     ctx->lds_bytes = (size_t)cap * (3 * sizeof(double) + 2 * sizeof(int));
-    // MLD_FORCE_WAVE_PATH=1 disables the thread-per-feature fast path (tests exercise both code paths)
-    const char* force = std::getenv("MLD_FORCE_WAVE_PATH");
-    c.threadPath = (force && force[0] == '1') ? 0 : 1;
-    // the thread path hands road-fallback candidates to a second kernel (dense lanes); MLD_NO_SPLIT_ROAD=1 keeps
-    // them inline
-    const char* noxcd = std::getenv("MLD_NO_XCD");
-    c.xcdAware = (noxcd && noxcd[0] == '1') ? 0 : 1;
-    const char* nosplit = std::getenv("MLD_NO_SPLIT_ROAD");
-    c.splitRoad = (c.threadPath && c.useRoad && !(nosplit && nosplit[0] == '1')) ? 1 : 0;
-    // list capacity of the thread path: 32 entries (8 KB of LDS per wave) keeps 16+ waves per CU resident;
-    // longer lists overflow to the wave-cooperative path.  MLD_K1MAX overrides (8..64) for experiments.
-    int k1max = 32;
-    if (const char* k = std::getenv("MLD_K1MAX")) k1max = std::atoi(k);
-    c.k1max = std::min(std::max(k1max, 8), kK1MaxLimit);
-    if (c.threadPath) ctx->lds_bytes = std::max(ctx->lds_bytes, (size_t)c.k1max * kWave * sizeof(uint32_t));
-    // the narrow window rarely holds more than two dozen points, and k_feature_main's residency is bounded by its LDS
-    // (blocks keep their lists while the dealt wavefronts finish): a smaller capacity there lets more blocks in.
-    // MLD_KMAIN overrides (8..k1max).
-    int k_main = 24;
-    if (const char* k = std::getenv("MLD_KMAIN")) k_main = std::atoi(k);
-    ctx->k_main = std::min(std::max(k_main, 8), c.k1max);
-    {
-        const char* nosort = std::getenv("MLD_NO_SORT");
-        ctx->sort_features = !(nosort && nosort[0] == '1');
-    }
-    ctx->lds_main = (size_t)(kMainThreads / kWave) * ctx->k_main * kWave * sizeof(uint32_t) + 2 * kMainThreads * sizeof(uint32_t) + 64;
-    c.kMain = ctx->k_main;
+    c.threadPath = 1;
+    c.xcdAware = 1;
+    c.splitRoad = 0;
+    // list capacities of the fused kernel: 32 entries for the scanned (road) window, 24 for the narrow one - 14 KB of
+    // LDS per wavefront; longer lists overflow to the wave-cooperative kernel
+    c.k1max = 32;
+    c.kMain = 24;
+#ifdef MLD_AB_SWITCHES
+    // Test / measurement build only (libmld_hip_ab.so): the shipped library has one code path and reads no environment.
+    //   MLD_FORCE_WAVE_PATH=1  every feature through the wave-cooperative kernel (the parity suite runs both paths)
+    //   MLD_NO_XCD=1           plain block -> slot mapping        MLD_K1MAX / MLD_KMAIN   list capacities
+    if (const char* e = std::getenv("MLD_FORCE_WAVE_PATH")) c.threadPath = (e[0] == '1') ? 0 : 1;
+    if (const char* e = std::getenv("MLD_NO_XCD")) c.xcdAware = (e[0] == '1') ? 0 : 1;
+    if (const char* e = std::getenv("MLD_K1MAX")) c.k1max = std::min(std::max(std::atoi(e), 8), kK1MaxLimit);
+    if (const char* e = std::getenv("MLD_KMAIN")) c.kMain = std::min(std::max(std::atoi(e), 8), c.k1max);
+#endif
     ctx->lds_fused = (size_t)(c.k1max + c.kMain) * kWave * sizeof(uint32_t);
     ctx->bm_ncol = (ctx->cam.width + 31) / 32 + 1;
     ctx->bm_ncolp = ctx->bm_ncol | 1;
@@ -293,10 +277,6 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     const size_t cls_bitmap = (size_t)c.bmStride * (size_t)ctx->bm_ncolp * sizeof(uint32_t);
     ctx->classify_staged = cls_fixed + cls_bitmap <= 128 * 1024;
     ctx->lds_classify = cls_fixed + (ctx->classify_staged ? cls_bitmap : 0);
-    {
-        const char* leg = std::getenv("MLD_LEGACY_SPLIT");
-        ctx->legacy_split = leg && leg[0] == '1';
-    }
 }
 
 int check_slot(mld_ctx* ctx, int slot) {
@@ -357,7 +337,7 @@ struct ScopedTimer {
 
 // New cloud for a slot: bump the map tag (zero-fill on wrap), forget the previous plane / debug data.
 int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int stride, bool clear_bitmap = true) {
-    if (n < 0 || n > kMaxPoints) return fail(ctx, MLD_ERR_CAPACITY, "cloud larger than 16 777 215 points");
+    if (n < 0 || n > kMaxPoints) return fail(ctx, MLD_ERR_CAPACITY, "cloud larger than 8 388 607 points");
     if (stride != 16 && stride != 32) return fail(ctx, MLD_ERR_INVALID_ARG, "stride_bytes must be 16 or 32");
     if (!dev_ptr && n > 0) return fail(ctx, MLD_ERR_INVALID_ARG, "null cloud pointer");
     if (((size_t)dev_ptr & 3) != 0) return fail(ctx, MLD_ERR_INVALID_ARG, "cloud pointer must be 4-byte aligned");
@@ -377,6 +357,7 @@ int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int strid
     s.d.stride = stride;
     s.d.has_plane = 0;
     s.d.inlier_mask = nullptr;
+    s.d.mask_in_key = 0;
     s.cloud_set = true;
     s.plane_decided = false;
     s.full_valid = false;
@@ -408,124 +389,51 @@ int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int sl
     return MLD_OK;
 }
 
-// The road-fallback queue of a slot must hold one entry per feature.
-int ensure_road_queue(mld_ctx* ctx, Slot& s, int64_t F) {
+// The work queues of a slot hold one entry per feature: the live queue (feature indices in row order, written by
+// k_classify) and the overflow queue ((feature, code) pairs for k_feature_wave).
+int ensure_queues(mld_ctx* ctx, Slot& s, int64_t F) {
     if ((size_t)F <= s.road_cap) return MLD_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (!s.queues_in_slab) {
-        if (s.d.road_queue) HIP_TRY(ctx, hipFree(s.d.road_queue));
         if (s.d.ovf_queue) HIP_TRY(ctx, hipFree(s.d.ovf_queue));
-        if (s.d.perm) HIP_TRY(ctx, hipFree(s.d.perm));
         if (s.d.live_queue) HIP_TRY(ctx, hipFree(s.d.live_queue));
     }
     s.queues_in_slab = false;
     s.d.live_queue = nullptr;
-    s.d.road_queue = nullptr;
     s.d.ovf_queue = nullptr;
-    s.d.perm = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**)&s.d.road_queue, (size_t)F * 2 * sizeof(int32_t)));
     HIP_TRY(ctx, hipMalloc((void**)&s.d.ovf_queue, (size_t)F * 2 * sizeof(int32_t)));
     HIP_TRY(ctx, hipMalloc((void**)&s.d.live_queue, (size_t)F * sizeof(int32_t)));
-    if (ctx->sort_features && ctx->calib.splitRoad) HIP_TRY(ctx, hipMalloc((void**)&s.d.perm, (size_t)F * sizeof(int32_t)));
     s.road_cap = (size_t)F;
     return MLD_OK;
 }
 
+// k_classify (per slot) -> k_feature_fused over the live queues -> k_feature_wave over the overflow queues.
+// k_classify sets both queue lengths, so no counter needs clearing.
 int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int slot, const Calib* override_calib = nullptr) {
     if (max_F <= 0) return MLD_OK;
     const Calib& calib = override_calib ? *override_calib : ctx->calib;
-    int per_slot = (int)((max_F + kWave - 1) / kWave);
-    const bool split = calib.splitRoad != 0;
+    const int per_slot = (int)((max_F + kWave - 1) / kWave);
     const uint32_t tag_all = single ? 0u : common_tag(ctx, n_slots);
-    if (!ctx->legacy_split) {
-        // classify (per slot) -> fused dense kernel over the live queues -> wave kernel over the overflow queues;
-        // k_classify sets both queue lengths, so no counter needs clearing
-        ctx->counters_clean = false;
-        {
-            ScopedTimer ts(ctx, 5);
-            auto kc = ctx->classify_staged ? mld::k_classify<true> : mld::k_classify<false>;
-            hipLaunchKernelGGL(kc, dim3(single ? 1u : (unsigned)n_slots), dim3(kClsThreads), ctx->lds_classify, ctx->stream,
-                               ctx->d_slots, single ? ctx->slots[slot].d : SlotDesc{}, single ? 1 : 0, calib, ctx->bm_ncol,
-                               ctx->bm_ncolp);
-        }
-        if (calib.threadPath) {
-            ScopedTimer tm(ctx, 1);
-            auto kf = calib.roadMode ? mld::k_feature_fused<1> : mld::k_feature_fused<0>;
-            const unsigned grid = single ? (unsigned)per_slot : (unsigned)per_slot * (unsigned)n_slots;
-            hipLaunchKernelGGL(kf, dim3(grid), dim3(kWave), ctx->lds_fused, ctx->stream, ctx->d_slots,
-                               single ? ctx->slots[slot].d : SlotDesc{}, single ? 1 : 0, calib, single ? 1 : n_slots, per_slot,
-                               tag_all);
-        }
-        {
-            ScopedTimer tm(ctx, 3);
-            // a batch gets 4 blocks per slot, a single slot up to 256: each block strides over the slot's queue
-            const int pw = single ? std::min(per_slot, 256) : std::min(per_slot, 4);
-            hipLaunchKernelGGL(k_feature_wave, dim3(single ? (unsigned)pw : (unsigned)pw * n_slots), dim3(kWave), ctx->lds_bytes,
-                               ctx->stream, ctx->d_slots, single ? ctx->slots[slot].d : SlotDesc{}, single ? 1 : 0, calib,
-                               single ? 1 : n_slots, pw, tag_all);
-        }
-        HIP_TRY(ctx, hipGetLastError());
-        return MLD_OK;
-    }
-    // queue lengths must be zero at launch; a batched setInputCloud has just cleared them with the bitmaps
-    if (!ctx->counters_clean)
-        HIP_TRY(ctx, hipMemsetAsync(ctx->road_counts, 0, sizeof(int32_t) * 2 * ctx->slots.size(), ctx->stream));
-    ctx->counters_clean = false;
-    if (split && ctx->sort_features) {
-        // features in row order first (MLD_NO_SORT=1 keeps the caller's order: no SlotDesc::perm is allocated then)
-        ScopedTimer ts(ctx, 5);
-        if (single) {
-            hipLaunchKernelGGL(k_sort_features, dim3(1), dim3(kSortThreads), 0, ctx->stream, ctx->d_slots, ctx->slots[slot].d, 1,
-                               calib);
-        } else {
-            hipLaunchKernelGGL(k_sort_features, dim3((unsigned)n_slots), dim3(kSortThreads), 0, ctx->stream, ctx->d_slots,
-                               SlotDesc{}, 0, calib);
-        }
-    }
+    const SlotDesc one = single ? ctx->slots[slot].d : SlotDesc{};
+    const int use_single = single ? 1 : 0, ns = single ? 1 : n_slots;
     {
-        ScopedTimer tm(ctx, 1);
-        if (split) {
-            // 256 features per block; the block re-deals its live features to dense wavefronts
-            const int pm = (int)((max_F + kMainThreads - 1) / kMainThreads);
-            Calib cm = calib;
-            cm.k1max = ctx->k_main;
-            if (single) {
-                hipLaunchKernelGGL(k_feature_main, dim3(pm), dim3(kMainThreads), ctx->lds_main, ctx->stream, ctx->d_slots,
-                                   ctx->slots[slot].d, 1, cm, 1, pm, 0u);
-            } else {
-                hipLaunchKernelGGL(k_feature_main, dim3((unsigned)pm * n_slots), dim3(kMainThreads), ctx->lds_main,
-                                   ctx->stream, ctx->d_slots, SlotDesc{}, 0, cm, n_slots, pm, tag_all);
-            }
-        } else if (single) {
-            hipLaunchKernelGGL(k_feature_depth, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream,
-                               ctx->d_slots, ctx->slots[slot].d, 1, calib, 1, per_slot, 0u);
-        } else {
-            hipLaunchKernelGGL(k_feature_depth, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
-                               ctx->stream, ctx->d_slots, SlotDesc{}, 0, calib, n_slots, per_slot, tag_all);
-        }
+        ScopedTimer ts(ctx, 5);
+        auto kc = ctx->classify_staged ? mld::k_classify<true> : mld::k_classify<false>;
+        hipLaunchKernelGGL(kc, dim3((unsigned)ns), dim3(kClsThreads), ctx->lds_classify, ctx->stream, ctx->d_slots, one,
+                           use_single, calib, ctx->bm_ncol, ctx->bm_ncolp);
     }
-    if (split) {
-        ScopedTimer tm(ctx, 2);
-        auto k_feature_road = calib.roadMode ? mld::k_feature_road<1> : mld::k_feature_road<0>;
-        if (single) {
-            hipLaunchKernelGGL(k_feature_road, dim3(per_slot), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
-                               ctx->slots[slot].d, 1, calib, 1, per_slot, 0u);
-        } else {
-            hipLaunchKernelGGL(k_feature_road, dim3((unsigned)per_slot * n_slots), dim3(kWave), ctx->lds_bytes,
-                               ctx->stream, ctx->d_slots, SlotDesc{}, 0, calib, n_slots, per_slot, tag_all);
-        }
+    if (calib.threadPath) {
+        ScopedTimer tm(ctx, 1);
+        auto kf = calib.roadMode ? mld::k_feature_fused<1> : mld::k_feature_fused<0>;
+        hipLaunchKernelGGL(kf, dim3((unsigned)per_slot * (unsigned)ns), dim3(kWave), ctx->lds_fused, ctx->stream, ctx->d_slots,
+                           one, use_single, calib, ns, per_slot, tag_all);
     }
     {
         ScopedTimer tm(ctx, 3);
         // a batch gets 4 blocks per slot, a single slot up to 256: each block strides over the slot's queue
         const int pw = single ? std::min(per_slot, 256) : std::min(per_slot, 4);
-        if (single) {
-            hipLaunchKernelGGL(k_feature_wave, dim3(pw), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots,
-                               ctx->slots[slot].d, 1, calib, 1, pw, 0u);
-        } else {
-            hipLaunchKernelGGL(k_feature_wave, dim3((unsigned)pw * n_slots), dim3(kWave), ctx->lds_bytes, ctx->stream,
-                               ctx->d_slots, SlotDesc{}, 0, calib, n_slots, pw, tag_all);
-        }
+        hipLaunchKernelGGL(k_feature_wave, dim3((unsigned)pw * (unsigned)ns), dim3(kWave), ctx->lds_bytes, ctx->stream,
+                           ctx->d_slots, one, use_single, calib, ns, pw, tag_all);
     }
     HIP_TRY(ctx, hipGetLastError());
     return MLD_OK;
@@ -562,14 +470,9 @@ int precheck_calc(mld_ctx* ctx, Slot& s, int64_t F) {
     return MLD_OK;
 }
 
-int set_plane_common(mld_ctx* ctx, Slot& s, const float coeffs[4]) {
-    if (!s.cloud_set) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "ground plane set before the slot's cloud");
-    s.plane_decided = true;
-    if (!coeffs) {
-        s.d.has_plane = 0;
-        s.d.inlier_mask = nullptr;
-        return 1;  // handled
-    }
+// Commits the plane coefficients of a slot: coeffs + the M-estimator prior (DepthEstimator.cpp:286-292).  Callers
+// validate their arguments and build the inlier mask BEFORE this, so that a failed call leaves the slot as it was.
+void set_plane_coeffs(Slot& s, const float coeffs[4]) {
     std::memcpy(s.d.coeffs, coeffs, sizeof(float) * 4);
     // DepthEstimator.cpp:289-291: prior = Hyperplane(Vector3d(a,b,c).normalized(), d)
     double a = (double)coeffs[0], b = (double)coeffs[1], cc = (double)coeffs[2];
@@ -585,7 +488,15 @@ int set_plane_common(mld_ctx* ctx, Slot& s, const float coeffs[4]) {
     s.d.prior_n[2] = cc;
     s.d.prior_off = (double)coeffs[3];
     s.d.has_plane = 1;
-    return MLD_OK;
+    s.plane_decided = true;
+}
+
+// "ransacPlane == nullptr" (DepthEstimator.cpp:580): the road fallback is skipped for this cloud.
+void clear_plane(Slot& s) {
+    s.d.has_plane = 0;
+    s.d.inlier_mask = nullptr;
+    s.d.mask_in_key = 0;
+    s.plane_decided = true;
 }
 
 int build_mask_from_indices(mld_ctx* ctx, Slot& s, const int32_t* idx_dev, int64_t n_inl) {
@@ -599,7 +510,6 @@ int build_mask_from_indices(mld_ctx* ctx, Slot& s, const int32_t* idx_dev, int64
                            (long long)s.d.n, s.mask_buf);
         HIP_TRY(ctx, hipGetLastError());
     }
-    s.d.inlier_mask = s.mask_buf;
     return MLD_OK;
 }
 
@@ -666,7 +576,7 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
         return bail(MLD_ERR_INVALID_ARG, "bad camera intrinsics");
     for (int t = 0; t < 12; t++)
         if (!std::isfinite(T_cam_lidar[t])) return bail(MLD_ERR_INVALID_ARG, "non-finite lidar->camera transform");
-    if (max_points > kMaxPoints) return bail(MLD_ERR_CAPACITY, "max_points exceeds 16 777 215");
+    if (max_points > kMaxPoints) return bail(MLD_ERR_CAPACITY, "max_points exceeds 8 388 607");
     std::string why;
     int v = validate_params(*params, why);
     if (v != MLD_OK) return bail(v, why);
@@ -697,24 +607,10 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     }
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
         return hip_bail(e, "hipStreamCreate");
-    if (ctx->lds_main > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_main), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)ctx->lds_main);
-        if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute");
-    }
     if (ctx->lds_bytes > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_depth),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_road<0>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_road<1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_wave),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
-        if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute");
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_wave), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)ctx->lds_bytes);
+        if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute(k_feature_wave)");
     }
     if (ctx->lds_classify > 48 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_classify<true>),
@@ -739,16 +635,15 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     ctx->bitmap_words = (size_t)ctx->calib.bmStride * (size_t)((camera->width + 31) / 32 + 1) + 4;  // + a slack column
     // one allocation: [queue lengths: max_frames road fallback + max_frames long-list overflow][bitmaps of the slots]
     const size_t cnt_words = 2 * (size_t)max_frames;
-    if ((e = hipMalloc((void**)&ctx->road_counts, (cnt_words + ctx->bitmap_words * (size_t)max_frames) * sizeof(uint32_t))) != hipSuccess)
+    if ((e = hipMalloc((void**)&ctx->queue_counts, (cnt_words + ctx->bitmap_words * (size_t)max_frames) * sizeof(uint32_t))) != hipSuccess)
         return hip_bail(e, "hipMalloc(bitmaps)");
-    ctx->bitmaps = reinterpret_cast<uint32_t*>(ctx->road_counts) + cnt_words;
-    if ((e = hipMemsetAsync(ctx->road_counts, 0, cnt_words * sizeof(uint32_t), ctx->stream)) != hipSuccess)
+    ctx->bitmaps = reinterpret_cast<uint32_t*>(ctx->queue_counts) + cnt_words;
+    if ((e = hipMemsetAsync(ctx->queue_counts, 0, cnt_words * sizeof(uint32_t), ctx->stream)) != hipSuccess)
         return hip_bail(e, "hipMemset(counters)");
     for (size_t si = 0; si < ctx->slots.size(); si++) ctx->slots[si].d.bitmap = ctx->bitmaps + si * ctx->bitmap_words;
     for (size_t si = 0; si < ctx->slots.size(); si++) {
-        ctx->slots[si].d.road_count = ctx->road_counts + si;
-        ctx->slots[si].d.live_count = ctx->road_counts + si;  // the legacy road queue and the live queue never coexist
-        ctx->slots[si].d.ovf_count = ctx->road_counts + (size_t)max_frames + si;
+        ctx->slots[si].d.live_count = ctx->queue_counts + si;
+        ctx->slots[si].d.ovf_count = ctx->queue_counts + (size_t)max_frames + si;
     }
     const size_t map_stride = (cells + 63) & ~(size_t)63;  // words; slots start on 256-byte boundaries
     if ((e = hipMalloc((void**)&ctx->map_slab, map_stride * (size_t)max_frames * sizeof(uint32_t))) != hipSuccess)
@@ -756,8 +651,7 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if ((e = hipMemsetAsync(ctx->map_slab, 0, map_stride * (size_t)max_frames * sizeof(uint32_t), ctx->stream)) != hipSuccess)
         return hip_bail(e, "hipMemset(maps)");
     const size_t qF = max_features > 0 ? (((size_t)max_features + 63) & ~(size_t)63) : 0;  // queue entries per slot
-    const bool want_perm = ctx->sort_features && ctx->calib.splitRoad;
-    const size_t q_stride = qF * (want_perm ? 6 : 5);  // int32 words per slot
+    const size_t q_stride = qF * 3;  // int32 words per slot: overflow queue (2F) + live queue (F)
     if (qF && (e = hipMalloc((void**)&ctx->queue_slab, q_stride * (size_t)max_frames * sizeof(int32_t))) != hipSuccess)
         return hip_bail(e, "hipMalloc(queues)");
     for (size_t si = 0; si < ctx->slots.size(); si++) {
@@ -767,10 +661,8 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
         if (qF) {
             // work queues of the feature kernels: no allocation in the first CalculateDepth
             int32_t* q = ctx->queue_slab + si * q_stride;
-            s.d.road_queue = q;
-            s.d.ovf_queue = q + 2 * qF;
-            s.d.live_queue = q + 4 * qF;
-            s.d.perm = want_perm ? q + 5 * qF : nullptr;
+            s.d.ovf_queue = q;
+            s.d.live_queue = q + 2 * qF;
             s.road_cap = qF;
             s.queues_in_slab = true;
         }
@@ -797,9 +689,7 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (Slot& s : ctx->slots) {
         if (!s.queues_in_slab) {
-            if (s.d.road_queue) (void)hipFree(s.d.road_queue);
             if (s.d.ovf_queue) (void)hipFree(s.d.ovf_queue);
-            if (s.d.perm) (void)hipFree(s.d.perm);
             if (s.d.live_queue) (void)hipFree(s.d.live_queue);
         }
         void* ptrs[] = {s.cloud_buf, s.uv_buf, s.depth_buf, s.type_buf, s.inl_buf,    s.mask_buf, s.cam,
@@ -811,7 +701,7 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->queue_slab) (void)hipFree(ctx->queue_slab);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->dummy) (void)hipFree(ctx->dummy);
-    if (ctx->road_counts) (void)hipFree(ctx->road_counts);  // also holds the bitmaps
+    if (ctx->queue_counts) (void)hipFree(ctx->queue_counts);  // also holds the bitmaps
     void* rsp[] = {ctx->rs_flags, ctx->rs_cand, ctx->rs_block, ctx->rs_M, ctx->rs_S, ctx->rs_sample, ctx->rs_sp,
                    ctx->rs_counts, ctx->rs_inl, ctx->rs_res, ctx->sem_img, ctx->sem_coeffs, ctx->sem_res};
     for (void* p : rsp)
@@ -863,23 +753,43 @@ int mld_set_cloud(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, int s
     return launch_project(ctx, 1, n, true, slot);
 }
 
-int mld_set_clouds_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev, const int64_t* n, int stride_bytes) {
+// setInputCloud for slots [0, n_slots) in one launch; coeffs / mask_dev (both or neither): the ground planes, known
+// before the projection, whose inlier flags then travel in the map keys.
+static int set_clouds_common(mld_ctx* ctx, int n_slots, const void* const* pts_dev, const int64_t* n, int stride_bytes,
+                             const float* coeffs, const uint32_t* const* mask_dev) {
     if (!ctx) return MLD_ERR_INVALID_ARG;
     if (n_slots < 1 || n_slots > (int)ctx->slots.size() || !pts_dev || !n)
         return fail(ctx, MLD_ERR_INVALID_ARG, "bad slot count / null arrays");
     int rc = bind_device(ctx);
     if (rc) return rc;
+    if (mask_dev)
+        for (int i = 0; i < n_slots; i++)
+            if (!mask_dev[i]) return fail(ctx, MLD_ERR_INVALID_ARG, "null mask");
     int64_t max_n = 0;
-    // the queue lengths and the slots' occupancy bitmaps are contiguous: one fill for the whole batch
-    HIP_TRY(ctx, hipMemsetAsync(ctx->road_counts, 0,
-                                (2 * ctx->slots.size() + ctx->bitmap_words * (size_t)n_slots) * sizeof(uint32_t), ctx->stream));
-    ctx->counters_clean = true;
+    // the slots' occupancy bitmaps are contiguous: one fill for the whole batch
+    HIP_TRY(ctx, hipMemsetAsync(ctx->bitmaps, 0, ctx->bitmap_words * (size_t)n_slots * sizeof(uint32_t), ctx->stream));
     for (int i = 0; i < n_slots; i++) {
-        if ((rc = begin_cloud(ctx, ctx->slots[i], pts_dev[i], n[i], stride_bytes, false))) return rc;
+        Slot& s = ctx->slots[i];
+        if ((rc = begin_cloud(ctx, s, pts_dev[i], n[i], stride_bytes, false))) return rc;
+        if (coeffs) {
+            set_plane_coeffs(s, coeffs + 4 * i);
+            s.d.inlier_mask = mask_dev[i];
+            s.d.mask_in_key = 1;
+        }
         max_n = std::max(max_n, n[i]);
     }
     if ((rc = upload_descs(ctx, n_slots))) return rc;
     return launch_project(ctx, n_slots, max_n, false, 0);
+}
+
+int mld_set_clouds_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev, const int64_t* n, int stride_bytes) {
+    return set_clouds_common(ctx, n_slots, pts_dev, n, stride_bytes, nullptr, nullptr);
+}
+
+int mld_set_clouds_planes_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev, const int64_t* n, int stride_bytes,
+                                 const float* coeffs, const uint32_t* const* mask_dev) {
+    if (ctx && (!coeffs || !mask_dev)) return fail(ctx, MLD_ERR_INVALID_ARG, "null plane arrays");
+    return set_clouds_common(ctx, n_slots, pts_dev, n, stride_bytes, coeffs, mask_dev);
 }
 
 // ---------------------------------------------------------------------------- ground plane
@@ -889,11 +799,18 @@ int mld_set_ground_plane_device(mld_ctx* ctx, int slot, const float coeffs[4], c
     if (rc) return rc;
     if ((rc = bind_device(ctx))) return rc;
     Slot& s = ctx->slots[slot];
-    rc = set_plane_common(ctx, s, coeffs);
-    if (rc == 1) return MLD_OK;
-    if (rc) return rc;
+    if (!s.cloud_set) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "ground plane set before the slot's cloud");
+    if (!coeffs) {
+        clear_plane(s);
+        return MLD_OK;
+    }
     if (n_inliers < 0 || (!inlier_idx_dev && n_inliers > 0)) return fail(ctx, MLD_ERR_INVALID_ARG, "bad inlier list");
-    return build_mask_from_indices(ctx, s, inlier_idx_dev, n_inliers);
+    // mask first, commit afterwards: a failure leaves the slot's previous plane state untouched
+    if ((rc = build_mask_from_indices(ctx, s, inlier_idx_dev, n_inliers))) return rc;
+    set_plane_coeffs(s, coeffs);
+    s.d.inlier_mask = s.mask_buf;
+    s.d.mask_in_key = 0;
+    return MLD_OK;
 }
 
 int mld_set_ground_plane(mld_ctx* ctx, int slot, const float coeffs[4], const int32_t* inlier_idx_host,
@@ -902,15 +819,21 @@ int mld_set_ground_plane(mld_ctx* ctx, int slot, const float coeffs[4], const in
     if (rc) return rc;
     if ((rc = bind_device(ctx))) return rc;
     Slot& s = ctx->slots[slot];
-    rc = set_plane_common(ctx, s, coeffs);
-    if (rc == 1) return MLD_OK;
-    if (rc) return rc;
+    if (!s.cloud_set) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "ground plane set before the slot's cloud");
+    if (!coeffs) {
+        clear_plane(s);
+        return MLD_OK;
+    }
     if (n_inliers < 0 || (!inlier_idx_host && n_inliers > 0)) return fail(ctx, MLD_ERR_INVALID_ARG, "bad inlier list");
     if ((rc = grow(ctx, s.inl_buf, s.inl_cap, (size_t)n_inliers))) return rc;
     if (n_inliers)
         HIP_TRY(ctx, hipMemcpyAsync(s.inl_buf, inlier_idx_host, (size_t)n_inliers * sizeof(int32_t),
                                     hipMemcpyHostToDevice, ctx->stream));
-    return build_mask_from_indices(ctx, s, s.inl_buf, n_inliers);
+    if ((rc = build_mask_from_indices(ctx, s, s.inl_buf, n_inliers))) return rc;
+    set_plane_coeffs(s, coeffs);
+    s.d.inlier_mask = s.mask_buf;
+    s.d.mask_in_key = 0;
+    return MLD_OK;
 }
 
 // per-point flags, their order-preserving compaction and the block sums in between
@@ -985,10 +908,14 @@ int mld_estimate_ground_plane(mld_ctx* ctx, int slot, uint32_t seed, float coeff
     Result res;
     HIP_TRY(ctx, hipMemcpyAsync(&res, ctx->rs_res, sizeof(Result), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (res.status != 0) return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");
-    rc = set_plane_common(ctx, s, res.coeffs);
-    if (rc) return rc;
+    if (res.status != 0) {
+        clear_plane(s);  // the slot's mask buffer has been overwritten
+        s.plane_decided = false;
+        return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");
+    }
+    set_plane_coeffs(s, res.coeffs);
     s.d.inlier_mask = s.mask_buf;
+    s.d.mask_in_key = 0;
     if (coeffs_out)
         for (int t = 0; t < 4; t++) coeffs_out[t] = res.coeffs[t];
     if (n_inliers_out) *n_inliers_out = res.n_inliers;
@@ -1046,10 +973,14 @@ static int semantic_plane_core(mld_ctx* ctx, Slot& s, const unsigned char* img_d
     SemResult res;
     HIP_TRY(ctx, hipMemcpyAsync(&res, ctx->sem_res, sizeof(SemResult), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (res.status != 0) return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");  // :224-227
-    rc = set_plane_common(ctx, s, res.coeffs);
-    if (rc) return rc;
+    if (res.status != 0) {  // :224-227
+        clear_plane(s);  // the slot's mask buffer has been overwritten
+        s.plane_decided = false;
+        return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");
+    }
+    set_plane_coeffs(s, res.coeffs);
     s.d.inlier_mask = s.mask_buf;
+    s.d.mask_in_key = 0;
     if (coeffs_out)
         for (int t = 0; t < 4; t++) coeffs_out[t] = res.coeffs[t];
     if (n_inliers_out) *n_inliers_out = res.n_inliers;
@@ -1114,11 +1045,15 @@ int mld_set_ground_plane_mask_device(mld_ctx* ctx, int slot, const float coeffs[
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     Slot& s = ctx->slots[slot];
-    rc = set_plane_common(ctx, s, coeffs);
-    if (rc == 1) return MLD_OK;
-    if (rc) return rc;
+    if (!s.cloud_set) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "ground plane set before the slot's cloud");
+    if (!coeffs) {
+        clear_plane(s);
+        return MLD_OK;
+    }
     if (!mask_dev) return fail(ctx, MLD_ERR_INVALID_ARG, "null mask");
+    set_plane_coeffs(s, coeffs);
     s.d.inlier_mask = mask_dev;
+    s.d.mask_in_key = 0;
     return MLD_OK;
 }
 
@@ -1143,7 +1078,7 @@ static int calc_one(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, dou
     s.d.type = type_dev;
     if (F == 0) return MLD_OK;
     {
-        int rcq = ensure_road_queue(ctx, s, F);
+        int rcq = ensure_queues(ctx, s, F);
         if (rcq) return rcq;
     }
     if (ctx->P.set_all_depths_to_zero) {
@@ -1301,7 +1236,7 @@ int mld_calculate_depths_device(mld_ctx* ctx, int n_slots, const double* const* 
         s.d.F = F[i];
         s.d.depth = depth_out_dev[i];
         s.d.type = type_out_dev ? type_out_dev[i] : nullptr;
-        if ((rc = ensure_road_queue(ctx, s, F[i]))) return rc;
+        if ((rc = ensure_queues(ctx, s, F[i]))) return rc;
         max_F = std::max(max_F, F[i]);
     }
     if (ctx->P.set_all_depths_to_zero) {

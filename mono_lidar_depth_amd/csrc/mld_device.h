@@ -6,9 +6,16 @@
 namespace mld {
 
 constexpr int kWave = 64;
-constexpr uint32_t kIdxBits = 24;               // pixel-map key: [tag:8 | (0xFFFFFF - origIdx):24]
-constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1u;
-constexpr int64_t kMaxPoints = (int64_t)kIdxMask;  // points per cloud representable in a key
+// pixel-map key: [tag:8 | (0x7FFFFF - origIdx):23 | ground-plane inlier:1]; atomicMax keeps the smallest original
+// index of the newest tag (indices are unique, so the flag bit never decides)
+constexpr uint32_t kIdxBits = 24;
+constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1u;  // list entries keep the point index in their low 24 bits
+constexpr uint32_t kKeyIdxMax = (1u << 23) - 1u;
+constexpr int64_t kMaxPoints = (int64_t)kKeyIdxMax;  // points per cloud representable in a key
+__host__ __device__ inline uint32_t make_key(uint32_t tag, uint32_t idx, uint32_t inlier) {
+    return (tag << kIdxBits) | ((kKeyIdxMax - idx) << 1) | (inlier & 1u);
+}
+__host__ __device__ inline uint32_t key_index(uint32_t key) { return kKeyIdxMax - ((key & kIdxMask) >> 1); }
 constexpr uint32_t kMaxTag = 255;
 constexpr int kMapPadCells = 16;  // the thread path reads rows with 16-byte loads that may overrun the last cell
 
@@ -44,7 +51,7 @@ struct Calib {
     int bmStride;    // words per 32-pixel column of the occupancy bitmap (word = (x >> 5) * bmStride + y): H + slack
     int k1max;       // thread path: neighbour list capacity per feature (entries in LDS)
     int kMain;       // fused kernel: capacity of the narrow-window list
-    int splitRoad;   // 1: the thread path queues road-fallback candidates for k_feature_road instead of running them inline
+    int splitRoad;   // unused (kept for layout stability of diagnostic builds)
     int xcdAware;    // 1: blocks of one slot are congruent mod 8 (same XCD under round-robin dispatch)
     int threadPath;  // 1: thread-per-feature fast path with wave-cooperative overflow; 0: wave path only
 };
@@ -58,11 +65,8 @@ struct SlotDesc {
     double* depth;                // F
     int32_t* type;                // F or nullptr
     const uint32_t* inlier_mask;  // bit i = original point i is a ground-plane inlier; nullptr = no plane
-    int32_t* road_queue;          // (feature index, main-path result) pairs queued for k_feature_road
-    int32_t* road_count;          // number of queued pairs (zeroed before every CalculateDepth launch)
     int32_t* ovf_queue;           // (feature index, code) pairs queued for k_feature_wave (long lists)
     int32_t* ovf_count;
-    int32_t* perm;                // feature order of k_feature_main (features sorted by image row), or nullptr = as given
     int32_t* live_queue;          // indices of the features k_classify found live, sorted by image row
     int32_t* live_count;          // their number
     double* corners;              // debug mode only: 9 x F triangle corners (NaN = none), written by k_feature_wave
@@ -75,7 +79,7 @@ struct SlotDesc {
     int stride;
     uint32_t tag;  // current map tag, 1..255
     int has_plane;
-    int pad_;
+    int mask_in_key;  // 1: the inlier flag of every map key is valid (the plane was known when the cloud was projected)
 };
 
 }  // namespace mld

@@ -7,18 +7,18 @@
 //   k_project_scatter : Transform_Cloud_LidarToCamera + getImagePoints + InitializeLidarProjection
 //                       (DepthEstimator.cpp:156-217, camera_pinhole.h:84-97, NeighborFinderPixel.cpp:29-58)
 //                       fused: one coalesced pass over the cloud, no intermediate arrays.
-//   k_sort_features   : row-order permutation of a frame's features (locality of the window scans and gathers).
-//   k_feature_main    : the per-feature loop (DepthEstimator.cpp:455-576), lane = feature, 256-thread blocks that
-//                       re-deal their live features to dense wavefronts after the window scan.
-//   k_feature_road    : the road fallback (DepthEstimator.cpp:578-597) for the features k_feature_main queued.
-//   k_feature_wave    : wavefront-per-feature variant for lists beyond the thread kernels' capacities (and debug mode).
-//   k_feature_depth   : main path + road fallback in one 64-thread kernel (A/B switch MLD_NO_SPLIT_ROAD=1).
+//   k_classify        : one block per frame slot; the slot's occupancy bitmap staged in LDS; features without enough
+//                       neighbours get their result at once, the others go, in image-row order, to the live queue.
+//   k_feature_fused   : the per-feature loop (DepthEstimator.cpp:455-597), one lane per live feature: ONE scan of the
+//                       road window serves the main path (its narrow sub-list) and the road fallback.
+//   k_feature_wave    : wavefront-per-feature variant for lists beyond the thread kernel's capacities (and debug mode).
 //   k_project_full / k_scan_* / k_export_* : lazy debug getters (visible list, _pointIndex, pixel map).
 //
 // Pixel map encoding.  The reference map holds the VISIBLE index of the first point (in cloud order,
 // with z_cam > 0) that falls into the pixel.  Visible indices preserve cloud order, so "first visible
 // index" == "smallest ORIGINAL index".  The device map stores
-//     key = tag << 24 | (0xFFFFFF - origIdx)         (atomicMax: smallest origIdx of the newest tag wins)
+//     key = tag << 24 | (0x7FFFFF - origIdx) << 1 | inlier     (atomicMax: smallest origIdx of the newest tag wins;
+//                                                                 inlier = ground-plane flag, when known at projection)
 // where tag is bumped per setInputCloud, which makes clearing the 1.86 MB map unnecessary (a stale key has
 // a smaller tag and loses / is ignored).  The map is zero-filled when the tag wraps (every 255 frames).
 // Neighbours are re-derived from the raw float point at gather time (bit-identical arithmetic), so no
@@ -284,7 +284,9 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
         // DepthEstimator.cpp:186-187 strict bounds (imply the inclusive test of camera_pinhole.h:93-95)
         if ((u > 0.0) && (u < Wd) && (v > 0.0) && (v < Hd)) {
             int xi = (int)u, yi = (int)v;  // truncation, NeighborFinderPixel.cpp:41-42
-            uint32_t key = (s.tag << kIdxBits) | (kIdxMask - (uint32_t)i);
+            uint32_t inl = 0u;
+            if (s.mask_in_key) inl = (GPTR(uint32_t, s.inlier_mask)[(size_t)i >> 5] >> ((uint32_t)i & 31u)) & 1u;
+            const uint32_t key = make_key(s.tag, (uint32_t)i, inl);
             __hip_atomic_fetch_max(GPTRW(uint32_t, s.map) + ((size_t)xi + (size_t)yi * (size_t)c.W), key,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bmw[r] = (xi >> 5) * c.bmStride + yi;
@@ -377,7 +379,7 @@ __device__ int gather_window(const Calib& c, const SlotDesc& s, double u, double
             int col = cidx - row * nx;
             uint32_t key = GPTR(uint32_t, s.map)[(size_t)(x0 + col) + (size_t)(y0 + row) * (size_t)c.W];
             has = (key >> kIdxBits) == s.tag;
-            orig = (int)(kIdxMask - (key & kIdxMask));
+            orig = (int)key_index(key);
         }
         unsigned long long m = __ballot(has);
         int rank = k + prefix_count(m);
@@ -951,11 +953,8 @@ __device__ __forceinline__ void finish_road(const Calib& c, bool triangle, doubl
 // tolerance of the exact form).  r[0..2]: weighted centre, r[3..8]: weighted scatter, r[9], r[10]: min / max z.
 __device__ __forceinline__ void finish_road_fast(const Calib& c, double u, double v, const double r[kRecFields],
                                                  int& out_type, double& out_depth) {
-    // CameraPinhole::getViewingRays + flip (camera_pinhole.h:52-69, DepthEstimator.cpp:938-939)
-    V3 d = {(c.Kinv[0] * u + c.Kinv[1] * v) + c.Kinv[2], (c.Kinv[3] * u + c.Kinv[4] * v) + c.Kinv[5],
-            (c.Kinv[6] * u + c.Kinv[7] * v) + c.Kinv[8]};
-    d = fast_normalized(d);
-    if (d.z < 0) d = vscale(d, -1.0);
+    const V3 dir = viewing_ray(c, u, v);
+    const V3 support = {0, 0, 0};
     const V3 center = {r[0], r[1], r[2]};
     double ev[3];
     V3 n0;
@@ -964,12 +963,13 @@ __device__ __forceinline__ void finish_road_fast(const Calib& c, double u, doubl
         const double qn = __builtin_nan("");
         n0 = {qn, qn, qn};
     }
-    n0 = fast_normalized(n0);
-    const double offset = -vdot(n0, center);
-    // ParametrizedLine::Through(n0 = direction, n1 = support = 0): origin d, direction (0 - d).normalized()
-    const V3 dir = fast_normalized(vscale(d, -1.0));
-    const double t = -(offset + vdot(n0, d)) * fast_rcp(vdot(n0, dir));
-    double depth = d.z + dir.z * t;
+    Plane pl;
+    pl.n = vnormalized(n0);
+    pl.offset = -vdot(pl.n, center);
+    // the intersection itself keeps the IEEE operations of the exact form: a plane through the camera centre gives
+    // the depth 0.0 exactly there, which sits ON the global threshold (treshold_depth_min = 0)
+    double depth = -1.0;
+    intersect(c, false, pl, dir, support, depth);  // n0 = direction, n1 = support (swapped, as the reference)
     int type = MLD_SuccessRoad;
     const int th = apply_thresholds(c, r[9], r[10], depth);
     if (th) type = th;
@@ -1078,7 +1078,7 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
 
     // ---------------- phase 3: road fallback (DepthEstimator.cpp:578-597) ----------------
     // Candidates: everything that is not Success and did not already return at :509-510.
-    const bool road_on = c.useRoad && s.has_plane;
+    const bool road_on = c.useRoad && s.has_plane && s.inlier_mask;
     bool cand = road_on && inmask && (mytype != MLD_Success) && (mytype != MLD_RadiusSearchInsufficientPoints);
     unsigned long long cm = __ballot(cand);
     while (cm) {
@@ -1255,103 +1255,6 @@ __device__ __forceinline__ V3 raw_point(const Calib& c, RawP r) { return lidar_t
 // list entry e of this lane, or 0 (a valid point index whenever any list is non-empty) beyond the list end
 #define LST_ID(e, n) (((e) < (n)) ? (LST(min((e), c.k1max - 1)) & kIdxMask) : 0u)
 
-// Window scan through the occupancy bitmap: the key map has one occupied cell in ~30, so reading it row by row
-// drags almost every 128-byte line of the 1.86 MB map through HBM.  The bitmap (63 KB per frame, cache resident)
-// tells which cells to fetch.  Pass 1 appends the CELL indices of the set bits (row-major order) to the lane's
-// list; pass 2 turns them into point indices with batched key loads.  Windows up to 32 cells wide.
-__device__ __forceinline__ int scan_window_bitmap(const Calib& c, const SlotDesc& s, int x0, int y0, int nx, int ny,
-                                                  uint32_t* lst, int lane ST_ARG) {
-    const int nymax = uniform(wave_max_i32(ny));
-    const auto* bm = GPTR(uint32_t, s.bitmap);
-    const unsigned long long colmask = (nx >= 64) ? ~0ull : ((1ull << nx) - 1ull);
-    int k = 0;
-    // The bitmap stores one column of 32 pixels contiguously (word = (x >> 5) * bmStride + y), so the rows of a
-    // window are consecutive words: four rows per 16-byte load, from the two word columns the window can straddle.
-    const auto* col0 = bm + (size_t)(x0 >> 5) * (size_t)c.bmStride + (size_t)y0;
-    const auto* col1 = col0 + c.bmStride;
-    const int sh = x0 & 31;
-    for (int r0 = 0; r0 < nymax; r0 += 8) {
-        u32x4u a[2], b2[2];
-#pragma unroll
-        for (int g = 0; g < 2; g++) {
-            a[g] = u32x4u{0u, 0u, 0u, 0u};
-            b2[g] = u32x4u{0u, 0u, 0u, 0u};
-            if (r0 + 4 * g < nymax) {  // wave-uniform
-                if (r0 + 4 * g < ny) {
-                    a[g] = *GPTR(u32x4u, col0 + r0 + 4 * g);
-                    b2[g] = *GPTR(u32x4u, col1 + r0 + 4 * g);
-                }
-            }
-        }
-        ST_USE_U32(a[0][0]);
-        ST_USE_U32(b2[0][0]);
-        ST_USE_U32(a[1][0]);
-        ST_USE_U32(b2[1][0]);
-        ST_MARK(2);
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            if (r0 + q < nymax) {
-                const unsigned long long v = ((unsigned long long)b2[q >> 2][q & 3] << 32) | (unsigned long long)a[q >> 2][q & 3];
-                unsigned long long b = ((r0 + q) < ny) ? ((v >> sh) & colmask) : 0ull;
-                const uint32_t rowbase = (uint32_t)((y0 + r0 + q) * c.W + x0);
-                while (b) {
-                    const int col = __ffsll((long long)b) - 1;
-                    b &= b - 1;
-                    if (k < c.k1max) LST(k) = rowbase + (uint32_t)col;
-                    k++;
-                }
-            }
-        }
-    }
-    // cell index -> original point index (every set bit has a key of the current tag)
-    ST_MARK(3);
-    const int kk = k <= c.k1max ? k : 0;  // overflowing lists (k > k1max) are redone by the wave path
-    const int kmax = uniform(wave_max_i32(kk));
-    const auto* mp = GPTR(uint32_t, s.map);
-    for (int e0 = 0; e0 < kmax; e0 += kKeyBatch) {
-        uint32_t key[kKeyBatch];
-#pragma unroll
-        for (int q = 0; q < kKeyBatch; q++) key[q] = (e0 + q < kk) ? mp[LST(min(e0 + q, c.k1max - 1))] : 0u;
-#pragma unroll
-        for (int q = 0; q < kKeyBatch; q++)
-            if (e0 + q < kk) LST(e0 + q) = kIdxMask - (key[q] & kIdxMask);
-    }
-    ST_MARK(4);
-    return k;
-}
-
-// Row-major window scan by one thread (NeighborFinderPixel.cpp:60-95): appends the original indices of the
-// occupied cells to the thread's LDS list.  Returns the count (may exceed c.k1max: overflow).
-__device__ __forceinline__ int scan_window_thread(const Calib& c, const SlotDesc& s, double u, double v, double halfX, double halfY,
-                                  bool active, uint32_t* lst, int lane ST_ARG) {
-    int x0 = 0, y0 = 0, nx = 0, ny = 0;
-    if (active && isfinite(u) && isfinite(v)) {
-        double a;
-        a = u - halfX;
-        double left = (a < 0.) ? 0. : a;
-        a = u + halfX;
-        double right = ((double)(c.W - 1) < a) ? (double)(c.W - 1) : a;
-        a = v - halfY;
-        double top = (a < 0.) ? 0. : a;
-        a = v + halfY;
-        double bottom = ((double)(c.H - 1) < a) ? (double)(c.H - 1) : a;
-        x0 = (int)left;
-        y0 = (int)top;
-        int x1 = (int)right, y1 = (int)bottom;
-        nx = x1 - x0 + 1;
-        ny = y1 - y0 + 1;
-        if (nx <= 0 || ny <= 0 || x0 < 0 || y0 < 0 || x1 >= c.W || y1 >= c.H) {
-            nx = 0;
-            ny = 0;
-        }
-    }
-    const int nxmax = uniform(wave_max_i32(nx));
-    if (nxmax <= 32) return scan_window_bitmap(c, s, x0, y0, nx, ny, lst, lane ST_PASS);
-    // windows wider than 32 cells (non-default parameters): every lane with a window reports an overflowing list,
-    // which sends its feature to the wave-cooperative kernel
-    return (nx > 0) ? c.k1max + 1 : 0;
-}
-
 // Max-spanning triangle for lists of at most M entries, fully unrolled: all M points are fetched in one batch and
 // kept in registers, pairs are visited in the reference's (i,j) order with strict '>' (first maximal pair wins),
 // then the third corner over k < n-1.  One memory round trip instead of one per pair.
@@ -1492,19 +1395,6 @@ __device__ __forceinline__ void enqueue_features(int32_t* queue, int32_t* count,
 // Road fallback of the thread path (DepthEstimator.cpp:578-597) for the lanes with `cand` set; mytype holds the main
 // path's result (resultOld) on entry.  Lanes whose wide-window list exceeds the capacities set `overflow`.
 // ROAD_MODE: 0 = M-estimator, 1 = max-spanning triangle, -1 = decided at run time (c.roadMode).
-template <int ROAD_MODE>
-__device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, bool cand,
-                                                const int k2, const double myu, const double myv, int& mytype,
-                                                double& mydepth, bool& overflow ST_ARG);
-
-template <int ROAD_MODE>
-__device__ __forceinline__ void road_thread(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, bool cand,
-                                            const double myu, const double myv, int& mytype, double& mydepth,
-                                            bool& overflow ST_ARG) {
-    const int k2 = scan_window_thread(c, s, myu, myv, c.halfX2, c.halfY2, cand, lst, lane ST_PASS);
-    road_after_scan<ROAD_MODE>(c, s, lst, lane, cand, k2, myu, myv, mytype, mydepth, overflow ST_PASS);
-}
-
 // The road fallback once the wide-window list (k2 entries, original point indices in the low 24 bits) is in `lst`.
 template <int ROAD_MODE>
 __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, bool cand,
@@ -1535,14 +1425,17 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
     double sw = 0, mx = 0, my = 0, mz = 0;
     double q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
     const V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
+    const bool keyInl = s.mask_in_key != 0;
     for (int e0 = 0; e0 < n2max; e0 += kRoadBatch) {
         RawP rp[kRoadBatch];
         uint32_t ids[kRoadBatch], mw[kRoadBatch];
 #pragma unroll
         for (int q = 0; q < kRoadBatch; q++) {
-            ids[q] = LST_ID(e0 + q, n2);
+            const uint32_t ent = (e0 + q < n2) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
+            ids[q] = ent & kIdxMask;
             rp[q] = load_raw(s, ids[q]);
-            mw[q] = GPTR(uint32_t, s.inlier_mask)[ids[q] >> 5];
+            // the inlier flag travels in the map key when the plane was known at projection time (bit 30 of the entry)
+            mw[q] = keyInl ? ((ent >> 30) << (ids[q] & 31u)) : GPTR(uint32_t, s.inlier_mask)[ids[q] >> 5];
         }
 #pragma unroll
         for (int q = 0; q < kRoadBatch; q++) {
@@ -1645,11 +1538,14 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
 // Everything between the window scan and the road fallback for one feature per lane (DepthEstimator.cpp:564-576):
 // histogram segmentation, corner selection, tail.  `lst` / `lane` address the lane's index list (they need not be
 // the executing wave's own region: k_feature_main re-deals the live features of a block to dense wavefronts).
-__device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane,
-                                                const int k, bool live, const double myu, const double myv,
-                                                int& mytype, double& mydepth, bool& overflow ST_ARG) {
-    int ks = live ? k : 0;
-    double minZ = 1.7976931348623157e308, maxZ = -1.7976931348623157e308;
+// First half: depth segmentation of the lane's neighbour list (DepthEstimator.cpp:726-780).  On return the list holds
+// the segmented points (ks entries, reference order) and minZ / maxZ their depth range; a failed histogram sets
+// mytype = HistogramNoLocalMax and clears `live`.
+__device__ __forceinline__ void main_hist(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, const int k,
+                                          bool& live, int& mytype, int& ks, double& minZ, double& maxZ ST_ARG) {
+    ks = live ? k : 0;
+    minZ = 1.7976931348623157e308;
+    maxZ = -1.7976931348623157e308;
     if (c.useHist) {
         // PointHistogram::FilterPointsMinDistBlob (HistogramPointDepth.cpp:15-123), per thread
         const int kmax = uniform(wave_max_i32(ks));
@@ -1830,7 +1726,14 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
 
     ST_USE_U32(ks);
     ST_MARK(9);
-    // ---- CalculateDepthSegmented (DepthEstimator.cpp:903-1037) ----
+}
+
+// Second half: CalculateDepthSegmented (DepthEstimator.cpp:903-1037) on the segmented list: corner selection (max
+// spanning triangle / first three points / PCA moments), planarity, ray-plane intersection, thresholds.
+__device__ __forceinline__ void main_tail(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, const int ks_in,
+                                          bool live, const double minZ, const double maxZ, const double myu,
+                                          const double myv, int& mytype, double& mydepth, bool& overflow ST_ARG) {
+    int ks = live ? ks_in : 0;
     double r[kRecFields];
 #pragma unroll
     for (int t = 0; t < kRecFields; t++) r[t] = 0.0;
@@ -1913,322 +1816,13 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
     ST_MARK(11);
 }
 
-// Single-kernel variant of the thread path (MLD_NO_SPLIT_ROAD=1): scan, main path and road fallback inline, 64 features
-// per block; also the front end of the wave-only mode (threadPath = 0: every feature is queued for k_feature_wave).
-__global__ __launch_bounds__(kWave) void k_feature_depth(const SlotDesc* __restrict__ slots, SlotDesc single,
-                                                         int use_single, Calib c, int n_slots, int per_slot,
-                                                         uint32_t tag_all) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    int slot, j;
-    decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
-    SlotDesc s = use_single ? single : slots[slot];
-    if (tag_all) s.tag = tag_all;
-    const long long f0 = (long long)j * kWave;
-    long long Fn = s.F;
-    if (s.F_dev) {
-        const long long fd = *GPTR(long long, s.F_dev);
-        Fn = fd < Fn ? fd : Fn;
-    }
-    if (f0 >= Fn) return;
-    const int lane = threadIdx.x;
-    const int nf = (int)((Fn - f0) < (long long)kWave ? (Fn - f0) : (long long)kWave);
-    const bool active = lane < nf;
-    uint32_t* lst = reinterpret_cast<uint32_t*>(smem);
-
-    double myu = 0, myv = 0;
-    if (active) {
-        const auto* q = GPTR(double, s.uv) + 2 * (f0 + lane);
-        myu = q[0];
-        myv = q[1];
-    }
-    int mytype = MLD_Unspecified;
-    double mydepth = -1.0;
-    bool overflow = false;
-    int ovf_code = -1;  // -1: the whole feature is redone by the wave kernel; >= 0: only its road part (= main result)
-
-    if (c.threadPath) {
-        // ---------------- main window (DepthEstimator.cpp:509-576) ----------------
-#ifdef MLD_STAMPS
-        Stamps st;
-        st.begin(3);
-#endif
-        int k = scan_window_thread(c, s, myu, myv, c.halfX1, c.halfY1, active, lst, lane ST_PASS);
-        overflow = k > c.k1max;
-        bool live = active && !overflow;  // still being computed by this path
-        if (live && (unsigned)k < c.countMin) {
-            mytype = MLD_RadiusSearchInsufficientPoints;
-            live = false;
-        }
-        main_after_scan(c, s, lst, lane, k, live, myu, myv, mytype, mydepth, overflow ST_PASS);
-
-        // ---------------- road fallback (DepthEstimator.cpp:578-597) ----------------
-        const bool road_on = c.useRoad && s.has_plane;
-        bool cand = road_on && active && !overflow && (mytype != MLD_Success) &&
-                    (mytype != MLD_RadiusSearchInsufficientPoints);
-        const unsigned long long cmask = __ballot(cand);
-        if (cmask) {
-            const int resultOld = mytype;
-            bool ovf2 = false;
-            road_thread<-1>(c, s, lst, lane, cand, myu, myv, mytype, mydepth, ovf2 ST_PASS);
-            if (ovf2) {  // long wide-window list: only the road part is redone by the wave kernel
-                overflow = true;
-                ovf_code = resultOld;
-            }
-        }
-    } else {
-        overflow = active;
-    }
-
-    // ---------------- long lists: queued for the wave-cooperative kernel (k_feature_wave) ----------------
-    enqueue_features(s.ovf_queue, s.ovf_count, overflow && active, lane, f0 + lane, ovf_code);
-
-    if (active) {
-        GPTRW(double, s.depth)[f0 + lane] = mydepth;
-        if (s.type) GPTRW(int32_t, s.type)[f0 + lane] = mytype;
-    }
-}
-
-// Processing order of the features: sorted by image row (counting sort, one block per frame slot).  The result of a
-// feature does not depend on the order, but its memory traffic does: features are independent random pixels, and
-// handing the lanes of a wavefront features of the same rows makes their window scans, key lookups and point gathers
-// fall into the same DRAM pages and cache lines (measured: -6 % on k_feature_main, -12 % on k_feature_road).
-// perm[i] = index of the i-th feature in row order; ties in arbitrary order.
-constexpr int kSortThreads = 256;
-constexpr int kSortBuckets = 1024;
-constexpr int kSortKeep = 8;  // buckets per thread kept in registers between the two passes (2048 features per slot)
-__global__ __launch_bounds__(kSortThreads) void k_sort_features(const SlotDesc* __restrict__ slots, SlotDesc single,
-                                                                int use_single, Calib c) {
-    __shared__ int hist[kSortBuckets];
-    __shared__ int wsum[kSortThreads / kWave];
-    SlotDesc s = use_single ? single : slots[blockIdx.x];
-    if (!s.perm) return;
-    long long Fn = s.F;
-    if (s.F_dev) {
-        const long long fd = *GPTR(long long, s.F_dev);
-        Fn = fd < Fn ? fd : Fn;
-    }
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-    for (int b = tid; b < kSortBuckets; b += kSortThreads) hist[b] = 0;
-    __syncthreads();
-    const auto* uv = GPTR(double, s.uv);
-    // bucket = image row scaled to the bucket count; non-finite / out-of-image rows go to the ends
-    const double scale = (double)kSortBuckets / (double)c.H;
-    auto bucket_of = [&](long long i) {
-        const double v = uv[2 * i + 1];
-        int b = 0;
-        if (v > 0.0) b = (v < (double)c.H) ? (int)(v * scale) : kSortBuckets - 1;
-        return b < kSortBuckets ? b : kSortBuckets - 1;
-    };
-    // the first kSortKeep buckets of a thread stay in registers for the scatter pass (a frame's worth of features)
-    int kept[kSortKeep];
-#pragma unroll
-    for (int q = 0; q < kSortKeep; q++) {
-        const long long i = tid + (long long)q * kSortThreads;
-        kept[q] = (i < Fn) ? bucket_of(i) : -1;
-    }
-#pragma unroll
-    for (int q = 0; q < kSortKeep; q++)
-        if (kept[q] >= 0) atomicAdd(&hist[kept[q]], 1);
-    for (long long i = tid + (long long)kSortKeep * kSortThreads; i < Fn; i += kSortThreads) atomicAdd(&hist[bucket_of(i)], 1);
-    __syncthreads();
-    // exclusive scan of the bucket counts: 4 buckets per thread, wave scan, block offsets
-    constexpr int kPer = kSortBuckets / kSortThreads;
-    int loc[kPer], sum = 0;
-#pragma unroll
-    for (int q = 0; q < kPer; q++) {
-        loc[q] = hist[tid * kPer + q];
-        sum += loc[q];
-    }
-    int incl = sum;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const int t = __shfl_up(incl, d);
-        if (lane >= d) incl += t;
-    }
-    if (lane == kWave - 1) wsum[wave] = incl;
-    __syncthreads();
-    int base = incl - sum;
-    for (int q = 0; q < wave; q++) base += wsum[q];
-#pragma unroll
-    for (int q = 0; q < kPer; q++) {
-        hist[tid * kPer + q] = base;
-        base += loc[q];
-    }
-    __syncthreads();
-    auto* perm = GPTRW(int32_t, s.perm);
-#pragma unroll
-    for (int q = 0; q < kSortKeep; q++)
-        if (kept[q] >= 0) perm[atomicAdd(&hist[kept[q]], 1)] = (int32_t)(tid + q * kSortThreads);
-    for (long long i = tid + (long long)kSortKeep * kSortThreads; i < Fn; i += kSortThreads)
-        perm[atomicAdd(&hist[bucket_of(i)], 1)] = (int32_t)i;
-}
-
-// Main kernel of the default configuration: 256 features per block.  After the window scan only the features that
-// still need work (enough neighbours for the histogram) are LIVE — about a third in a KITTI-like frame, where the
-// sky has no LiDAR returns — so the block re-deals them to dense wavefronts before the histogram / triangle / tail
-// code runs; wavefronts that receive nothing retire at once.  A dealt lane addresses the index list of the lane
-// that scanned the feature (same LDS, other wave's region).
-constexpr int kMainThreads = 256;
-__global__ __launch_bounds__(kMainThreads) void k_feature_main(const SlotDesc* __restrict__ slots, SlotDesc single,
-                                                               int use_single, Calib c, int n_slots, int per_slot,
-                                                               uint32_t tag_all) {
-    extern __shared__ __align__(16) unsigned char smem[];
-#ifdef MLD_STAMPS
-    Stamps st;
-    st.begin(0);
-#endif
-    int slot, j;
-    decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
-    SlotDesc s = use_single ? single : slots[slot];
-    if (tag_all) s.tag = tag_all;
-    const long long f0 = (long long)j * kMainThreads;
-    long long Fn = s.F;
-    if (s.F_dev) {
-        const long long fd = *GPTR(long long, s.F_dev);
-        Fn = fd < Fn ? fd : Fn;
-    }
-    if (f0 >= Fn) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & (kWave - 1);
-    constexpr int kWaves = kMainThreads / kWave;
-    uint32_t* lst_all = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* info = lst_all + kWaves * c.k1max * kWave;  // [kMainThreads] dealt slot -> (origin thread | k << 16)
-    int32_t* fidx = reinterpret_cast<int32_t*>(info + kMainThreads);  // [kMainThreads] feature index of the scanning thread
-    int* wsum = reinterpret_cast<int*>(fidx + kMainThreads);
-    uint32_t* lst = lst_all + wave * c.k1max * kWave;
-    const bool active = f0 + tid < Fn;
-    // the feature this thread scans: the (f0 + tid)-th in row order
-    const long long fme = (active && s.perm) ? (long long)GPTR(int32_t, s.perm)[f0 + tid] : f0 + tid;
-    double myu = 0, myv = 0;
-    if (active) {
-        const auto* q = GPTR(double, s.uv) + 2 * fme;
-        myu = q[0];
-        myv = q[1];
-    }
-    ST_USE_F64(myu);
-    ST_USE_F64(myv);
-    ST_MARK(1);
-    // ---------------- main window (DepthEstimator.cpp:509-510) ----------------
-    const int k = scan_window_thread(c, s, myu, myv, c.halfX1, c.halfY1, active, lst, lane ST_PASS);
-    const bool overflow = active && (k > c.k1max);
-    int mytype = MLD_Unspecified;
-    bool live = active && !overflow;
-    if (live && (unsigned)k < c.countMin) {
-        mytype = MLD_RadiusSearchInsufficientPoints;
-        live = false;
-    }
-    // fewer neighbours than the histogram's minimum bin count: no bin can become a maximum, FilterPointsMinDistBlob
-    // returns false on every path (HistogramPointDepth.cpp:53,84,95)
-    if (live && c.useHist && c.minCount >= 1 && k < c.minCount) {
-        mytype = MLD_HistogramNoLocalMax;
-        live = false;
-    }
-    const bool road_on = c.useRoad && s.has_plane;
-    // ---------------- deal the live features to dense wavefronts ----------------
-    const unsigned long long lm = __ballot(live);
-    if (lane == 0) wsum[wave] = (int)__popcll(lm);
-    __syncthreads();
-    int base = 0, nlive = 0;
-#pragma unroll
-    for (int q = 0; q < kWaves; q++) {
-        const int t = wsum[q];
-        base += (q < wave) ? t : 0;
-        nlive += t;
-    }
-    if (live) info[base + prefix_count(lm)] = (uint32_t)tid | ((uint32_t)k << 16);
-    fidx[tid] = (int32_t)fme;
-    __syncthreads();
-    ST_MARK(5);
-    // features finished (or handed on) by the scanning lane itself
-    if (active && !live) {
-        GPTRW(double, s.depth)[fme] = -1.0;
-        if (s.type) GPTRW(int32_t, s.type)[fme] = mytype;
-    }
-    enqueue_features(s.road_queue, s.road_count, road_on && active && !live && !overflow && mytype == MLD_HistogramNoLocalMax,
-                     lane, fme, mytype);
-    enqueue_features(s.ovf_queue, s.ovf_count, overflow, lane, fme, -1);
-    ST_MARK(6);
-#ifdef MLD_STAMPS
-    if (wave * kWave >= nlive) st.flush();
-#endif
-    if (wave * kWave >= nlive) return;  // nothing dealt to this wavefront (no barrier follows)
-    // ---------------- dealt features: histogram, triangle, tail ----------------
-    const bool has = tid < nlive;
-    const uint32_t inf = has ? info[tid] : 0u;
-    const int origin = (int)(inf & 0xFFFFu), kd = (int)(inf >> 16);
-    const long long f = has ? (long long)fidx[origin] : 0;
-    double u = 0, v = 0;
-    if (has) {
-        const auto* q = GPTR(double, s.uv) + 2 * f;
-        u = q[0];
-        v = q[1];
-    }
-    uint32_t* olst = lst_all + (origin >> 6) * c.k1max * kWave;
-    ST_USE_F64(u);
-    ST_USE_F64(v);
-    ST_MARK(7);
-    int type2 = MLD_Unspecified;
-    double depth2 = -1.0;
-    bool ovf2 = false;
-    main_after_scan(c, s, olst, origin & (kWave - 1), kd, has, u, v, type2, depth2, ovf2 ST_PASS);
-    if (has) {
-        GPTRW(double, s.depth)[f] = depth2;
-        if (s.type) GPTRW(int32_t, s.type)[f] = type2;
-    }
-    enqueue_features(s.road_queue, s.road_count,
-                     road_on && has && !ovf2 && (type2 != MLD_Success) && (type2 != MLD_RadiusSearchInsufficientPoints), lane,
-                     f, type2);
-    enqueue_features(s.ovf_queue, s.ovf_count, has && ovf2, lane, f, -1);
-    ST_MARK(12);
-#ifdef MLD_STAMPS
-    st.flush();
-#endif
-}
-
-// Road fallback for the features queued by k_feature_main: one lane per queued feature.
-template <int ROAD_MODE>
-__global__ __launch_bounds__(kWave) void k_feature_road(const SlotDesc* __restrict__ slots, SlotDesc single, int use_single,
-                                                        Calib c, int n_slots, int per_slot, uint32_t tag_all) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    int slot, j;
-    decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
-    SlotDesc s = use_single ? single : slots[slot];
-    if (tag_all) s.tag = tag_all;
-    if (!s.road_count) return;
-    const int count = *GPTR(int32_t, s.road_count);
-    const int e0 = j * kWave;
-    if (e0 >= count) return;
-#ifdef MLD_STAMPS
-    Stamps st;
-    st.begin(1);
-#endif
-    const int lane = threadIdx.x;
-    const bool active = e0 + lane < count;
-    uint32_t* lst = reinterpret_cast<uint32_t*>(smem);
-    long long f = 0;
-    int mytype = MLD_Unspecified;
-    double mydepth = -1.0, myu = 0, myv = 0;
-    if (active) {
-        f = (long long)GPTR(int32_t, s.road_queue)[2 * (size_t)(e0 + lane)];
-        mytype = GPTR(int32_t, s.road_queue)[2 * (size_t)(e0 + lane) + 1];
-        const auto* q = GPTR(double, s.uv) + 2 * f;
-        myu = q[0];
-        myv = q[1];
-    }
-    bool overflow = false;
-    const int resultOld = mytype;
-    ST_USE_F64(myu);
-    ST_USE_F64(myv);
-    ST_MARK(1);
-    road_thread<ROAD_MODE>(c, s, lst, lane, active, myu, myv, mytype, mydepth, overflow ST_PASS);
-    enqueue_features(s.ovf_queue, s.ovf_count, overflow && active, lane, f, resultOld);
-    if (active) {
-        GPTRW(double, s.depth)[f] = mydepth;
-        if (s.type) GPTRW(int32_t, s.type)[f] = mytype;
-    }
-    ST_MARK(12);
-#ifdef MLD_STAMPS
-    st.flush();
-#endif
+__device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane,
+                                                const int k, bool live, const double myu, const double myv,
+                                                int& mytype, double& mydepth, bool& overflow ST_ARG) {
+    int ks;
+    double minZ, maxZ;
+    main_hist(c, s, lst, lane, k, live, mytype, ks, minZ, maxZ ST_PASS);
+    main_tail(c, s, lst, lane, ks, live, minZ, maxZ, myu, myv, mytype, mydepth, overflow ST_PASS);
 }
 
 // Wave-cooperative kernel for the features the thread kernels could not hold (lists longer than their capacities).
@@ -2375,8 +1969,29 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
     const bool road_on = c.useRoad && s.has_plane && s.inlier_mask;
     const auto* uv = GPTR(double, s.uv);
     const double scale = (double)kClsBuckets / (double)c.H;
+    // occupied cells of a window, counted in the (staged) bitmap
+    auto count_window = [&](int x0, int y0, int nx, int ny) -> int {
+        const int cx = x0 >> 5, sh = x0 & 31;
+        const uint32_t colmask = (nx >= 32) ? ~0u : ((1u << nx) - 1u);
+        int k = 0;
+        for (int r = 0; r < ny; r++) {
+            const int y = y0 + r;
+            uint32_t lo, hi;
+            if (STAGED) {
+                lo = lbm[y * ncolp + cx];
+                hi = lbm[y * ncolp + cx + 1];
+            } else {
+                lo = bm[(size_t)cx * c.bmStride + y];
+                hi = bm[(size_t)(cx + 1) * c.bmStride + y];
+            }
+            k += __popc(__builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh) & colmask);
+        }
+        return k;
+    };
     // class of feature i: CLS_DEAD (fewer than radiusSearch_count_min neighbours, DepthEstimator.cpp:680), CLS_OVF
-    // (a window wider than 32 cells, or the wave-only mode: handled by k_feature_wave), or its row bucket (live)
+    // (a window wider than 32 cells, or the wave-only mode: handled by k_feature_wave), or its row bucket (live).
+    // (Sorting the live features by list length as well, so that the lanes of a wavefront iterate equally long, was
+    // measured: the fused kernel gained what the extra counting cost here.)
     auto classify = [&](double u, double v) -> int {
         if (!c.threadPath) return CLS_OVF;
         int x0, y0, nx, ny;
@@ -2387,21 +2002,7 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
                 int a0, a1, anx, any_;
                 if (window_bounds(c, u, v, c.halfX2, c.halfY2, a0, a1, anx, any_) && anx > 32) return CLS_OVF;
             }
-            const int cx = x0 >> 5, sh = x0 & 31;
-            const unsigned long long colmask = (1ull << nx) - 1ull;
-            for (int r = 0; r < ny; r++) {
-                const int y = y0 + r;
-                uint32_t lo, hi;
-                if (STAGED) {
-                    lo = lbm[y * ncolp + cx];
-                    hi = lbm[y * ncolp + cx + 1];
-                } else {
-                    lo = bm[(size_t)cx * c.bmStride + y];
-                    hi = bm[(size_t)(cx + 1) * c.bmStride + y];
-                }
-                const unsigned long long w = ((unsigned long long)hi << 32) | lo;
-                k1 += __popcll((w >> sh) & colmask);
-            }
+            k1 = count_window(x0, y0, nx, ny);
         }
         if ((unsigned)k1 < c.countMin) return CLS_DEAD;
         int b = 0;
@@ -2589,7 +2190,7 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDes
         for (int q = 0; q < kKeyBatchF; q++) key[q] = (e0 + q < kk) ? mp[cell[q] & 0x7FFFFFFFu] : 0u;
 #pragma unroll
         for (int q = 0; q < kKeyBatchF; q++)
-            if (e0 + q < kk) LST(e0 + q) = (kIdxMask - (key[q] & kIdxMask)) | (cell[q] & 0x80000000u);
+            if (e0 + q < kk) LST(e0 + q) = key_index(key[q]) | ((key[q] & 1u) << 30) | (cell[q] & 0x80000000u);
     }
     ST_MARK(4);
     kflag = kf;
@@ -2889,7 +2490,7 @@ __global__ void k_export_map(const uint32_t* __restrict__ map, uint32_t tag, con
     if (i >= cells) return;
     uint32_t key = map[i];
     int32_t r = -1;
-    if ((key >> kIdxBits) == tag) r = rank[kIdxMask - (key & kIdxMask)];
+    if ((key >> kIdxBits) == tag) r = rank[key_index(key)];
     out[i] = r;
 }
 

@@ -310,9 +310,8 @@ class DepthEstimator:
         """One pass of the hot path over the batch: setInputCloud + ground-plane hook + CalculateDepth for every
         slot (asynchronous on `stream`)."""
         lib, ctx, n = self._lib, self._ctx, b["n"]
-        self._check(lib.mld_set_clouds_device(ctx, n, b["cloud_ptrs"], b["cloud_n"], b["stride"]))
-        self._check(lib.mld_set_ground_planes_mask_device(ctx, n, b["coeffs"].ctypes.data_as(C.POINTER(C.c_float)),
-                                                          b["mask_ptrs"]))
+        self._check(lib.mld_set_clouds_planes_device(ctx, n, b["cloud_ptrs"], b["cloud_n"], b["stride"],
+                                                     b["coeffs"].ctypes.data_as(C.POINTER(C.c_float)), b["mask_ptrs"]))
         self._check(lib.mld_calculate_depths_device(ctx, n, b["uv_ptrs"], b["F"], b["depth_ptrs"], b["type_ptrs"]))
 
     def estimateGroundPlane(self, slot: int = 0, seed: int = 0):

@@ -9,18 +9,15 @@ from helpers import assert_depth_parity, kitti_camera, make_estimator, make_orac
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["split", "inline-road", "wave-only"])
+@pytest.fixture(autouse=True, params=["fused", "wave-only"])
 def feature_kernel_path(request, monkeypatch):
-    """Every test runs three ways (the switches are read by mld_create):
-    split       thread-per-feature kernel + road-fallback kernel + long-list wave kernel (the default)
-    inline-road thread kernel with the road fallback inline (MLD_NO_SPLIT_ROAD=1)
-    wave-only   every feature through the wave-cooperative kernel (MLD_FORCE_WAVE_PATH=1)"""
-    monkeypatch.delenv("MLD_FORCE_WAVE_PATH", raising=False)
-    monkeypatch.delenv("MLD_NO_SPLIT_ROAD", raising=False)
+    """Every test runs both ways:
+    fused       k_classify + k_feature_fused + the long-list k_feature_wave: the shipped library (libmld_hip.so)
+    wave-only   every feature through the wave-cooperative kernel: the test build of the same sources
+                (libmld_hip_ab.so, -DMLD_AB_SWITCHES) with MLD_FORCE_WAVE_PATH=1, read by its mld_create"""
     if request.param == "wave-only":
         monkeypatch.setenv("MLD_FORCE_WAVE_PATH", "1")
-    elif request.param == "inline-road":
-        monkeypatch.setenv("MLD_NO_SPLIT_ROAD", "1")
+        monkeypatch.setattr(capi, "_lib", capi.load_ab())
     yield request.param
 
 
@@ -228,6 +225,55 @@ def test_batched_slots_match_single_slot(B):
     for b in range(B):
         _, (d0, t0) = run_oracle(P, clouds[b], uvs[b], planes[b])
         assert_depth_parity(t_depth[b].cpu().numpy(), t_type[b].cpu().numpy(), d0, t0)
+
+
+def test_planes_known_at_projection_equal_planes_set_afterwards():
+    """setInputCloud(cloud, groundPlane) with the plane known at projection time (mld_set_clouds_planes_device: the
+    inlier flags travel in the pixel-map keys) against the plane installed after the cloud (mask lookups), and both
+    against the oracle; then a DIFFERENT plane set after the combined call must win over the flags in the keys."""
+    import torch
+    P = capi.params_c0()
+    B, F = 11, 900
+    est = make_estimator(P, max_frames=B, max_features=F)
+    clouds = [synth.make_cloud(synth.HDL64_KITTI, seed=70 + (b % 4), frame=b) for b in range(B)]
+    uvs = [synth.make_features(F, seed=80 + b) for b in range(B)]
+    planes = [synth.make_ground_plane(c) for c in clouds]
+    dev = torch.device("cuda:0")
+
+    def mask_of(inl, n):
+        m = np.zeros((n + 31) // 32, dtype=np.uint32)
+        np.bitwise_or.at(m, inl >> 5, (np.uint32(1) << (inl & 31).astype(np.uint32)))
+        return torch.from_numpy(m.view(np.int32)).to(dev)
+
+    t_clouds = [torch.from_numpy(c).to(dev) for c in clouds]
+    t_uvs = [torch.from_numpy(u).to(dev) for u in uvs]
+    t_masks = [mask_of(p[1], c.shape[0]) for p, c in zip(planes, clouds)]
+    coeffs = np.stack([p[0] for p in planes])
+    d_a = [torch.empty(F, dtype=torch.float64, device=dev) for _ in range(B)]
+    t_a = [torch.empty(F, dtype=torch.int32, device=dev) for _ in range(B)]
+    torch.cuda.synchronize()
+    batch = est.prepareBatch(t_clouds, t_uvs, d_a, t_a, coeffs, t_masks)
+    est.runBatch(batch)  # combined entry point
+    est.synchronize()
+    res_a = [(d.cpu().numpy().copy(), t.cpu().numpy().copy()) for d, t in zip(d_a, t_a)]
+    est.setInputClouds(t_clouds, 16)  # plane after the cloud
+    est.setGroundPlanesMask(coeffs, t_masks)
+    est.CalculateDepths(t_uvs, d_a, t_a)
+    est.synchronize()
+    for b in range(B):
+        _, (d0, t0) = run_oracle(P, clouds[b], uvs[b], planes[b])
+        assert_depth_parity(res_a[b][0], res_a[b][1], d0, t0)
+        assert np.array_equal(res_a[b][1], t_a[b].cpu().numpy())
+        assert np.array_equal(res_a[b][0], d_a[b].cpu().numpy(), equal_nan=True)
+    # a plane with half the inliers, installed after the combined call: the keys' flags are stale and must be ignored
+    half = [(p[0], p[1][::2].copy()) for p in planes]
+    est.runBatch(batch)
+    est.setGroundPlanesMask(coeffs, [mask_of(h[1], c.shape[0]) for h, c in zip(half, clouds)])
+    est.CalculateDepths(t_uvs, d_a, t_a)
+    est.synchronize()
+    for b in range(0, B, 5):
+        _, (d0, t0) = run_oracle(P, clouds[b], uvs[b], half[b])
+        assert_depth_parity(d_a[b].cpu().numpy(), t_a[b].cpu().numpy(), d0, t0)
 
 
 def test_config5_dense_cloud_integer_features():

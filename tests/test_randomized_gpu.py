@@ -96,12 +96,13 @@ def test_cloud_with_non_finite_and_duplicate_points():
 
 
 def test_cloud_size_limit():
-    """24-bit point index in the pixel-map key: 16 777 215 points are accepted, one more is a capacity error."""
+    """23-bit point index in the pixel-map key (beside the tag and the inlier flag): 8 388 607 points are accepted,
+    one more is a capacity error."""
     import torch
     from mono_lidar_depth_amd import DepthEstimatorError
     P = capi.params_c0().replace(do_use_ransac_plane=0)
     est = make_estimator(P)
-    n_max = (1 << 24) - 1
+    n_max = (1 << 23) - 1
     big = torch.zeros((n_max + 1, 4), dtype=torch.float32, device="cuda:0")
     # a handful of real points at the very end of the largest legal cloud: the highest indices must round-trip
     tail = torch.from_numpy(synth.make_cloud(synth.VLP16, seed=5)[:20000]).to("cuda:0")
