@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the DepthEstimator hot path on MI355X (contract: see the task's bench.py section).
 
-One "step" = one pass of the hot path (setInputCloud + ground-plane hook + CalculateDepth) over one batch of
-`--frames-per-step` synthetic frames of BASELINE.json config 2 (64x2048 cloud, 2000 features/frame, C0
-parameters), all inputs resident in HBM before the timed region.  Metric: feature-depth associations per second =
-features x frames / wall time (every submitted feature counts).  Multi-GPU: one process per GPU (torchrun), each
-rank owns its own sequences (weak scaling); the only collective is the RCCL broadcast of the calibration block.
+One "step" = one pass of the hot path (setInputCloud with its ground plane + CalculateDepth) over one batch of
+`--frames-per-step` synthetic frames of BASELINE.json config 2 (64x2048 cloud, 2000 features/frame, C0 parameters), all
+inputs resident in HBM before the timed region.  Metric: feature-depth associations per second = features x frames /
+wall time (every submitted feature counts).
+
+Multi-GPU: one process per GPU, each rank owns its own sequence (weak scaling); the only collective is the RCCL
+broadcast of the calibration block.  `python bench.py --gpus N` starts the N ranks itself (torch.distributed.run as a
+child process, before this process touches the GPU) unless it already runs under a launcher (WORLD_SIZE set).
 
 The JSON line also carries
-  roofline      algorithmic bytes of the dominant kernel / its hipEvent-measured duration, vs 8 TB/s HBM
+  verified      sampled slots of the timed batch compared with the CPU oracle after the timed region (exit 1 if not)
+  roofline      the dominant kernel priced on the bytes THIS design moves, / its hipEvent-measured duration, vs 8 TB/s
+                (`formula_GBps` keeps SURVEY.md §8(d)'s formula, which also charges a map clear and a camera-frame
+                copy that are never performed)
   cpu_baseline  the restated reference CPU path (oracle/, kind "port") timed on this host, rank 0, N=1 only
+  latency / streaming / configs["3"], configs["5"]   PCIe-inclusive legs and the other single-GPU BASELINE configs
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -26,6 +34,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+K_PROJECT, K_FUSED, K_WAVE, K_CLASSIFY = 0, 1, 3, 5  # mld_kernel_time_ms ids (include/mld.h)
 
 
 def parse_args():
@@ -37,8 +46,7 @@ def parse_args():
     ap.add_argument("--slots", type=int, default=0,
                     help="frame slots of the context (0 = frames-per-step); a step runs frames-per-step/slots launch sets")
     ap.add_argument("--contexts", type=int, default=1,
-                    help="independent contexts (HIP streams) the frames of a step are split over; >1 lets the "
-                         "HBM-bound projection of one half overlap the VALU-bound feature kernel of the other")
+                    help="independent contexts (HIP streams) the frames of a step are split over")
     ap.add_argument("--unique-frames", type=int, default=16, help="distinct synthetic clouds generated per rank")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -47,13 +55,31 @@ def parse_args():
     ap.add_argument("--streaming-batches", type=int, default=24,
                     help="batches of the pipelined host->device leg (PCIe-inclusive throughput; 0 = skip)")
     ap.add_argument("--streaming-frames", type=int, default=64, help="frames per batch of the streaming leg")
-    ap.add_argument("--stat-slots", type=int, default=4, help="slots sampled for the algorithmic-byte statistics")
+    ap.add_argument("--config-frames", type=int, default=256,
+                    help="resident frames of the config-3 leg / sequence length of the config-5 leg (0 = skip both)")
+    ap.add_argument("--verify-slots", type=int, default=4, help="slots of the timed batch checked against the oracle")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-every", type=int, default=4,
                     help="record hipEvents around the kernels of every n-th timed step (event records cost ~6 us each)")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(n: int) -> int:
+    """`--gpus N` without a launcher: start N ranks (one per GPU) as a child torch.distributed.run and relay their
+    output.  Nothing in this process has initialised the GPU (torch is imported in the workers only)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------ legs
 def cpu_baseline(P, cam_struct, T, clouds, planes, uvs, seconds):
     """The restated reference CPU path on this host's cores (OpenMP over features, DepthEstimator.cpp:455)."""
     from oracle import oracle
@@ -133,6 +159,12 @@ def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
     }
 
 
+def mask_words(inl, n):
+    m = np.zeros((n + 31) // 32, dtype=np.uint32)
+    np.bitwise_or.at(m, inl >> 5, (np.uint32(1) << (inl & 31).astype(np.uint32)))
+    return m.view(np.int32)
+
+
 def streaming_leg(P, cam, T, clouds, planes, uvs, device, frames_per_batch, n_batches):
     """Frames streamed from pinned host memory: double-buffered H2D copies on a copy stream overlapped with the kernels
     on the context's stream, results copied back.  PCIe-inclusive THROUGHPUT (the latency leg is the unpipelined
@@ -143,12 +175,6 @@ def streaming_leg(P, cam, T, clouds, planes, uvs, device, frames_per_batch, n_ba
     S, N, F = frames_per_batch, clouds[0].shape[0], uvs[0].shape[0]
     U = len(clouds)
     words = (N + 31) // 32
-
-    def mask_of(inl):
-        m = np.zeros(words, dtype=np.uint32)
-        np.bitwise_or.at(m, inl >> 5, (np.uint32(1) << (inl & 31).astype(np.uint32)))
-        return m.view(np.int32)
-
     # pinned host batch (what a driver thread would fill from the sensor queue) and two device buffer sets
     h_cloud = torch.empty((S, N, 4), dtype=torch.float32).pin_memory()
     h_mask = torch.empty((S, words), dtype=torch.int32).pin_memory()
@@ -156,7 +182,7 @@ def streaming_leg(P, cam, T, clouds, planes, uvs, device, frames_per_batch, n_ba
     coeffs = np.empty((S, 4), dtype=np.float32)
     for b in range(S):
         h_cloud[b] = torch.from_numpy(clouds[b % U])
-        h_mask[b] = torch.from_numpy(mask_of(planes[b % U][1]))
+        h_mask[b] = torch.from_numpy(mask_words(planes[b % U][1], N))
         h_uv[b] = torch.from_numpy(uvs[b % len(uvs)])
         coeffs[b] = planes[b % U][0]
     h_depth = [torch.empty((S, F), dtype=torch.float64).pin_memory() for _ in range(2)]
@@ -224,21 +250,281 @@ def streaming_leg(P, cam, T, clouds, planes, uvs, device, frames_per_batch, n_ba
     }
 
 
+class Resident:
+    """B device-resident frames (U distinct clouds, B distinct feature sets) and a context with S frame slots."""
+
+    def __init__(self, P, cam, T, scanner, B, U, F, seq, device, integer_uv=False, slots=0, contexts=1):
+        import torch
+        from mono_lidar_depth_amd import DepthEstimator, synth
+        dev = torch.device("cuda", device)
+        self.P, self.cam, self.T, self.B, self.F = P, cam, T, B, F
+        self.clouds_h = [synth.make_cloud(scanner, seed=seq, frame=f) for f in range(U)]
+        self.planes_h = [synth.make_ground_plane(c) for c in self.clouds_h]
+        self.uvs_h = [synth.make_features(F, seed=seq * 100000 + b, integer=integer_uv) for b in range(B)]
+        self.N = N = self.clouds_h[0].shape[0]
+        self.U = U
+        words = (N + 31) // 32
+        # distinct HBM per slot, carved out of one allocation per kind (large, contiguous mappings)
+        self.all_clouds = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+        self.all_masks = torch.empty((B, words), dtype=torch.int32, device=dev)
+        self.all_uvs = torch.empty((B, F, 2), dtype=torch.float64, device=dev)
+        self.all_depth = torch.empty((B, F), dtype=torch.float64, device=dev)
+        self.all_type = torch.empty((B, F), dtype=torch.int32, device=dev)
+        d_unique = [torch.from_numpy(c).to(dev) for c in self.clouds_h]
+        m_unique = [torch.from_numpy(mask_words(p[1], N)).to(dev) for p in self.planes_h]
+        for b in range(B):
+            self.all_clouds[b].copy_(d_unique[b % U])
+            self.all_masks[b].copy_(m_unique[b % U])
+            self.all_uvs[b].copy_(torch.from_numpy(self.uvs_h[b]))
+        del d_unique, m_unique
+        self.coeffs = np.stack([self.planes_h[b % U][0] for b in range(B)])
+        torch.cuda.synchronize()
+        NC = max(1, contexts)
+        self.S = S = slots if slots > 0 else B // NC
+        assert B % (S * NC) == 0, "--frames-per-step must be a multiple of --slots x --contexts"
+        self.ests = []
+        for _ in range(NC):
+            e = DepthEstimator(device=device, max_frames=S, max_features=F)  # queues allocated up front
+            e.InitConfig(P)
+            e.Initialize(cam, T)
+            self.ests.append(e)
+        # a step walks the B resident frames in launch sets of S frame slots, dealt round-robin to the contexts (one HIP
+        # stream each); the slots' pixel maps are reused from one launch set to the next
+        rows = lambda t, i: [t[b] for b in range(i, i + S)]  # noqa: E731
+        self.batches = [(self.ests[(i // S) % NC], self.ests[(i // S) % NC].prepareBatch(
+            rows(self.all_clouds, i), rows(self.all_uvs, i), rows(self.all_depth, i), rows(self.all_type, i),
+            self.coeffs[i:i + S], rows(self.all_masks, i), stride_bytes=16)) for i in range(0, B, S)]
+
+    def run_step(self):
+        for e, b in self.batches:
+            e.runBatch(b)
+
+    def sync(self):
+        for e in self.ests:
+            e.synchronize()
+
+    def close(self):
+        for e in self.ests:
+            e.close()
+
+    def verify(self, n_slots):
+        """Frames of the timed batch against the CPU oracle (checker only, outside every timed region): result types
+        identical, depths bit-exact on the main path and within 1e-4 m on the road path.  Returns (ok, report)."""
+        from oracle import oracle
+        ref = oracle.OracleDepthEstimator(self.P, self.cam.as_struct(), self.T)
+        picks = sorted({int(x) for x in np.linspace(0, self.B - 1, max(1, n_slots))})
+        worst, bad = 0.0, []
+        for fr in picks:
+            ref.set_cloud(self.clouds_h[fr % self.U])
+            ref.set_ground_plane(*self.planes_h[fr % self.U])
+            d0, t0 = ref.calculate_depth(self.uvs_h[fr], 8)
+            d, t = self.all_depth[fr].cpu().numpy(), self.all_type[fr].cpu().numpy()
+            same_t = np.array_equal(t, t0)
+            diff = np.abs(np.nan_to_num(d, nan=-7.0) - np.nan_to_num(d0, nan=-7.0))
+            main = t0 != 16
+            ok = same_t and diff.max(initial=0.0) <= 1e-4 and np.array_equal(d[main], d0[main], equal_nan=True)
+            worst = max(worst, float(diff.max(initial=0.0)))
+            if not ok:
+                bad.append(fr)
+        return (not bad), {"frames_checked": picks, "max_abs_depth_diff_m": worst, "mismatching_frames": bad}
+
+
+def design_bytes_project(cloud, cam, T, inl):
+    """Bytes k_project_scatter has to move for one frame in THIS design: the cloud once (16 B/point), one 4-byte map
+    entry per point that lands in the image in front of the camera, the occupancy words those points set, and the
+    inlier-mask words read for them.  (No map clear, no camera-frame copy: DESIGN.md §2.)"""
+    xyz = cloud[:, :3].astype(np.float64)
+    p = xyz @ T[:, :3].T + T[:, 3]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        u = (cam.focal_length * p[:, 0] + cam.principal_point_x * p[:, 2]) / p[:, 2]
+        v = (cam.focal_length * p[:, 1] + cam.principal_point_y * p[:, 2]) / p[:, 2]
+        vis = (p[:, 2] > 0) & (u > 0) & (u < cam.width) & (v > 0) & (v < cam.height)
+    idx = np.nonzero(vis)[0]
+    words = np.unique((u[idx].astype(np.int64) >> 5) * 100000 + v[idx].astype(np.int64)).size
+    mwords = np.unique(idx >> 5).size
+    return {"bytes": 16 * cloud.shape[0] + 4 * idx.size + 4 * words + 4 * mwords, "n_front_in_image": int(idx.size),
+            "bitmap_words": int(words)}
+
+
 def pmc_traffic(kernel, frames_per_launch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
-    profiles/summarize.py: FETCH_SIZE/WRITE_SIZE in separate --pmc runs, gfx950 correction applied); None when no
-    profile of the same launch size is on record.  bench.py itself never runs under the profiler."""
+    """HBM bytes per launch of `kernel` and the launch time they were measured with, from the committed rocprofv3 PMC
+    passes (profiles/traffic.json, written by profiles/summarize.py: FETCH_SIZE/WRITE_SIZE in separate --pmc runs,
+    gfx950 correction applied); None when no profile of the same launch size is on record."""
     try:
         t = json.loads((ROOT / "profiles" / "traffic.json").read_text())
         if int(t.get("frames_per_launch", -1)) != int(frames_per_launch):
             return None
-        return float(t[kernel]["hbm_bytes_per_launch"])
+        return float(t[kernel]["hbm_bytes_per_launch"]), float(t[kernel]["launch_s"]), t.get("source", "")
     except Exception:  # noqa: BLE001
         return None
 
 
+def kernel_times(est):
+    out = {}
+    for name, k in (("k_project_scatter", K_PROJECT), ("k_classify", K_CLASSIFY), ("k_feature_fused", K_FUSED),
+                    ("k_feature_wave", K_WAVE)):
+        ms, n = est.kernelTimeMs(k)
+        out[name] = {"avg_ms": ms, "launches": n}
+    return out
+
+
+def timed_resident(res, steps, warmup, timing, timing_every, barrier=lambda: None):
+    import torch
+    est = res.ests[0]
+    for _ in range(warmup):
+        res.run_step()
+    res.sync()
+    if timing:
+        est.timingEnable(True)
+        est.timingReset()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(steps):
+        if timing:
+            est.timingEnable(it % max(1, timing_every) == 0)  # sampled steps of the timed region
+        res.run_step()
+    res.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    kt = kernel_times(est) if timing else {}
+    est.timingEnable(False)
+    return elapsed, kt
+
+
+def config3_leg(cam, T, device, B, steps=8):
+    """BASELINE config 3: VLP-16 sparse cloud (16x1800), 5000 features/frame, device-resident, C0 parameters plus the
+    threshold-treatment sweep of SURVEY.md §8(d) (Dispose/Adjust x absolute/relative)."""
+    from mono_lidar_depth_amd import capi, synth
+    P0 = capi.params_c0()
+    out = {"workload": f"BASELINE config 3: VLP-16 16x1800 cloud x 5000 features/frame, {B} device-resident frames per "
+                       "step, plane known at projection", "modes": {}}
+    for name, kw in (("c0_dispose", {}),
+                     ("adjust_relative", dict(treshold_depth_mode=1, treshold_depth_local_mode=1,
+                                              treshold_depth_local_valuetype=1)),
+                     ("adjust_absolute", dict(treshold_depth_mode=1, treshold_depth_local_mode=1,
+                                              treshold_depth_local_valuetype=0))):
+        res = Resident(P0.replace(**kw), cam, T, synth.VLP16, B, 8, 5000, 3, device)
+        el, kt = timed_resident(res, steps, 2, True, 2)
+        ok, rep = res.verify(2)
+        hist = np.zeros(capi.MLD_RESULT_TYPE_COUNT, dtype=np.int64)
+        for b in range(0, B, max(1, B // 16)):
+            hist += res.ests[0].resultHistogram(res.all_type[b])
+        out["modes"][name] = {
+            "associations_per_s": B * 5000 * steps / el, "ms_per_frame": 1e3 * el / steps / B, "verified": ok,
+            "max_abs_depth_diff_m": rep["max_abs_depth_diff_m"],
+            "kernels_ms_per_launch": {k: v["avg_ms"] for k, v in kt.items()},
+            "success_fraction": float((hist[1] + hist[16]) / max(1, hist.sum())),
+        }
+        if name == "c0_dispose":
+            db = [design_bytes_project(res.clouds_h[u], cam, T, res.planes_h[u][1]) for u in range(2)]
+            pb = float(np.mean([d["bytes"] for d in db])) * B
+            pms = kt["k_project_scatter"]["avg_ms"]
+            out["roofline_project"] = {"design_bytes_per_launch": pb, "kernel_ms": pms,
+                                       "frac": pb / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS if pms > 0 else None}
+        res.close()
+    out["verified"] = all(m["verified"] for m in out["modes"].values())
+    return out
+
+
+def config5_leg(cam, T, device, n_frames):
+    """BASELINE config 5: 128x4096 dense cloud (524 288 points), 10 000 tracks/frame through the tracklet API with
+    device pointers (mld_tracklets_depth_device); the previous frame's slot stays resident (no re-projection), 10 % of
+    the tracks are new every frame.  One frame per call sequence, as a tracker delivers them."""
+    import ctypes as C
+    import torch
+    from mono_lidar_depth_amd import DepthEstimator, GroundPlane, capi, synth
+    from oracle import oracle
+    dev = torch.device("cuda", device)
+    P = capi.params_c0()
+    U, n_tracks = 4, 10000
+    clouds_h = [synth.make_cloud(synth.DENSE128, seed=5, frame=f) for f in range(U)]
+    planes_h = [synth.make_ground_plane(c) for c in clouds_h]
+    N = clouds_h[0].shape[0]
+    d_clouds = [torch.from_numpy(c).to(dev) for c in clouds_h]
+    d_masks = [torch.from_numpy(mask_words(p[1], N)).to(dev) for p in planes_h]
+    rng = np.random.default_rng(5)
+    K = 8  # distinct track sets
+    sets = []
+    for k in range(K):
+        u0 = rng.integers(0, cam.width, n_tracks).astype(np.float32)
+        v0 = rng.integers(100, cam.height, n_tracks).astype(np.float32)
+        u1 = (u0 + rng.integers(-3, 4, n_tracks)).astype(np.float32)
+        v1 = (v0 + rng.integers(-2, 3, n_tracks)).astype(np.float32)
+        new = np.zeros(n_tracks, dtype=np.uint8)
+        new[rng.choice(n_tracks, n_tracks // 10, replace=False)] = 1
+        sets.append(tuple(torch.from_numpy(a).to(dev) for a in (u0, v0, u1, v1, new)) + ((u0, v0, u1, v1, new),))
+    d_cur = torch.empty(n_tracks, dtype=torch.float32, device=dev)
+    d_last = torch.zeros(n_tracks, dtype=torch.float32, device=dev)
+    t_cur = torch.empty(n_tracks, dtype=torch.int32, device=dev)
+    t_last = torch.zeros(n_tracks, dtype=torch.int32, device=dev)
+    est = DepthEstimator(device=device, max_frames=2, max_features=n_tracks)
+    est.InitConfig(P)
+    est.Initialize(cam, T)
+    lib, ctx = est._lib, est._ctx
+    ptrs = (C.c_void_p * 1)()
+    cnt = (C.c_int64 * 1)(N)
+    mptr = (C.c_void_p * 1)()
+
+    def frame(it, slot_cur, have_last):
+        i = it % U
+        s = sets[it % K]
+        est._check(lib.mld_set_cloud_device(ctx, slot_cur, d_clouds[i].data_ptr(), N, 16))
+        co = (C.c_float * 4)(*[float(x) for x in planes_h[i][0]])
+        est._check(lib.mld_set_ground_plane_mask_device(ctx, slot_cur, co, d_masks[i].data_ptr()))
+        est._check(lib.mld_tracklets_depth_device(ctx, slot_cur, (1 - slot_cur) if have_last else -1,
+                                                  s[0].data_ptr(), s[1].data_ptr(), s[2].data_ptr(), s[3].data_ptr(),
+                                                  s[4].data_ptr(), n_tracks, d_cur.data_ptr(), d_last.data_ptr(),
+                                                  t_cur.data_ptr(), t_last.data_ptr(), None))
+
+    slot = 0
+    for it in range(6):
+        frame(it, slot, it > 0)
+        slot = 1 - slot
+    est.synchronize()
+    est.timingEnable(True)
+    est.timingReset()
+    t0 = time.perf_counter()
+    for it in range(6, 6 + n_frames):
+        frame(it, slot, True)
+        slot = 1 - slot
+    est.synchronize()
+    el = time.perf_counter() - t0
+    kt = kernel_times(est)
+    est.timingEnable(False)
+    # check the last frame's current-slot depths against the oracle (integer-pixel features, float32 depths)
+    it = 6 + n_frames - 1
+    i, s = it % U, sets[it % K][5]
+    ref = oracle.OracleDepthEstimator(P, cam.as_struct(), T)
+    ref.set_cloud(clouds_h[i])
+    ref.set_ground_plane(*planes_h[i])
+    uv = np.stack([np.trunc(s[0]).astype(np.float64), np.trunc(s[1]).astype(np.float64)], axis=1)
+    d0, t0_ = ref.calculate_depth(uv, 8)
+    ok = bool(np.array_equal(t_cur.cpu().numpy(), t0_) and
+              np.allclose(d_cur.cpu().numpy(), d0.astype(np.float32), rtol=0, atol=1e-4, equal_nan=True))
+    est.close()
+    assoc = n_tracks + n_tracks // 10
+    db = design_bytes_project(clouds_h[0], cam, T, planes_h[0][1])
+    pms = kt["k_project_scatter"]["avg_ms"]
+    return {
+        "workload": f"BASELINE config 5: 128x4096 cloud ({N} points), {n_tracks} tracks/frame (10 % new) through "
+                    "mld_tracklets_depth_device, one frame per call sequence, previous frame's slot resident",
+        "frames": n_frames, "ms_per_frame": 1e3 * el / n_frames, "associations_per_s": assoc * n_frames / el,
+        "kernels_ms_per_launch": {k: v["avg_ms"] for k, v in kt.items()},
+        "launches_per_frame": {k: v["launches"] / n_frames for k, v in kt.items()},
+        "roofline_project": {"design_bytes_per_launch": db["bytes"], "kernel_ms": pms,
+                             "frac": db["bytes"] / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS if pms > 0 else None},
+        "verified": ok,
+    }
+
+
+# ------------------------------------------------------------------------------------------------ worker
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
 
@@ -247,7 +533,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # one process per GPU; RCCL ("nccl" on ROCm) carries the calibration broadcast and the two scalar reductions.
+    # one process per GPU; RCCL ("nccl" on ROCm) carries the calibration broadcast and the scalar reductions.
     # MLD_BENCH_BACKEND=gloo is a functional-test hook: it lets several ranks share one GPU box (collectives on CPU
     # tensors) so that the N>1 code path can be exercised where only one GPU is visible.
     backend = os.environ.get("MLD_BENCH_BACKEND", "nccl")
@@ -260,9 +546,8 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    local_rank = gpu_index
 
-    from mono_lidar_depth_amd import CameraPinhole, DepthEstimator, capi, sharding, synth, traffic
+    from mono_lidar_depth_amd import CameraPinhole, capi, sharding, synth, traffic
 
     # ---- calibration: rank 0 owns it, everyone receives it over RCCL -------------------------------------
     if rank == 0:
@@ -275,169 +560,112 @@ def main():
     cam = CameraPinhole(cam_struct.width, cam_struct.height, cam_struct.focal_length, cam_struct.principal_point_x,
                         cam_struct.principal_point_y)
 
-    # ---- synthetic inputs: this rank's sequence(s), resident in HBM --------------------------------------
-    B, U, F = args.frames_per_step, max(1, min(args.unique_frames, args.frames_per_step)), args.features
-    scanner = synth.HDL64
+    # ---- this rank's sequence, resident in HBM ------------------------------------------------------------
+    B, F = args.frames_per_step, args.features
+    U = max(1, min(args.unique_frames, B))
     seq = sharding.assign_sequences(world, world)[rank][0]  # one sequence per rank (config 4 layout)
-    clouds_h = [synth.make_cloud(scanner, seed=seq, frame=f) for f in range(U)]
-    planes_h = [synth.make_ground_plane(c) for c in clouds_h]
-    uvs_h = [synth.make_features(F, seed=seq * 100000 + b) for b in range(B)]
-    N = clouds_h[0].shape[0]
-
-    def mask_of(inl):
-        m = np.zeros((N + 31) // 32, dtype=np.uint32)
-        np.bitwise_or.at(m, inl >> 5, (np.uint32(1) << (inl & 31).astype(np.uint32)))
-        return m.view(np.int32)
-
-    masks_h = [mask_of(p[1]) for p in planes_h]
-    # distinct HBM per slot, carved out of one allocation per kind (large, contiguous mappings instead of B small ones)
-    words = masks_h[0].shape[0]
-    all_clouds = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
-    all_masks = torch.empty((B, words), dtype=torch.int32, device=dev)
-    all_uvs = torch.empty((B, F, 2), dtype=torch.float64, device=dev)
-    all_depth = torch.empty((B, F), dtype=torch.float64, device=dev)
-    all_type = torch.empty((B, F), dtype=torch.int32, device=dev)
-    d_unique = [torch.from_numpy(clouds_h[u]).to(dev) for u in range(U)]
-    m_unique = [torch.from_numpy(masks_h[u]).to(dev) for u in range(U)]
-    for b in range(B):
-        all_clouds[b].copy_(d_unique[b % U])
-        all_masks[b].copy_(m_unique[b % U])
-        all_uvs[b].copy_(torch.from_numpy(uvs_h[b]))
-    del d_unique, m_unique
-    t_clouds = [all_clouds[b] for b in range(B)]
-    t_masks = [all_masks[b] for b in range(B)]
-    t_uvs = [all_uvs[b] for b in range(B)]
-    t_depth = [all_depth[b] for b in range(B)]
-    t_type = [all_type[b] for b in range(B)]
-    coeffs = np.stack([planes_h[b % U][0] for b in range(B)])
-    torch.cuda.synchronize()
-
-    NC = max(1, args.contexts)
-    S = args.slots if args.slots > 0 else B // NC
-    assert B % (S * NC) == 0, "--frames-per-step must be a multiple of --slots x --contexts"
-    ests = []
-    for _ in range(NC):
-        e = DepthEstimator(device=local_rank, max_frames=S, max_features=F)  # queues allocated up front
-        e.InitConfig(P)
-        e.Initialize(cam, T)
-        ests.append(e)
-    est = ests[0]
-    # a step walks the B resident frames in launch sets of S frame slots, dealt round-robin to the contexts (one
-    # HIP stream each); the slots' pixel maps are reused from one launch set to the next
-    batches = [(ests[(i // S) % NC], ests[(i // S) % NC].prepareBatch(
-        t_clouds[i:i + S], t_uvs[i:i + S], t_depth[i:i + S], t_type[i:i + S], coeffs[i:i + S], t_masks[i:i + S],
-        stride_bytes=16)) for i in range(0, B, S)]
-
-    def run_step():
-        for e, b in batches:
-            e.runBatch(b)
-
-    def sync_all():
-        for e in ests:
-            e.synchronize()
+    res = Resident(P, cam, T, synth.HDL64, B, U, F, seq, gpu_index, slots=args.slots, contexts=args.contexts)
+    S, N = res.S, res.N
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    # ---- warm-up, then exactly K timed steps ---------------------------------------------------------------
-    for _ in range(args.warmup):
-        run_step()
-    sync_all()
     timing = not args.no_kernel_timing
-    if timing:
-        est.timingEnable(True)
-        est.timingReset()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        if timing:
-            est.timingEnable(it % max(1, args.timing_every) == 0)  # sampled steps of the timed region
-        run_step()
-    sync_all()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
+    elapsed, kt = timed_resident(res, args.steps, args.warmup, timing, args.timing_every, barrier)
     elapsed = sharding.max_over_ranks(elapsed, device=coll_dev)
     units = sharding.sum_over_ranks(float(B * F * args.steps), device=coll_dev)
 
-    k_proj_ms, n_proj = est.kernelTimeMs(0) if timing else (0.0, 0)
-    k_feat_ms, n_feat = est.kernelTimeMs(1) if timing else (0.0, 0)
-    k_road_ms, n_road = est.kernelTimeMs(2) if timing else (0.0, 0)
-    k_wave_ms, n_wave = est.kernelTimeMs(3) if timing else (0.0, 0)
-    k_sort_ms, n_sort = est.kernelTimeMs(5) if timing else (0.0, 0)
-    est.timingEnable(False)
-
+    # ---- the timed batch against the oracle (every rank checks its own sequence) ---------------------------
+    verified, vrep = res.verify(args.verify_slots) if args.verify_slots > 0 else (None, {})
+    n_bad = sharding.sum_over_ranks(0.0 if verified in (True, None) else 1.0, device=coll_dev)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
-        return
+        sys.exit(0 if verified in (True, None) else 1)
+    if args.verify_slots > 0:
+        verified = n_bad == 0
 
-    # ---- statistics for the algorithmic byte count (sampled slots, outside the timed region) -------------
-    stat_slots = list(range(0, S, max(1, S // max(1, args.stat_slots))))[:max(1, args.stat_slots)]
-    stats = []
+    est = res.ests[0]
+    # ---- byte counts (sampled slots, outside the timed region) --------------------------------------------
     type_hist = np.zeros(capi.MLD_RESULT_TYPE_COUNT, dtype=np.int64)
     for b in range(B):
-        type_hist += est.resultHistogram(t_type[b])
+        type_hist += est.resultHistogram(res.all_type[b])
+    stat_slots = list(range(0, S, max(1, S // 4)))[:4]
+    stats, design = [], []
     for b in stat_slots:
         fr = B - S + b  # the slots hold the last sub-batch of the step
-        fb = traffic.frame_bytes(P, cam.width, cam.height, N, est.getVisibleCount(b), est.getPixelMap(b),
-                                 uvs_h[fr], t_type[fr].cpu().numpy())
-        stats.append(fb)
-    proj_bytes = float(np.mean([s["project_bytes"] for s in stats])) * S  # per launch: S frames
-    feat_bytes = float(np.mean([s["feature_bytes"] for s in stats])) * S
-    # the road fallback runs as its own kernel (k_feature_road) when the thread path is on; its algorithmic bytes
-    # are the "+ 4*P2 + 25*k2" terms of the per-feature formula
-    road_bytes = float(np.mean([s["road_bytes"] for s in stats])) * S
-    main_bytes = feat_bytes - road_bytes if n_road else feat_bytes
-    cand = {"k_project_scatter": (k_proj_ms, proj_bytes), "k_feature_main": (k_feat_ms, main_bytes)}
-    if n_road:
-        cand["k_feature_road"] = (k_road_ms, road_bytes)
-    dominant = max(cand, key=lambda k: cand[k][0])
-    dom_ms, dom_bytes = cand[dominant]
-    achieved = (dom_bytes / (dom_ms * 1e-3)) / 1e9 if dom_ms > 0 else 0.0
-    traffic = pmc_traffic(dominant, S)
+        stats.append(traffic.frame_bytes(P, cam.width, cam.height, N, est.getVisibleCount(b), est.getPixelMap(b),
+                                         res.uvs_h[fr], res.all_type[fr].cpu().numpy()))
+        design.append(design_bytes_project(res.clouds_h[fr % U], cam, T, res.planes_h[fr % U][1]))
+    formula_project = float(np.mean([s["project_bytes"] for s in stats])) * S  # per launch: S frames
+    formula_feature = float(np.mean([s["feature_bytes"] for s in stats])) * S
+    design_project = float(np.mean([d["bytes"] for d in design])) * S
+
+    def ms(k):
+        return kt.get(k, {}).get("avg_ms", 0.0)
+
+    def gbps(nbytes, t_ms):
+        return (nbytes / (t_ms * 1e-3)) / 1e9 if t_ms > 0 else 0.0
+
+    # The dominant kernel by time.  k_project_scatter is the HBM-bound one (it streams every cloud once);
+    # k_feature_fused is bound by the rate of divergent gathers and by f64 issue, not by HBM - its
+    # figure below is the §8(d) per-feature formula over its launch time.
+    cand = {"k_project_scatter": ms("k_project_scatter"), "k_feature_fused": ms("k_feature_fused")}
+    dominant = max(cand, key=cand.get) if timing else "k_project_scatter"
+    dom_ms = cand.get(dominant, 0.0)
+    dom_bytes = design_project if dominant == "k_project_scatter" else formula_feature
+    pmc = pmc_traffic(dominant, S)
     roofline = {
         "bound": "hbm",
-        "achieved": achieved,
+        "achieved": gbps(dom_bytes, dom_ms),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS,
-        "traffic": traffic,
-        # the same kernel priced on the bytes the HBM counters saw (committed PMC profile) instead of the algorithmic
-        # formula, which also charges a map clear and a camera-frame copy that this implementation does not perform
-        "traffic_GBps": (traffic / (dom_ms * 1e-3)) / 1e9 if (traffic and dom_ms > 0) else None,
-        "traffic_frac": (traffic / (dom_ms * 1e-3)) / 1e9 / HBM_PEAK_GBS if (traffic and dom_ms > 0) else None,
+        "frac": gbps(dom_bytes, dom_ms) / HBM_PEAK_GBS,
+        "traffic": pmc[0] if pmc else None,
         "kernel": dominant,
         "kernel_ms": dom_ms,
-        "algorithmic_bytes_per_launch": dom_bytes,
+        "bytes_per_launch": dom_bytes,
+        "bytes_model": ("design: 16 B/point + 4 B per map entry + occupancy and inlier-mask words touched"
+                        if dominant == "k_project_scatter" else "SURVEY 8(d) per-feature formula"),
+        # the committed PMC profile of the same launch size, priced with ITS OWN kernel time (reproducible from
+        # profiles/: traffic.json and the kernel-stats summary it names)
+        "traffic_profile": ({"hbm_bytes_per_launch": pmc[0], "launch_ms": pmc[1] * 1e3,
+                             "frac": pmc[0] / pmc[1] / 1e9 / HBM_PEAK_GBS, "source": pmc[2]} if pmc else None),
         "kernels": {
-            "k_project_scatter": {"avg_ms": k_proj_ms, "launches": n_proj, "algorithmic_bytes_per_launch": proj_bytes,
-                                  "GBps": (proj_bytes / (k_proj_ms * 1e-3)) / 1e9 if k_proj_ms > 0 else 0.0},
-            "k_feature_main": {"avg_ms": k_feat_ms, "launches": n_feat, "algorithmic_bytes_per_launch": main_bytes,
-                                "GBps": (main_bytes / (k_feat_ms * 1e-3)) / 1e9 if k_feat_ms > 0 else 0.0},
-            "k_feature_road": {"avg_ms": k_road_ms, "launches": n_road, "algorithmic_bytes_per_launch": road_bytes,
-                               "GBps": (road_bytes / (k_road_ms * 1e-3)) / 1e9 if k_road_ms > 0 else 0.0},
+            "k_project_scatter": {**kt.get("k_project_scatter", {}), "design_bytes_per_launch": design_project,
+                                  "design_GBps": gbps(design_project, ms("k_project_scatter")),
+                                  "frac": gbps(design_project, ms("k_project_scatter")) / HBM_PEAK_GBS,
+                                  # 16 N + 4 W H + 28 Nvis - charges a map clear and a camera-frame copy
+                                  # that this design does not perform, so it may exceed the peak
+                                  "formula_bytes_per_launch": formula_project,
+                                  "formula_GBps": gbps(formula_project, ms("k_project_scatter"))},
+            "k_classify": kt.get("k_classify", {}),
+            "k_feature_fused": {**kt.get("k_feature_fused", {}), "formula_bytes_per_launch": formula_feature,
+                                "formula_GBps": gbps(formula_feature, ms("k_feature_fused"))},
+            "k_feature_wave": kt.get("k_feature_wave", {}),
         },
-        "k_feature_wave_ms": k_wave_ms,  # long-list overflow kernel (queue normally empty in this workload)
-        "k_sort_features_ms": k_sort_ms,  # row-order permutation of the features (counting sort per frame)
-        "feature_kernels_GBps": (feat_bytes / ((k_feat_ms + k_road_ms) * 1e-3)) / 1e9 if k_feat_ms > 0 else 0.0,
-        "whole_step_GBps": ((proj_bytes + feat_bytes) * (B // S) * args.steps / elapsed) / 1e9,
+        "whole_step_formula_GBps": ((formula_project + formula_feature) * (B // S) * args.steps / elapsed) / 1e9,
+        "whole_step_design_GBps": (design_project * (B // S) * args.steps / elapsed) / 1e9,
     }
 
-    cpu = None
-    if world == 1 and args.cpu_seconds > 0:
-        cpu = cpu_baseline(P, cam_struct, T, clouds_h, planes_h, uvs_h, args.cpu_seconds)
-
-    latency = None
-    if world == 1 and args.latency_frames > 0:
-        latency = latency_leg(P, cam, T, clouds_h, planes_h, uvs_h, args.latency_frames, local_rank)
-
-    streaming = None
-    if world == 1 and args.streaming_batches > 0:
-        streaming = streaming_leg(P, cam, T, clouds_h, planes_h, uvs_h, local_rank, args.streaming_frames,
-                                  args.streaming_batches)
+    cpu = latency = streaming = None
+    configs = {}
+    if world == 1:
+        if args.cpu_seconds > 0:
+            cpu = cpu_baseline(P, cam_struct, T, res.clouds_h, res.planes_h, res.uvs_h, args.cpu_seconds)
+        if args.latency_frames > 0:
+            latency = latency_leg(P, cam, T, res.clouds_h, res.planes_h, res.uvs_h, args.latency_frames, gpu_index)
+        if args.streaming_batches > 0:
+            streaming = streaming_leg(P, cam, T, res.clouds_h, res.planes_h, res.uvs_h, gpu_index, args.streaming_frames,
+                                      args.streaming_batches)
+    clouds_kept = None  # noqa: F841
+    res.close()
+    del res
+    torch.cuda.empty_cache()
+    if world == 1 and args.config_frames > 0:
+        configs["3"] = config3_leg(cam, T, gpu_index, args.config_frames)
+        configs["5"] = config5_leg(cam, T, gpu_index, min(args.config_frames, 200))
 
     value = units / elapsed
     out = {
@@ -454,12 +682,15 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
+        "verified": verified,
+        "verification": vrep,
         "config": {
             "workload": (f"BASELINE config 2: 64x2048 cloud ({N} points) x {F} features/frame, C0 parameters, "
-                         f"{B} device-resident frames per step per GPU in launch sets of {S}, plane-as-input"),
+                         f"{B} device-resident frames per step per GPU in launch sets of {S}, ground plane known at "
+                         "projection (setInputCloud(cloud, plane))"),
             "frames_per_step": B,
             "frame_slots_per_launch": S,
-            "contexts": NC,
+            "contexts": args.contexts,
             "features_per_frame": F,
             "points_per_frame": N,
             "sequences": world,
@@ -467,16 +698,20 @@ def main():
         },
         "result_types": {capi.RESULT_TYPE_NAMES[i]: int(c) for i, c in enumerate(type_hist) if c},
         "success_fraction": float((type_hist[1] + type_hist[16]) / max(1, type_hist.sum())),
-        "frame_stats": {k: float(np.mean([s[k] for s in stats])) for k in
-                        ("n_visible", "k1_mean", "k2_mean_fallback", "fallback_features")},
+        "frame_stats": {**{k: float(np.mean([s[k] for s in stats])) for k in
+                           ("n_visible", "k1_mean", "k2_mean_fallback", "fallback_features")},
+                        "n_front_in_image": float(np.mean([d["n_front_in_image"] for d in design]))},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "latency": latency,
         "streaming": streaming,
+        "configs": configs,
     }
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    bad_cfg = any(c.get("verified") is False for c in configs.values())
+    sys.exit(1 if (verified is False or bad_cfg) else 0)
 
 
 if __name__ == "__main__":

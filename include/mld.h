@@ -239,6 +239,16 @@ int mld_calculate_depth(mld_ctx* ctx, int slot, const double* uv_host, int64_t F
                         int32_t* type_out_host);
 int mld_calculate_depth_device(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, double* depth_out_dev,
                                int32_t* type_out_dev);
+/*
+ * CalculateDepth(cloud, uv, depths, resultType, groundPlane) (DepthEstimator.cpp:404-420: setInputCloud followed by
+ * the per-feature loop) for ONE frame held in host memory, in a single call: mld_set_cloud + mld_set_ground_plane +
+ * mld_calculate_depth with the small transfers combined and the plane installed before the projection.  The one-frame
+ * latency path of a ROS callback (tracklet_depth_module.cpp:63-117).  coeffs == NULL: no plane (road fallback off).
+ * Synchronises.  type_out may be NULL.
+ */
+int mld_calculate_depth_frame(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, int stride_bytes,
+                              const float coeffs[4], const int32_t* inlier_idx_host, int64_t n_inliers,
+                              const double* uv_host, int64_t F, double* depth_out_host, int32_t* type_out_host);
 /* All slots [0, n_slots) in ONE launch set (host arrays of device pointers / counts). */
 int mld_calculate_depths_device(mld_ctx* ctx, int n_slots, const double* const* uv_dev, const int64_t* F,
                                 double* const* depth_out_dev, int32_t* const* type_out_dev);

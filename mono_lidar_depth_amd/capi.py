@@ -135,6 +135,8 @@ _SIGNATURES = [
     ("mld_set_ground_plane_mask_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p]),
     ("mld_set_ground_planes_mask_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), _P(C.c_void_p)]),
     ("mld_calculate_depth", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("mld_calculate_depth_frame", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, _P(C.c_float), C.c_void_p,
+                                            C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("mld_calculate_depth_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("mld_calculate_depths_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64),
                                               _P(C.c_void_p), _P(C.c_void_p)]),

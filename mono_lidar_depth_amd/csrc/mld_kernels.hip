@@ -1828,8 +1828,10 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
 // Wave-cooperative kernel for the features the thread kernels could not hold (lists longer than their capacities).
 // Queue entries: (feature, -1) = main path + road fallback, (feature, t >= 0) = road fallback only, t being the
 // main path's result.
+// `chunk` (<= 64) queue entries per block and iteration: a wavefront works on ONE feature at a time, so small chunks
+// spread a long queue (dense clouds: every feature overflows) over many more wavefronts.
 __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restrict__ slots, SlotDesc single, int use_single,
-                                                        Calib c, int n_slots, int per_slot, uint32_t tag_all) {
+                                                        Calib c, int n_slots, int per_slot, uint32_t tag_all, int chunk) {
     extern __shared__ __align__(16) unsigned char smem[];
     int slot, j;
     decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
@@ -1838,9 +1840,8 @@ __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restri
     if (!s.ovf_count) return;
     const int count = *GPTR(int32_t, s.ovf_count);
     const int lane = threadIdx.x;
-    // few blocks per slot (the queue is usually empty), each striding over the queue in chunks of 64 entries
-    for (int e0 = j * kWave; e0 < count; e0 += per_slot * kWave) {
-        const bool active = e0 + lane < count;
+    for (int e0 = j * chunk; e0 < count; e0 += per_slot * chunk) {
+        const bool active = lane < chunk && e0 + lane < count;
         long long f = 0;
         int code = 0;
         double myu = 0, myv = 0;

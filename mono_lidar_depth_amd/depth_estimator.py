@@ -381,6 +381,9 @@ class DepthEstimator:
         """
         if len(args) == 3:
             cloud, uv, gp = args
+            fast = self._frame_call(cloud, uv, gp, slot)
+            if fast is not None:
+                return fast if return_types else fast[0]
             self.setInputCloud(cloud, gp, slot=slot)
         elif len(args) == 1:
             (uv,) = args
@@ -412,6 +415,35 @@ class DepthEstimator:
                                                       types.ctypes.data))
         self._last_types = types
         return (depth, types) if return_types else depth
+
+    def _frame_call(self, cloud, uv, gp, slot):
+        """CalculateDepth(cloud, uv, groundPlane) entirely from host memory with a plane that needs no estimation: the
+        single-call entry point mld_calculate_depth_frame (one frame per call, the ROS usage).  None: not applicable."""
+        self._require_init("CalculateDepth")
+        if self._debug or _is_torch_cuda(cloud) or _is_torch_cuda(uv):
+            return None
+        road = bool(self._parameters.do_use_ransac_plane)
+        if road and gp is not NO_PLANE:
+            if gp is None or not isinstance(gp, GroundPlane) or not gp.isSegmented() or _is_torch_cuda(gp.inliers):
+                return None
+            if isinstance(gp, RansacPlane) and gp.inliers is None:
+                return None
+        ptr, n, stride, keep = self._cloud_view(cloud)
+        uvh = self._uv_host(uv)
+        F = int(uvh.size // 2)
+        depth = np.empty(F, dtype=np.float64)
+        types = np.empty(F, dtype=np.int32)
+        if road and gp is not NO_PLANE:
+            coeffs = (C.c_float * 4)(*[float(x) for x in gp.coeffs])
+            inl = np.ascontiguousarray(gp.inliers, dtype=np.int32)
+            self._check(self._lib.mld_calculate_depth_frame(self._ctx, slot, ptr, n, stride, coeffs, inl.ctypes.data,
+                                                            int(inl.size), uvh.ctypes.data, F, depth.ctypes.data,
+                                                            types.ctypes.data))
+        else:
+            self._check(self._lib.mld_calculate_depth_frame(self._ctx, slot, ptr, n, stride, None, None, 0,
+                                                            uvh.ctypes.data, F, depth.ctypes.data, types.ctypes.data))
+        self._last_types = types
+        return depth, types
 
     # ------------------------------------------------------------------ debug mode
     def ActivateDebugMode(self):

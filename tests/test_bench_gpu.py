@@ -1,0 +1,42 @@
+"""bench.py end to end on the GPU box: the `--gpus N` launcher (two ranks sharing the one visible GPU, collectives over
+gloo through the MLD_BENCH_BACKEND hook) and the self-check of the timed batch against the oracle."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+pytestmark = pytest.mark.gpu
+
+SMALL = ["--steps", "2", "--warmup", "1", "--frames-per-step", "32", "--unique-frames", "4", "--cpu-seconds", "0",
+         "--latency-frames", "0", "--streaming-batches", "0", "--config-frames", "0"]
+
+
+def _run(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py")] + extra, capture_output=True, text=True, timeout=900,
+                       env=env, cwd=str(ROOT))
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_two_ranks_and_each_checks_its_sequence():
+    out = _run(["--gpus", "2"] + SMALL, {"MLD_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["config"]["sequences"] == 2
+    assert out["verified"] is True
+    assert out["value"] > 0 and out["scaling"] == "weak"
+
+
+def test_bench_single_rank_line_is_physical():
+    out = _run(SMALL)
+    assert out["n_gpus"] == 1 and out["verified"] is True
+    r = out["roofline"]
+    assert 0.0 < r["frac"] <= 1.0
+    assert r["kernels"]["k_project_scatter"]["frac"] <= 1.0
+    assert out["verification"]["mismatching_frames"] == []
