@@ -237,6 +237,10 @@ int mld_set_ground_planes_mask_device(mld_ctx* ctx, int n_slots, const float* co
  */
 int mld_calculate_depth(mld_ctx* ctx, int slot, const double* uv_host, int64_t F, double* depth_out_host,
                         int32_t* type_out_host);
+/* flags of mld_calculate_depth_opts */
+#define MLD_CALC_SKIP_ROAD 1u /* this call only: "ransacPlane == nullptr" (DepthEstimator.cpp:580), the slot's plane stays */
+int mld_calculate_depth_opts(mld_ctx* ctx, int slot, const double* uv_host, int64_t F, double* depth_out_host,
+                             int32_t* type_out_host, uint32_t flags);
 int mld_calculate_depth_device(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, double* depth_out_dev,
                                int32_t* type_out_dev);
 /*

@@ -1083,7 +1083,7 @@ int mld_set_ground_planes_mask_device(mld_ctx* ctx, int n_slots, const float* co
 
 // ---------------------------------------------------------------------------- CalculateDepth
 static int calc_one(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, double* depth_dev, int32_t* type_dev,
-                    double* corners_dev = nullptr) {
+                    double* corners_dev = nullptr, bool skip_road = false) {
     Slot& s = ctx->slots[slot];
     s.d.uv = uv_dev;
     s.d.F = F;
@@ -1110,6 +1110,11 @@ static int calc_one(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, dou
         s.d.corners = nullptr;
         return rc;
     }
+    if (skip_road) {  // "ransacPlane == nullptr" for this call only (DepthEstimator.cpp:580)
+        Calib nr = ctx->calib;
+        nr.useRoad = 0;
+        return launch_features(ctx, 1, F, true, slot, &nr);
+    }
     return launch_features(ctx, 1, F, true, slot);
 }
 
@@ -1125,11 +1130,19 @@ int mld_calculate_depth_device(mld_ctx* ctx, int slot, const double* uv_dev, int
 
 int mld_calculate_depth(mld_ctx* ctx, int slot, const double* uv_host, int64_t F, double* depth_out_host,
                         int32_t* type_out_host) {
+    return mld_calculate_depth_opts(ctx, slot, uv_host, F, depth_out_host, type_out_host, 0u);
+}
+
+int mld_calculate_depth_opts(mld_ctx* ctx, int slot, const double* uv_host, int64_t F, double* depth_out_host,
+                             int32_t* type_out_host, uint32_t flags) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     if ((rc = bind_device(ctx))) return rc;
     Slot& s = ctx->slots[slot];
-    if ((rc = precheck_calc(ctx, s, F))) return rc;
+    const bool skip_road = (flags & MLD_CALC_SKIP_ROAD) != 0;
+    if (!s.cloud_set) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "call of 'CalculateDepth' without 'SetInputCloud'");
+    if (!skip_road && (rc = precheck_calc(ctx, s, F))) return rc;
+    if (F < 0 || F > 0x7FFFFFFFLL) return fail(ctx, MLD_ERR_INVALID_ARG, "bad feature count");
     if (F == 0) return MLD_OK;
     if (!uv_host || !depth_out_host) return fail(ctx, MLD_ERR_INVALID_ARG, "null feature/output pointer");
     if ((size_t)F > s.feat_cap) {
@@ -1146,7 +1159,7 @@ int mld_calculate_depth(mld_ctx* ctx, int slot, const double* uv_host, int64_t F
         s.feat_cap = (size_t)F;
     }
     HIP_TRY(ctx, hipMemcpyAsync(s.uv_buf, uv_host, (size_t)F * 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = calc_one(ctx, slot, s.uv_buf, F, s.depth_buf, s.type_buf))) return rc;
+    if ((rc = calc_one(ctx, slot, s.uv_buf, F, s.depth_buf, s.type_buf, nullptr, skip_road))) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(depth_out_host, s.depth_buf, (size_t)F * sizeof(double), hipMemcpyDeviceToHost,
                                 ctx->stream));
     if (type_out_host)

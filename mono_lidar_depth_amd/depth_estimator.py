@@ -214,6 +214,27 @@ class DepthEstimator:
     def stream(self) -> int:
         return int(self._lib.mld_get_stream(self._ctx) or 0)
 
+    @staticmethod
+    def _after_torch(*tensors):
+        """The context launches on its own non-blocking HIP stream.  Device tensors handed in may still be being
+        written by work queued on torch's current stream (a kernel, a non_blocking copy): wait for that stream before
+        launching on ours.  (Idle stream: a few microseconds.)"""
+        import torch
+        for t in tensors:
+            if t is not None and _is_torch_cuda(t):
+                torch.cuda.current_stream(t.device).synchronize()
+                return
+
+    def orderTorchAfter(self):
+        """Makes torch's current stream wait for everything queued on the context's stream so far: outputs of the
+        asynchronous batch calls (runBatch, CalculateDepths) may then be consumed by torch operations without a host
+        synchronisation."""
+        import torch
+        dev = torch.device("cuda", self._device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.ExternalStream(self.stream, device=dev))
+        torch.cuda.current_stream(dev).wait_event(ev)
+
     def synchronize(self):
         self._check(self._lib.mld_synchronize(self._ctx))
 
@@ -244,6 +265,7 @@ class DepthEstimator:
         ptr, n, stride, keep = self._cloud_view(cloud)
         self._keepalive[("cloud", slot)] = keep
         if _is_torch_cuda(cloud):
+            self._after_torch(cloud)
             self._check(self._lib.mld_set_cloud_device(self._ctx, slot, ptr, n, stride))
         else:
             self._check(self._lib.mld_set_cloud(self._ctx, slot, ptr, n, stride))
@@ -275,6 +297,7 @@ class DepthEstimator:
             if inl.dtype != torch.int32 or not inl.is_contiguous():
                 raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "inliers must be contiguous int32")
             self._keepalive[("inl", slot)] = inl
+            self._after_torch(inl)
             self._check(self._lib.mld_set_ground_plane_device(self._ctx, slot, coeffs, inl.data_ptr(), int(inl.numel())))
         else:
             arr = np.ascontiguousarray(inl, dtype=np.int32)
@@ -287,6 +310,7 @@ class DepthEstimator:
         c = np.ascontiguousarray(coeffs, dtype=np.float32).reshape(n_slots, 4)
         ptrs = (C.c_void_p * n_slots)(*[int(m.data_ptr()) for m in masks])
         self._keepalive["masks"] = list(masks)
+        self._after_torch(*masks[:1])
         self._check(self._lib.mld_set_ground_planes_mask_device(
             self._ctx, n_slots, c.ctypes.data_as(C.POINTER(C.c_float)), ptrs))
 
@@ -308,8 +332,10 @@ class DepthEstimator:
 
     def runBatch(self, b):
         """One pass of the hot path over the batch: setInputCloud + ground-plane hook + CalculateDepth for every
-        slot (asynchronous on `stream`)."""
+        slot (asynchronous on `stream`; inputs still being produced on torch's current stream are waited for, use
+        `synchronize()` or `orderTorchAfter()` before consuming the outputs)."""
         lib, ctx, n = self._lib, self._ctx, b["n"]
+        self._after_torch(b["keep"][0][0])
         self._check(lib.mld_set_clouds_planes_device(ctx, n, b["cloud_ptrs"], b["cloud_n"], b["stride"],
                                                      b["coeffs"].ctypes.data_as(C.POINTER(C.c_float)), b["mask_ptrs"]))
         self._check(lib.mld_calculate_depths_device(ctx, n, b["uv_ptrs"], b["F"], b["depth_ptrs"], b["type_ptrs"]))
@@ -367,18 +393,21 @@ class DepthEstimator:
                 raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "setInputClouds needs CUDA clouds of one stride")
             ptrs[i], counts[i] = p, n
             self._keepalive[("cloud", i)] = keep
+        self._after_torch(*clouds[:1])
         self._check(self._lib.mld_set_clouds_device(self._ctx, n_slots, ptrs, counts, stride_bytes))
 
     # ------------------------------------------------------------------ CalculateDepth
-    def CalculateDepth(self, *args, slot: int = 0, return_types: bool = True):
+    def CalculateDepth(self, *args, slot: int = 0, return_types: bool = True, uv_layout: Optional[str] = None):
         """The reference's overloads (DepthEstimator.cpp:404-488):
 
         CalculateDepth(cloud, uv, groundPlane)   -> setInputCloud + per-feature loop
         CalculateDepth(uv)                       -> per-feature loop on the current cloud
-        `uv` is 2 x F (Eigen::Matrix2Xd layout, column i = (u,v)) or F x 2.  Returns (depths, resultTypes)
-        — the callee-resized VectorXd / VectorXi of the reference — as numpy arrays (host input) or torch
-        CUDA tensors (device input).
+        `uv` is 2 x F (Eigen::Matrix2Xd layout, column i = (u,v)) or F x 2; a 2 x 2 array is ambiguous and needs
+        uv_layout="2xF" (the reference's layout) or "Fx2".  Returns (depths, resultTypes) — the callee-resized
+        VectorXd / VectorXi of the reference — as numpy arrays (host input) or torch CUDA tensors (device input;
+        asynchronous inputs on torch's current stream are waited for, the results are complete on return).
         """
+        self._uv_layout = uv_layout
         if len(args) == 3:
             cloud, uv, gp = args
             fast = self._frame_call(cloud, uv, gp, slot)
@@ -491,12 +520,20 @@ class DepthEstimator:
             self._check(self._lib.mld_get_ground_plane_cloud(self._ctx, slot, out.ctypes.data, n.value, C.byref(n)))
         return out.T
 
-    @staticmethod
-    def _uv_host(uv) -> np.ndarray:
+    def _uv_host(self, uv) -> np.ndarray:
         a = np.asarray(uv, dtype=np.float64)
         if a.ndim != 2:
             raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "uv must be 2xF or Fx2")
-        if a.shape[0] == 2 and a.shape[1] != 2:
+        layout = getattr(self, "_uv_layout", None)
+        if layout not in (None, "2xF", "Fx2"):
+            raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "uv_layout must be '2xF' or 'Fx2'")
+        if a.shape == (2, 2) and layout is None:
+            # two features as Eigen::Matrix2Xd (columns) or as rows: silently guessing would transpose one of them
+            raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG,
+                                      "a 2x2 uv array is ambiguous: pass uv_layout='2xF' (Eigen::Matrix2Xd) or 'Fx2'")
+        if layout == "2xF" or (layout is None and a.shape[0] == 2 and a.shape[1] != 2):
+            if a.shape[0] != 2:
+                raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "uv must be 2xF")
             a = a.T  # Matrix2Xd -> interleaved (u0,v0,u1,v1,...) == column-major 2xF
         elif a.shape[1] != 2:
             raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "uv must be 2xF or Fx2")
@@ -522,6 +559,7 @@ class DepthEstimator:
             Fs[i] = int(uvd.shape[0])
             dp[i] = depths[i].data_ptr()
             tp[i] = types[i].data_ptr() if types is not None else None
+        self._after_torch(*uvs[:1])
         self._check(self._lib.mld_calculate_depths_device(self._ctx, n_slots, uvp, Fs, dp, tp if types is not None else None))
 
     # ------------------------------------------------------------------ debug getters

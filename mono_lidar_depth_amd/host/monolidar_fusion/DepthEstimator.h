@@ -154,7 +154,8 @@ public:
     }
     bool isSegmented() const { return is_segmented_; }
     std::array<float, 4>& getModelCoeffs() { return _modelCoeffs; }
-    const std::vector<int>& getInlinersIndex() { return _inliersIndex; }
+    const std::array<float, 4>& getModelCoeffs() const { return _modelCoeffs; }
+    const std::vector<int>& getInlinersIndex() const { return _inliersIndex; }
     bool CheckPointInPlane(const int index) const {
         for (int i : _inliersIndex)
             if (i == index) return true;
@@ -275,6 +276,7 @@ public:
         check(mld_set_cloud(_ctx, slot, cloud->points.data(), (int64_t)cloud->points.size(), (int)sizeof(PointXYZI)));
         _numPoints = (int64_t)cloud->points.size();
         _isInitializedPointCloud = true;
+        _installedPlane = nullptr;
         if (_parameters->do_use_ransac_plane) {
             if (groundPlane == nullptr) groundPlane = std::make_shared<RansacPlane>(_parameters);  // DepthEstimator.cpp:275-278
             if (!groundPlane->isSegmented()) {                                               // :281-283
@@ -296,12 +298,11 @@ public:
                     std::vector<int> inl((size_t)n_inl);
                     check(mld_get_ground_plane_inliers(_ctx, slot, reinterpret_cast<int32_t*>(inl.data()), n_inl, &n_inl));
                     rp->assign({coeffs[0], coeffs[1], coeffs[2], coeffs[3]}, std::move(inl));
+                    _installedPlane = groundPlane.get();
                     return;  // the estimator already installed the plane on the device
                 }
             }
-            const auto& c = groundPlane->getModelCoeffs();
-            const auto& inl = groundPlane->getInlinersIndex();
-            check(mld_set_ground_plane(_ctx, slot, c.data(), inl.data(), (int64_t)inl.size()));
+            installPlane(*groundPlane, slot);
         } else {
             check(mld_set_ground_plane(_ctx, slot, nullptr, nullptr, 0));
         }
@@ -383,6 +384,24 @@ public:
     }
     void CalculateDepth(const Cloud::ConstPtr& pointCloud, const std::vector<double>& points_image_cs,
                         std::vector<double>& points_depths, std::vector<int>& resultType, GroundPlane::Ptr& ransacPlane) {
+        const int64_t F = (int64_t)(points_image_cs.size() / 2);
+        if (frameCall(pointCloud, points_image_cs.data(), F, ransacPlane)) {  // one C-ABI call for the whole frame
+            points_depths.resize((size_t)F);
+            resultType.resize((size_t)F);
+            static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
+            const bool road = _parameters->do_use_ransac_plane;
+            check(mld_calculate_depth_frame(_ctx, 0, pointCloud->points.data(), (int64_t)pointCloud->points.size(),
+                                            (int)sizeof(PointXYZI), road ? ransacPlane->getModelCoeffs().data() : nullptr,
+                                            road ? reinterpret_cast<const int32_t*>(ransacPlane->getInlinersIndex().data()) : nullptr,
+                                            road ? (int64_t)ransacPlane->getInlinersIndex().size() : 0,
+                                            points_image_cs.data(), F, points_depths.data(),
+                                            reinterpret_cast<int32_t*>(resultType.data())));
+            _numPoints = (int64_t)pointCloud->points.size();
+            _isInitializedPointCloud = true;
+            _installedPlane = road ? ransacPlane.get() : nullptr;
+            _depthCalcStats.SetFromTypes(reinterpret_cast<const int32_t*>(resultType.data()), F);
+            return;
+        }
         setInputCloud(pointCloud, ransacPlane);
         CalculateDepth(points_image_cs, points_depths, resultType, ransacPlane);
     }
@@ -394,8 +413,9 @@ public:
     void CalculateDepth(const std::vector<double>& points_image_cs, std::vector<double>& points_depths,
                         std::vector<int>& resultType, const GroundPlane::Ptr& ransacPlane) {
         if (!_isInitializedPointCloud) throw "call of 'CalculateDepth' without 'SetInputCloud'";
-        if (ransacPlane == nullptr && _parameters->do_use_ransac_plane)
-            check(mld_set_ground_plane(_ctx, 0, nullptr, nullptr, 0));  // "ransacPlane == nullptr": no road fallback
+        // The reference decides per call (DepthEstimator.cpp:580): a null plane skips the road fallback for THIS call
+        // only, a plane other than the one installed with the cloud is installed first.
+        const uint32_t flags = planeForCall(ransacPlane);
         const int64_t F = (int64_t)(points_image_cs.size() / 2);
         points_depths.resize((size_t)F);  // callee-resized outputs, DepthEstimator.cpp:442-443
         resultType.resize((size_t)F);
@@ -409,8 +429,8 @@ public:
             _depthCalcStats.SetFromTypes(reinterpret_cast<const int32_t*>(resultType.data()), F);
             return;
         }
-        check(mld_calculate_depth(_ctx, 0, points_image_cs.data(), F, points_depths.data(),
-                                  reinterpret_cast<int32_t*>(resultType.data())));
+        check(mld_calculate_depth_opts(_ctx, 0, points_image_cs.data(), F, points_depths.data(),
+                                       reinterpret_cast<int32_t*>(resultType.data()), flags));
         _depthCalcStats.SetFromTypes(reinterpret_cast<const int32_t*>(resultType.data()), F);
     }
     std::pair<DepthResultType, double> CalculateDepth(const std::array<double, 2>& point_image_cs,
@@ -444,12 +464,11 @@ public:
     void CalculateDepth(const Eigen::Matrix2Xd& featurePoints_image_cs, Eigen::VectorXd& points_depths,
                         Eigen::VectorXi& resultType, const GroundPlane::Ptr& ransacPlane) {
         if (!_isInitializedPointCloud) throw "call of 'CalculateDepth' without 'SetInputCloud'";
-        if (ransacPlane == nullptr && _parameters->do_use_ransac_plane)
-            check(mld_set_ground_plane(_ctx, 0, nullptr, nullptr, 0));
+        const uint32_t flags = planeForCall(ransacPlane);
         const int64_t F = featurePoints_image_cs.cols();
         points_depths.resize(F);
         resultType.resize(F);
-        check(mld_calculate_depth(_ctx, 0, featurePoints_image_cs.data(), F, points_depths.data(), resultType.data()));
+        check(mld_calculate_depth_opts(_ctx, 0, featurePoints_image_cs.data(), F, points_depths.data(), resultType.data(), flags));
         _depthCalcStats.SetFromTypes(resultType.data(), F);
     }
     std::pair<DepthResultType, double> CalculateDepth(const Eigen::Vector2d& point_image_cs, const GroundPlane::Ptr& ransacPlane) {
@@ -467,6 +486,31 @@ public:
     }
 
 private:
+    // installs a segmented plane (coefficients + inlier set) as the slot's ground plane
+    void installPlane(const GroundPlane& gp, int slot = 0) {
+        const auto& c = gp.getModelCoeffs();
+        const auto& inl = gp.getInlinersIndex();
+        static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
+        check(mld_set_ground_plane(_ctx, slot, c.data(), reinterpret_cast<const int32_t*>(inl.data()), (int64_t)inl.size()));
+        _installedPlane = &gp;
+    }
+    // per-call plane of the feature-only overloads: returns the flags for mld_calculate_depth_opts
+    uint32_t planeForCall(const GroundPlane::Ptr& ransacPlane) {
+        if (!_parameters->do_use_ransac_plane) return 0u;
+        if (ransacPlane == nullptr) return MLD_CALC_SKIP_ROAD;
+        if (ransacPlane.get() != _installedPlane && ransacPlane->isSegmented()) installPlane(*ransacPlane);
+        return 0u;
+    }
+    // the whole frame can go through mld_calculate_depth_frame: no debug vectors wanted and nothing to estimate
+    bool frameCall(const Cloud::ConstPtr& cloud, const double* uv, int64_t F, const GroundPlane::Ptr& gp) const {
+        (void)uv;
+        (void)F;
+        if (!_isInitialized || _debugMode || !cloud) return false;
+        if (!_parameters->do_use_ransac_plane) return true;
+        return gp != nullptr && gp->isSegmented();
+    }
+    const GroundPlane* _installedPlane = nullptr;
+
     void check(int rc) {
         if (rc == MLD_OK) return;
         if (rc == MLD_ERR_CLOUD_TOO_SMALL) throw GroundPlane::ExceptionPclInvalid();

@@ -99,6 +99,30 @@ int main(int argc, char** argv) {
             std::cout << "semantic segmented " << (sem->isSegmented() ? 1 : 0) << " inliers " << sem->getInlinersIndex().size()
                       << " nz " << sem->getModelCoeffs()[2] << "\n";
         }
+        // The reference decides about the road fallback per call (DepthEstimator.cpp:580): a null plane switches it off
+        // for that call only, the plane handed in afterwards is used again, and so is a DIFFERENT plane object.
+        if (est.getParameters()->do_use_ransac_plane) {
+            DepthEstimator e2(0);
+            auto p2 = std::make_shared<DepthEstimatorParameters>();
+            mld_params_c0(p2.get());
+            e2.InitConfig(p2);
+            e2.Initialize(cam, T);
+            std::vector<double> da, db, dc, dd;
+            std::vector<int> ta, tb, tc, td;
+            e2.CalculateDepth(ccloud, uv, da, ta, gp);
+            GroundPlane::Ptr none;
+            e2.CalculateDepth(uv, db, tb, none);
+            e2.CalculateDepth(uv, dc, tc, gp);
+            std::vector<int> half;
+            for (size_t i = 0; i < gp->getInlinersIndex().size(); i += 2) half.push_back(gp->getInlinersIndex()[i]);
+            GroundPlane::Ptr other = std::make_shared<GroundPlane>(std::array<float, 4>{0.f, 0.f, 1.f, 1.73f}, half);
+            e2.CalculateDepth(uv, dd, td, other);
+            size_t road_b = 0, road_d = 0;
+            for (int t : tb) road_b += t == SuccessRoad;
+            for (int t : td) road_d += t == SuccessRoad;
+            std::cout << "percall same_after_null " << ((ta == tc && da == dc) ? 1 : 0) << " road_with_null " << road_b
+                      << " road_other " << road_d << " road_first " << stats[SuccessRoad] << "\n";
+        }
         // usage error as in the reference: CalculateDepth before setInputCloud
         DepthEstimator fresh(0);
         fresh.InitConfig();

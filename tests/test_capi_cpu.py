@@ -153,3 +153,19 @@ def test_params_from_file_tolerates_formatting(tmp_path):
     assert p.do_use_ransac_plane == 0     # absent key reads as 0
     with pytest.raises(Exception, match="Cant find settings file"):
         capi.params_from_file(str(tmp_path / "missing.yaml"))
+
+
+def test_uv_layouts_of_the_python_mirror():
+    """Eigen::Matrix2Xd (2 x F, columns are features) and F x 2 are both accepted; 2 x 2 is ambiguous and must be
+    disambiguated instead of being silently transposed."""
+    from mono_lidar_depth_amd.depth_estimator import DepthEstimator, DepthEstimatorError
+    e = DepthEstimator.__new__(DepthEstimator)
+    a = np.arange(10, dtype=np.float64).reshape(5, 2)
+    assert np.array_equal(e._uv_host(a), a) and np.array_equal(e._uv_host(a.T), a)
+    two = np.array([[1.0, 2.0], [3.0, 4.0]])
+    with pytest.raises(DepthEstimatorError, match="ambiguous"):
+        e._uv_host(two)
+    e._uv_layout = "2xF"
+    assert np.array_equal(e._uv_host(two), [[1.0, 3.0], [2.0, 4.0]])  # columns (1,3) and (2,4) are the features
+    e._uv_layout = "Fx2"
+    assert np.array_equal(e._uv_host(two), two)

@@ -52,6 +52,12 @@ def test_cpp_shim_matches_oracle(tmp_path, with_plane):
     assert n_plane == (np.unique(inl).size if with_plane else 0)
     assert n_nb == 0 and n_cam == cloud.shape[0]
     if with_plane:
+        # per-call plane of the feature-only overloads: null plane -> no road result in that call, the slot's plane
+        # is used again afterwards (bit-identical results), another plane object is installed when it is handed in
+        m = re.search(r"percall same_after_null (\d+) road_with_null (\d+) road_other (\d+) road_first (\d+)", r.stdout)
+        assert m, r.stdout
+        same_after, road_null, road_other, road_first = map(int, m.groups())
+        assert same_after == 1 and road_null == 0 and road_first > 0 and 0 < road_other < road_first
         m = re.search(r"semantic segmented (\d+) inliers (\d+) nz (\S+)", r.stdout)
         assert m, r.stdout
         assert int(m.group(1)) == 1 and int(m.group(2)) > 1000 and abs(abs(float(m.group(3))) - 1.0) < 0.05
