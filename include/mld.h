@@ -186,6 +186,20 @@ int mld_set_clouds_planes_device(mld_ctx* ctx, int n_slots, const void* const* p
                                  int stride_bytes, const float* coeffs, const uint32_t* const* mask_dev);
 
 /*
+ * setInputCloud(cloud, groundPlane) with a plane that is NOT segmented yet — the reference's default call — for slots
+ * [0, n_slots) in one asynchronous launch set: RansacPlane::CalculateInliersPlane (RansacPlane.cpp:41-140) runs for
+ * every slot on the GPU (one block per slot), the planes stay in device memory where the projection (inlier flags in
+ * the map keys) and the feature kernels read them; nothing returns to the host.  seeds: one per slot (the reference's
+ * pcl::RandomSample is time-seeded).  A slot whose estimation fails (GroundPlane::ExceptionPclInvalid, which the
+ * caller of the reference catches, tracklet_depth_module.cpp:321,338) runs without the road fallback.
+ * mld_get_estimated_planes returns coefficients / inlier counts / status (0 ok, 1 failed) and synchronises; the inlier
+ * sets are available through mld_get_ground_plane_inliers.
+ */
+int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev, const int64_t* n,
+                                          int stride_bytes, const uint32_t* seeds);
+int mld_get_estimated_planes(mld_ctx* ctx, int n_slots, float* coeffs_out, int64_t* n_inliers_out, int32_t* status_out);
+
+/*
  * The GroundPlane object handed to setInputCloud/CalculateDepth (RansacPlane.h:38-123):
  * coefficients a,b,c,d in the LIDAR frame + the inlier index set keyed by ORIGINAL cloud index
  * (`_pointIsInPlane`, RansacPlane.h:116-122).  coeffs == NULL: "ransacPlane == nullptr"

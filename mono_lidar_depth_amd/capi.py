@@ -124,6 +124,9 @@ _SIGNATURES = [
     ("mld_set_clouds_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64), C.c_int]),
     ("mld_set_clouds_planes_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64), C.c_int,
                                                _P(C.c_float), _P(C.c_void_p)]),
+    ("mld_set_clouds_estimate_planes_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64), C.c_int,
+                                                        _P(C.c_uint32)]),
+    ("mld_get_estimated_planes", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), _P(C.c_int64), _P(C.c_int32)]),
     ("mld_set_ground_plane", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p, C.c_int64]),
     ("mld_set_ground_plane_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_float), C.c_void_p, C.c_int64]),
     ("mld_estimate_ground_plane", C.c_int, [C.c_void_p, C.c_int, C.c_uint32, _P(C.c_float), _P(C.c_int64)]),

@@ -121,6 +121,11 @@ struct mld_ctx {
     unsigned char* fr_host = nullptr;  // pinned: [inlier indices | uv] in, [depth | type] out
     unsigned char* fr_dev = nullptr;
     size_t fr_cap = 0;
+    // batched ground-plane estimation (mld_set_clouds_estimate_planes_device)
+    uint32_t* rsb_masks = nullptr;   // inlier bitmasks of all slots, contiguous
+    size_t rsb_mask_words = 0;       // per slot
+    PlaneDev* rsb_planes = nullptr;  // one per slot
+    uint32_t* rsb_seeds = nullptr;
     hipStream_t side = nullptr;  // the plane's inlier mask is built here while the cloud is still in flight
     hipEvent_t side_done = nullptr;
     bool timing = false;
@@ -364,6 +369,7 @@ int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int strid
     s.d.has_plane = 0;
     s.d.inlier_mask = nullptr;
     s.d.mask_in_key = 0;
+    s.d.plane_dev = nullptr;
     s.cloud_set = true;
     s.plane_decided = false;
     s.full_valid = false;
@@ -497,6 +503,7 @@ void set_plane_coeffs(Slot& s, const float coeffs[4]) {
     s.d.prior_n[2] = cc;
     s.d.prior_off = (double)coeffs[3];
     s.d.has_plane = 1;
+    s.d.plane_dev = nullptr;
     s.plane_decided = true;
 }
 
@@ -505,6 +512,7 @@ void clear_plane(Slot& s) {
     s.d.has_plane = 0;
     s.d.inlier_mask = nullptr;
     s.d.mask_in_key = 0;
+    s.d.plane_dev = nullptr;
     s.plane_decided = true;
 }
 
@@ -719,6 +727,9 @@ void mld_destroy(mld_ctx* ctx) {
                    ctx->trk_type_last, ctx->trk_rank, ctx->trk_n_new, ctx->trk_stage};
     for (void* p : trk)
         if (p) (void)hipFree(p);
+    if (ctx->rsb_masks) (void)hipFree(ctx->rsb_masks);
+    if (ctx->rsb_planes) (void)hipFree(ctx->rsb_planes);
+    if (ctx->rsb_seeds) (void)hipFree(ctx->rsb_seeds);
     if (ctx->fr_host) (void)hipHostFree(ctx->fr_host);
     if (ctx->fr_dev) (void)hipFree(ctx->fr_dev);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
@@ -803,6 +814,100 @@ int mld_set_clouds_planes_device(mld_ctx* ctx, int n_slots, const void* const* p
                                  const float* coeffs, const uint32_t* const* mask_dev) {
     if (ctx && (!coeffs || !mask_dev)) return fail(ctx, MLD_ERR_INVALID_ARG, "null plane arrays");
     return set_clouds_common(ctx, n_slots, pts_dev, n, stride_bytes, coeffs, mask_dev);
+}
+
+// setInputCloud for slots [0, n_slots) with the ground plane ESTIMATED for every slot (the reference's default: the
+// GroundPlane handed in is not segmented yet, DepthEstimator.cpp:275-283 -> RansacPlane::CalculateInliersPlane): one
+// launch of k_rs_batch (a block per slot) ahead of the projection, nothing returns to the host.
+int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev, const int64_t* n,
+                                          int stride_bytes, const uint32_t* seeds) {
+    using namespace ransac;
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    if (n_slots < 1 || n_slots > (int)ctx->slots.size() || !pts_dev || !n || !seeds)
+        return fail(ctx, MLD_ERR_INVALID_ARG, "bad slot count / null arrays");
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    const mld_params& P = ctx->P;
+    if (!P.do_use_ransac_plane) return set_clouds_common(ctx, n_slots, pts_dev, n, stride_bytes, nullptr, nullptr);
+    const int n_draws = P.ransac_plane_max_iterations + 1;
+    if (n_draws < 1) return fail(ctx, MLD_ERR_INVALID_ARG, "ransac_plane_max_iterations must be >= 0");
+    if (P.ransac_plane_min_z > -1001.) {
+        // z pass-through (RansacPlane.cpp:57-64): ordered compaction of the whole cloud, per-slot path
+        if ((rc = set_clouds_common(ctx, n_slots, pts_dev, n, stride_bytes, nullptr, nullptr))) return rc;
+        for (int i = 0; i < n_slots; i++) {
+            rc = mld_estimate_ground_plane(ctx, i, seeds[i], nullptr, nullptr);
+            if (rc == MLD_ERR_CLOUD_TOO_SMALL) {  // the frame goes on without a plane (the caller's catch, :321,338)
+                clear_plane(ctx->slots[i]);
+                rc = MLD_OK;
+            }
+            if (rc) return rc;
+        }
+        return MLD_OK;
+    }
+    int64_t max_n = 0;
+    for (int i = 0; i < n_slots; i++) max_n = std::max(max_n, n[i]);
+    const size_t words = (size_t)((max_n + 31) / 32) + 1;
+    if (!ctx->rsb_planes || words > ctx->rsb_mask_words) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->rsb_masks) HIP_TRY(ctx, hipFree(ctx->rsb_masks));
+        ctx->rsb_masks = nullptr;
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_masks, words * ctx->slots.size() * sizeof(uint32_t)));
+        ctx->rsb_mask_words = words;
+        if (!ctx->rsb_planes) {
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_planes, ctx->slots.size() * sizeof(PlaneDev)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_seeds, ctx->slots.size() * sizeof(uint32_t)));
+            const size_t lds = (size_t)kSample * 4 * sizeof(float) + (size_t)kPartials * 9 * sizeof(float) +
+                               (2 * kRsRound + 8) * sizeof(int);
+            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_batch),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+    }
+    // occupancy bitmaps and inlier masks of the batch: one fill each
+    HIP_TRY(ctx, hipMemsetAsync(ctx->bitmaps, 0, ctx->bitmap_words * (size_t)n_slots * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->rsb_masks, 0, ctx->rsb_mask_words * (size_t)n_slots * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->rsb_seeds, seeds, (size_t)n_slots * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    for (int i = 0; i < n_slots; i++) {
+        Slot& s = ctx->slots[i];
+        if ((rc = begin_cloud(ctx, s, pts_dev[i], n[i], stride_bytes, false))) return rc;
+        s.d.inlier_mask = ctx->rsb_masks + (size_t)i * ctx->rsb_mask_words;
+        s.d.mask_in_key = 1;
+        s.d.plane_dev = ctx->rsb_planes + i;
+        s.d.has_plane = 1;  // the device copy decides (PlaneDev::has_plane)
+        s.plane_decided = true;
+    }
+    if ((rc = upload_descs(ctx, n_slots))) return rc;
+    {
+        ScopedTimer tm(ctx, 4);
+        const size_t lds = (size_t)kSample * 4 * sizeof(float) + (size_t)kPartials * 9 * sizeof(float) +
+                           (2 * kRsRound + 8) * sizeof(int);
+        hipLaunchKernelGGL(k_rs_batch, dim3((unsigned)n_slots), dim3(kRsThreads), lds, ctx->stream, ctx->d_slots, ctx->rsb_seeds,
+                           n_draws, P.ransac_plane_max_iterations, P.ransac_plane_probability,
+                           P.ransac_plane_distance_treshold, P.ransac_plane_refinement_treshold,
+                           P.ransac_plane_use_refinement, ctx->rsb_planes);
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return launch_project(ctx, n_slots, max_n, false, 0);
+}
+
+// The planes of the last mld_set_clouds_estimate_planes_device: coefficients (n_slots x 4), inlier counts and status
+// (0 ok, 1 = GroundPlane::ExceptionPclInvalid: that frame runs without the road fallback).  Synchronises.
+int mld_get_estimated_planes(mld_ctx* ctx, int n_slots, float* coeffs_out, int64_t* n_inliers_out, int32_t* status_out) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    if (n_slots < 1 || n_slots > (int)ctx->slots.size()) return fail(ctx, MLD_ERR_INVALID_ARG, "bad slot count");
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    if (!ctx->rsb_planes) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "no batched plane estimation has run");
+    std::vector<PlaneDev> h((size_t)n_slots);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->rsb_planes, h.size() * sizeof(PlaneDev), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_slots; i++) {
+        const bool on_dev = ctx->slots[i].d.plane_dev != nullptr;
+        if (coeffs_out)
+            for (int t = 0; t < 4; t++) coeffs_out[4 * i + t] = on_dev ? h[i].coeffs[t] : ctx->slots[i].d.coeffs[t];
+        if (n_inliers_out) n_inliers_out[i] = on_dev ? h[i].n_inliers : -1;
+        if (status_out) status_out[i] = on_dev ? h[i].status : (ctx->slots[i].d.has_plane ? 0 : 1);
+    }
+    return MLD_OK;
 }
 
 // ---------------------------------------------------------------------------- ground plane

@@ -56,6 +56,17 @@ struct Calib {
     int threadPath;  // 1: thread-per-feature fast path with wave-cooperative overflow; 0: wave path only
 };
 
+// A ground plane estimated on the device (batched RANSAC): what set_plane_coeffs() computes on the host, left in device
+// memory so that no host round trip separates the estimation from the kernels that use it.
+struct PlaneDev {
+    double prior_n[3];
+    double prior_off;
+    float coeffs[4];
+    int has_plane;   // 0: the estimation failed (GroundPlane::ExceptionPclInvalid): the road fallback is off for the frame
+    int status;      // 0 ok, 1 too few points / no model
+    int n_inliers, iterations, best_draw, best_count, S, pad_;
+};
+
 // Per-frame-slot descriptor (device-resident array, or passed by value for single-slot calls).
 struct SlotDesc {
     const unsigned char* cloud;   // float32 records, `stride` bytes apart (x,y,z first)
@@ -71,6 +82,7 @@ struct SlotDesc {
     int32_t* live_count;          // their number
     double* corners;              // debug mode only: 9 x F triangle corners (NaN = none), written by k_feature_wave
     const long long* F_dev;       // optional device-side feature count (<= F); used when the count is produced on the GPU
+    const PlaneDev* plane_dev;    // optional: the slot's plane lives in device memory (overrides the plane fields below)
     long long n;                  // points
     long long F;                  // features
     double prior_n[3];            // M-estimator prior (normalised lidar-frame normal, DepthEstimator.cpp:286-292)

@@ -161,6 +161,22 @@ __device__ __forceinline__ V3 vcross(V3 a, V3 b) {
     return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 
+// A plane estimated on the device overrides the descriptor's host-side plane fields (wave-uniform scalar loads).
+__device__ __forceinline__ void apply_plane_dev(SlotDesc& s) {
+    if (s.plane_dev) {
+        const auto* p = GPTR(PlaneDev, s.plane_dev);
+        s.has_plane = p->has_plane;
+        s.prior_n[0] = p->prior_n[0];
+        s.prior_n[1] = p->prior_n[1];
+        s.prior_n[2] = p->prior_n[2];
+        s.prior_off = p->prior_off;
+        s.coeffs[0] = p->coeffs[0];
+        s.coeffs[1] = p->coeffs[1];
+        s.coeffs[2] = p->coeffs[2];
+        s.coeffs[3] = p->coeffs[3];
+    }
+}
+
 // Raw float point -> camera frame (DepthEstimator.cpp:169,173).
 __device__ __forceinline__ void load_point(const SlotDesc& s, long long i, double& x, double& y, double& z) {
     const unsigned char* p = s.cloud + (size_t)i * (size_t)s.stride;
@@ -1836,6 +1852,7 @@ __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restri
     int slot, j;
     decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
     SlotDesc s = use_single ? single : slots[slot];
+    apply_plane_dev(s);
     if (tag_all) s.tag = tag_all;
     if (!s.ovf_count) return;
     const int count = *GPTR(int32_t, s.ovf_count);
@@ -1930,6 +1947,7 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
     int* ctr = wsum + kClsThreads / kWave;              // [0] overflow-queue cursor
     uint32_t* lbm = reinterpret_cast<uint32_t*>(ctr + 4);  // staged bitmap
     SlotDesc s = use_single ? single : slots[blockIdx.x];
+    apply_plane_dev(s);
     long long Fn = s.F;
     if (s.F_dev) {
         const long long fd = *GPTR(long long, s.F_dev);
@@ -2213,6 +2231,7 @@ __global__ __launch_bounds__(kWave, MLD_FUSED_WAVES) void k_feature_fused(const 
         int slot, j;
         decode_block(w, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
         SlotDesc s = use_single ? single : slots[slot];
+        apply_plane_dev(s);
         if (tag_all) s.tag = tag_all;
         const int count = *GPTR(int32_t, s.live_count);
         const int e0 = j * kWave;

@@ -312,13 +312,218 @@ __global__ __launch_bounds__(kPartials) void k_rs_refine(const float* __restrict
     for (int j = tid; j < S; j += kPartials) {
         if (valid && ((double)plane_dist(rm, sp + 3 * j) < sel_thr)) {
             const int32_t id = sample_idx[j];
-            atomicOr(&mask[id >> 5], 1u << (id & 31));
-            cnt++;
+            const uint32_t bit = 1u << (id & 31);
+            cnt += (atomicOr(&mask[id >> 5], bit) & bit) ? 0 : 1;  // a stratified sample may name a point twice
         }
     }
     atomicAdd(&total_s, cnt);
     __syncthreads();
     if (tid == 0) res->n_inliers = total_s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched, asynchronous form: ONE block per frame slot runs the whole estimator — stratified sample gathered into LDS,
+// hypotheses in rounds of 16 (one wavefront each) with PCL's sequential stopping rule replayed after every round,
+// refinement, inlier bitmask — and leaves the plane in device memory (PlaneDev) where the feature kernels read it.
+// No host round trip.  Arithmetic and association orders are those of the single-slot kernels above (bit-identical
+// results).  The z pass-through (:57-64) needs an ordered compaction of the whole cloud and is not part of this form:
+// the host falls back to the per-slot path when it is enabled.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRsThreads = 1024;
+constexpr int kRsRound = kRsThreads / kWave;  // hypotheses evaluated per round
+
+__device__ inline long long sample_pos(long long M, int j, uint32_t seed) {
+    long long pos = j;
+    if (M > kSample) {
+        double u = (double)mix(seed, (uint32_t)j, 0x5A17u) * (1.0 / 4294967296.0);
+        pos = (long long)(((double)j + u) * (double)M / (double)kSample);
+        if (pos > M - 1) pos = M - 1;
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restrict__ slots, const uint32_t* __restrict__ seeds,
+                                                        int n_draws, int max_it, double probability, double thr,
+                                                        double refine_thr, int use_refinement, PlaneDev* out) {
+    extern __shared__ __align__(16) unsigned char rs_smem[];
+    float* sp = reinterpret_cast<float*>(rs_smem);                 // [3 * kSample]
+    int* inl_pos = reinterpret_cast<int*>(sp + 3 * kSample);       // [kSample]
+    float* acc = reinterpret_cast<float*>(inl_pos + kSample);      // [kPartials * 9]
+    int* counts = reinterpret_cast<int*>(acc + kPartials * 9);     // [kRsRound]
+    int* wsum = counts + kRsRound;                                 // [kRsRound]
+    int* misc = wsum + kRsRound;                                   // [0] running offset, [1] inlier total
+    const SlotDesc s = slots[blockIdx.x];
+    PlaneDev* pd = out + blockIdx.x;
+    const uint32_t seed = seeds[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid >> 6;
+    const long long M = s.n;
+    const int S = M > kSample ? kSample : (int)M;
+    auto fail = [&]() {
+        if (tid == 0) {
+            pd->has_plane = 0;
+            pd->status = 1;
+            pd->n_inliers = 0;
+            pd->S = S;
+        }
+    };
+    if (M < 3) {  // RansacPlane.cpp:44-50
+        fail();
+        return;
+    }
+    for (int j = tid; j < S; j += kRsThreads) {
+        const float* p = reinterpret_cast<const float*>(s.cloud + (size_t)sample_pos(M, j, seed) * (size_t)s.stride);
+        sp[3 * j] = p[0];
+        sp[3 * j + 1] = p[1];
+        sp[3 * j + 2] = p[2];
+    }
+    if (tid == 0) {
+        misc[0] = 0;
+        misc[1] = 0;
+    }
+    __syncthreads();
+    // ---- hypotheses, rounds of kRsRound; the replay below is executed by every thread on the same data ----
+    int iterations = 0, best = -2147483647, best_draw = -1;
+    double k = 1.0;
+    const double log_probability = log(1.0 - probability);
+    const double one_over = 1.0 / (double)S;
+    bool done = false;
+    for (int d0 = 0; d0 < n_draws && !done; d0 += kRsRound) {
+        const int d = d0 + w;
+        int cnt = 0;
+        bool degenerate = false;
+        if (d < n_draws) {
+            const Model m = draw_model(sp, S, seed, d);
+            degenerate = m.degenerate != 0;
+            if (m.valid)
+                for (int j = lane; j < S; j += kWave)
+                    if ((double)plane_dist(m.c, sp + 3 * j) < thr) cnt++;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        if (lane == 0) counts[w] = degenerate ? -1 : cnt;
+        __syncthreads();
+        for (int q = 0; q < kRsRound; q++) {  // ransac.hpp computeModel, as k_rs_select
+            if (d0 + q >= n_draws || !((double)iterations < k)) {
+                done = true;
+                break;
+            }
+            const int c = counts[q];
+            if (c < 0) continue;  // skipped draw
+            if (c > best) {
+                best = c;
+                best_draw = d0 + q;
+                const double wr = (double)best * one_over;
+                double p_no = 1.0 - wr * wr * wr;
+                p_no = fmax(2.220446049250313e-16, p_no);
+                p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
+                k = log_probability / log(p_no);
+            }
+            ++iterations;
+            if (iterations > max_it) {
+                done = true;
+                break;
+            }
+        }
+        __syncthreads();
+    }
+    if (best_draw < 0) {
+        fail();
+        return;
+    }
+    const Model bm = draw_model(sp, S, seed, best_draw);
+    const float rm[4] = {bm.c[0], bm.c[1], bm.c[2], bm.c[3]};
+    float coeffs[4] = {rm[0], rm[1], rm[2], rm[3]};
+    const bool valid = fabs((double)rm[2]) >= 0.984807753012208;
+    // ---- ordered list of the RANSAC inliers (positions in the sample), as k_rs_refine ----
+    for (int c0 = 0; c0 < S; c0 += kRsThreads) {
+        const int j = c0 + tid;
+        const bool in = (j < S) && valid && ((double)plane_dist(rm, sp + 3 * j) < thr);
+        const unsigned long long m = __ballot(in);
+        if (lane == 0) wsum[w] = __popcll(m);
+        __syncthreads();
+        int off = misc[0];
+        for (int q = 0; q < w; q++) off += wsum[q];
+        if (in) inl_pos[off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = j;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int q = 0; q < kRsRound; q++) t += wsum[q];
+            misc[0] += t;
+        }
+        __syncthreads();
+    }
+    const int ni = misc[0];
+    if (use_refinement && ni > 3) {
+        if (tid < kPartials) {  // thread p owns inliers p, p + 256, ...: the association of the single-slot kernel
+            float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int q = tid; q < ni; q += kPartials) {
+                const float* v = sp + 3 * inl_pos[q];
+                a[0] += v[0] * v[0];
+                a[1] += v[0] * v[1];
+                a[2] += v[0] * v[2];
+                a[3] += v[1] * v[1];
+                a[4] += v[1] * v[2];
+                a[5] += v[2] * v[2];
+                a[6] += v[0];
+                a[7] += v[1];
+                a[8] += v[2];
+            }
+            for (int t = 0; t < 9; t++) acc[tid * 9 + t] = a[t];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float s9[9];
+            for (int t = 0; t < 9; t++) {
+                float sum = 0.0f;
+                for (int p = 0; p < kPartials; p++) sum += acc[p * 9 + t];
+                s9[t] = sum / (float)ni;
+            }
+            float cov[6] = {s9[0] - s9[6] * s9[6], s9[1] - s9[6] * s9[7], s9[2] - s9[6] * s9[8],
+                            s9[3] - s9[7] * s9[7], s9[4] - s9[7] * s9[8], s9[5] - s9[8] * s9[8]};
+            double sd[6] = {cov[0], cov[1], cov[2], cov[3], cov[4], cov[5]}, n0[3];
+            rs_smallest_eigvec(sd, n0);
+            const float e0 = (float)n0[0], e1 = (float)n0[1], e2 = (float)n0[2];
+            coeffs[0] = e0;
+            coeffs[1] = e1;
+            coeffs[2] = e2;
+            coeffs[3] = -1.0f * (e0 * s9[6] + e1 * s9[7] + e2 * s9[8]);
+        }
+    }
+    // ---- final inlier set (bitmask keyed by original index; the host cleared it before the launch) ----
+    const double sel_thr = use_refinement ? refine_thr : thr;
+    int cnt = 0;
+    for (int j = tid; j < S; j += kRsThreads) {
+        if (valid && ((double)plane_dist(rm, sp + 3 * j) < sel_thr)) {
+            const uint32_t id = (uint32_t)sample_pos(M, j, seed);
+            const uint32_t bit = 1u << (id & 31);
+            cnt += (atomicOr(const_cast<uint32_t*>(s.inlier_mask) + (id >> 5), bit) & bit) ? 0 : 1;  // duplicates count once
+        }
+    }
+    atomicAdd(&misc[1], cnt);
+    __syncthreads();
+    if (tid == 0) {
+        // the plane as the feature kernels consume it: coefficients + M-estimator prior (DepthEstimator.cpp:286-292)
+        for (int t = 0; t < 4; t++) pd->coeffs[t] = coeffs[t];
+        double a = (double)coeffs[0], b = (double)coeffs[1], cc = (double)coeffs[2];
+        const double z = a * a + (b * b + cc * cc);
+        if (z > 0.0) {
+            const double nrm = sqrt(z);
+            a /= nrm;
+            b /= nrm;
+            cc /= nrm;
+        }
+        pd->prior_n[0] = a;
+        pd->prior_n[1] = b;
+        pd->prior_n[2] = cc;
+        pd->prior_off = (double)coeffs[3];
+        pd->n_inliers = misc[1];
+        pd->iterations = iterations;
+        pd->best_draw = best_draw;
+        pd->best_count = best;
+        pd->S = S;
+        pd->status = 0;
+        pd->has_plane = 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -396,6 +396,34 @@ class DepthEstimator:
         self._after_torch(*clouds[:1])
         self._check(self._lib.mld_set_clouds_device(self._ctx, n_slots, ptrs, counts, stride_bytes))
 
+    def setInputCloudsEstimatePlanes(self, clouds: Sequence, seeds: Sequence[int], stride_bytes: int = 16):
+        """Batched setInputCloud(cloud, RansacPlane()) — the reference's default call with a plane that is not segmented
+        yet (DepthEstimator.cpp:275-283): the ground plane of every slot is estimated on the GPU ahead of the projection,
+        asynchronously; nothing returns to the host (mld_set_clouds_estimate_planes_device)."""
+        self._require_init("setInputCloud")
+        n_slots = len(clouds)
+        ptrs = (C.c_void_p * n_slots)()
+        counts = (C.c_int64 * n_slots)()
+        for i, cl in enumerate(clouds):
+            p, n, stride, keep = self._cloud_view(cl)
+            if stride != stride_bytes or not _is_torch_cuda(cl):
+                raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "needs CUDA clouds of one stride")
+            ptrs[i], counts[i] = p, n
+            self._keepalive[("cloud", i)] = keep
+        sd = (C.c_uint32 * n_slots)(*[int(x) & 0xFFFFFFFF for x in seeds])
+        self._after_torch(*clouds[:1])
+        self._check(self._lib.mld_set_clouds_estimate_planes_device(self._ctx, n_slots, ptrs, counts, stride_bytes, sd))
+
+    def getEstimatedPlanes(self, n_slots: int):
+        """(coefficients [n,4] float32, inlier counts, status 0 ok / 1 failed) of the last batched estimation."""
+        co = np.empty((n_slots, 4), dtype=np.float32)
+        ni = np.empty(n_slots, dtype=np.int64)
+        st = np.empty(n_slots, dtype=np.int32)
+        self._check(self._lib.mld_get_estimated_planes(self._ctx, n_slots, co.ctypes.data_as(C.POINTER(C.c_float)),
+                                                       ni.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                       st.ctypes.data_as(C.POINTER(C.c_int32))))
+        return co, ni, st
+
     # ------------------------------------------------------------------ CalculateDepth
     def CalculateDepth(self, *args, slot: int = 0, return_types: bool = True, uv_layout: Optional[str] = None):
         """The reference's overloads (DepthEstimator.cpp:404-488):

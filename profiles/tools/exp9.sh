@@ -10,7 +10,7 @@ r=d['roofline']
 print('value', round(d['value']/1e6,1), 'ms/step', round(d['ms_per_step'],4), 'verified', d['verified'], d['verification'])
 print('roofline', {k:(round(v,4) if isinstance(v,float) else v) for k,v in r.items() if k not in ('kernels','traffic_profile')})
 print('kernels', json.dumps(r['kernels'])[:1500])
-print('cpu', d['cpu_baseline'] and round(d['cpu_baseline']['value']/1e6,2), 'latency', d['latency'] and d['latency']['ms_per_frame_median'], 'streaming', d['streaming'] and round(d['streaming']['frames_per_s']))
+print('estimated', d.get('plane_estimated')); print('cpu', d['cpu_baseline'] and round(d['cpu_baseline']['value']/1e6,2), 'latency', d['latency'] and d['latency']['ms_per_frame_median'], 'streaming', d['streaming'] and round(d['streaming']['frames_per_s']))
 print('config3', json.dumps(d['configs'].get('3'))[:2500])
 print('config5', json.dumps(d['configs'].get('5'))[:2500])
 PY

@@ -118,3 +118,52 @@ def test_no_horizontal_plane_in_the_cloud():
     d0, t0 = ref.calculate_depth(uv)
     assert_depth_parity(d, t, d0, t0)
     assert (t != 16).all()
+
+
+@pytest.mark.gpu
+def test_batched_estimation_every_slot_equals_the_restatement():
+    """mld_set_clouds_estimate_planes_device: 16 slots, one launch, no host round trip.  Every slot's coefficients and
+    inlier set are bit-identical to the CPU restatement run with the same seed, and the depths computed with the
+    estimated planes agree with the oracle end to end (inlier flags ride in the map keys)."""
+    import torch
+    P = capi.params_c0()
+    B, F = 16, 600
+    est = make_estimator(P, max_frames=B, max_features=F)
+    dev = torch.device("cuda:0")
+    scanners = [synth.HDL64_KITTI, synth.HDL64, synth.VLP16]
+    clouds = [synth.make_cloud(scanners[b % 3], seed=30 + b % 5, frame=b) for b in range(B)]
+    clouds[7] = clouds[7][:2].copy()  # fewer than three points: ExceptionPclInvalid -> that frame runs without a plane
+    seeds = [1000 + 17 * b for b in range(B)]
+    uvs = [synth.make_features(F, seed=40 + b) for b in range(B)]
+    t_clouds = [torch.from_numpy(c).to(dev) for c in clouds]
+    t_uvs = [torch.from_numpy(u).to(dev) for u in uvs]
+    d = [torch.empty(F, dtype=torch.float64, device=dev) for _ in range(B)]
+    t = [torch.empty(F, dtype=torch.int32, device=dev) for _ in range(B)]
+    torch.cuda.synchronize()
+    est.setInputCloudsEstimatePlanes(t_clouds, seeds)
+    est.CalculateDepths(t_uvs, d, t)
+    est.synchronize()
+    coeffs, n_inl, status = est.getEstimatedPlanes(B)
+    for b in range(B):
+        ref = make_oracle(P)
+        ref.set_cloud(clouds[b])
+        if b == 7:
+            assert status[b] == 1
+            ref.set_ground_plane(None, None)
+        else:
+            c0, inl0 = ref.estimate_ground_plane(seeds[b])
+            assert status[b] == 0
+            assert np.array_equal(coeffs[b], c0), b
+            assert np.array_equal(est.getGroundPlaneInliers(b), inl0), b
+            assert n_inl[b] == inl0.size
+        d0, t0 = ref.calculate_depth(uvs[b])
+        assert_depth_parity(d[b].cpu().numpy(), t[b].cpu().numpy(), d0, t0)
+    # the reference's own tolerance test on the same entry point (test_monolidar_fusion.cpp:376-441)
+    P2 = capi.params_c0().replace(**{k: v for k, v in REF_TEST_PARAMS.items() if not k.endswith("_z")})
+    e2 = make_estimator(P2, max_frames=2)
+    cl = torch.from_numpy(_reference_test_cloud()).to(dev)
+    e2.setInputCloudsEstimatePlanes([cl, cl], [3, 4])
+    co2, _, st2 = e2.getEstimatedPlanes(2)
+    assert (st2 == 0).all()
+    _check_truth(co2[0])
+    _check_truth(co2[1])
