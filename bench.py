@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--streaming-frames", type=int, default=64, help="frames per batch of the streaming leg")
     ap.add_argument("--config-frames", type=int, default=256,
                     help="resident frames of the config-3 leg / sequence length of the config-5 leg (0 = skip both)")
+    ap.add_argument("--only-config", type=int, default=0, choices=[0, 3, 5],
+                    help="run only that BASELINE config's leg and print its object (for per-config rocprofv3 runs)")
     ap.add_argument("--verify-slots", type=int, default=4, help="slots of the timed batch checked against the oracle")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-every", type=int, default=4,
@@ -573,6 +575,12 @@ def main():
     P, cam_struct, T = sharding.broadcast_calibration(P, cam_struct, T, device=coll_dev)
     cam = CameraPinhole(cam_struct.width, cam_struct.height, cam_struct.focal_length, cam_struct.principal_point_x,
                         cam_struct.principal_point_y)
+
+    if args.only_config:
+        leg = (config3_leg(cam, T, gpu_index, args.config_frames) if args.only_config == 3
+               else config5_leg(cam, T, gpu_index, min(args.config_frames, 200)))
+        print(json.dumps({"config": str(args.only_config), **leg}), flush=True)
+        sys.exit(0 if leg.get("verified") else 1)
 
     # ---- this rank's sequence, resident in HBM ------------------------------------------------------------
     B, F = args.frames_per_step, args.features

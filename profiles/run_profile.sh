@@ -1,17 +1,26 @@
 #!/bin/bash
 # Profiles bench.py under rocprofv3 on the GPU box (invoke through gpurun from the repo root):
-#   gpurun -- 'bash profiles/run_profile.sh r1'
-# Writes raw output under gpurun_out/prof_<tag>/; copy the summaries worth keeping into profiles/.
-TAG=${1:-r1}
+#   gpurun -- 'bash profiles/run_profile.sh r2'
+# Writes raw output under gpurun_out/prof_<tag>/; profiles/summarize.py condenses it into profiles/<tag>_*.
+TAG=${1:-r2}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 3 --cpu-seconds 0 --latency-frames 0 --streaming-batches 0"
+COMMON="--cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0"
+ARGS="--steps 20 --warmup 3 $COMMON"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
-PMCARGS="--steps 4 --warmup 1 --cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --no-kernel-timing"
+PMCARGS="--steps 4 --warmup 1 $COMMON --no-kernel-timing"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_sq.json 2> $OUT/pmc_sq.log
-find $OUT -name "*.csv" | head -50
-for f in $(find $OUT/trace -name "*kernel_stats.csv"); do echo "== $f"; cat $f; done
+# the other single-GPU BASELINE configs, one leg per run
+for c in 3 5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c$c -- python3 $REPO/bench.py --only-config $c > $OUT/bench_c$c.json 2> $OUT/trace_c$c.log
+done
+cd $REPO
+python3 profiles/summarize.py $TAG > $OUT/summary.log 2>&1
+python3 profiles/summarize_config.py $TAG 3 >> $OUT/summary.log 2>&1
+python3 profiles/summarize_config.py $TAG 5 >> $OUT/summary.log 2>&1
+mkdir -p $OUT/keep && cp profiles/${TAG}_*.md profiles/${TAG}_*.csv profiles/traffic.json $OUT/keep/ 2>/dev/null
+tail -40 $OUT/summary.log

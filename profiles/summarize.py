@@ -7,7 +7,7 @@ import sys
 
 import pandas as pd
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 src = f"gpurun_out/prof_{tag}"
 import os
 
@@ -21,7 +21,8 @@ stats = newest(f"{src}/trace/*/*kernel_stats.csv")
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 lines = [f"# rocprofv3 summary — {tag}", "",
          "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 "
-         "--cpu-seconds 0 --latency-frames 0 --streaming-batches 0` (see profiles/run_profile.sh); PMC passes are separate runs with `--pmc`.", ""]
+         "--cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0` (see profiles/run_profile.sh); PMC "
+         "passes are separate runs of the same command with `--pmc` (4 steps).", ""]
 ks = pd.read_csv(stats)
 ks = ks[ks.Name.str.contains("mld::")]
 lines += ["## kernel-trace --stats", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
@@ -32,7 +33,9 @@ try:
     b = json.loads(open(f"{src}/bench_trace.json").read().strip().splitlines()[-1])
     rk = b["roofline"]["kernels"]
     lines += ["", "bench.py hipEvent averages in the same run: " +
-              ", ".join(f"`{k}` {v['avg_ms'] * 1e3:.1f} us" for k, v in rk.items()), ""]
+              ", ".join(f"`{k}` {v.get('avg_ms', 0) * 1e3:.1f} us" for k, v in rk.items()), ""]
+    lines += [f"bench.py line of that run: value {b['value'] / 1e9:.3f} G associations/s, ms_per_step {b['ms_per_step']:.4f}, "
+              f"verified {b['verified']}, roofline.frac {b['roofline']['frac']:.3f} ({b['roofline']['kernel']})", ""]
 except Exception as e:  # noqa: BLE001
     lines += ["", f"(bench json not parsed: {e})", ""]
 lines += ["## PMC (per launch, mean over launches)", "",
@@ -46,7 +49,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
     if not f_:
         continue
     df = pd.read_csv(f_)
-    df = df[df.Kernel_Name.str.contains("k_feature_main|k_feature_depth|k_project_scatter|k_feature_road|k_feature_wave|k_sort_features")]
+    df = df[df.Kernel_Name.str.contains("k_project_scatter|k_classify|k_feature_fused|k_feature_wave|k_rs_batch")]
     df["k"] = df.Kernel_Name.str.extract(r"(k_\w+)")
     g = df.groupby(["k", "Counter_Name"]).Counter_Value.mean()
     for (k, c), v in g.items():
@@ -54,7 +57,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
         lines.append(f"| `{k}` | {c} | {v:,.1f} |")
 lines += ["", "## derived", ""]
 traffic = {}
-for k in ("k_project_scatter", "k_feature_main", "k_feature_road"):
+for k in ("k_project_scatter", "k_classify", "k_feature_fused"):
     if (k, "FETCH_SIZE") in rows and (k, "WRITE_SIZE") in rows:
         f, w = rows[(k, "FETCH_SIZE")] * 1024, rows[(k, "WRITE_SIZE")] * 1024
         fc = 2 * f if k == "k_project_scatter" else f
