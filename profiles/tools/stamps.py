@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 import resident  # noqa: E402
 
-NAMES = {0: "prologue", 1: "perm+uv", 2: "bitmap loads", 3: "bit loop", 4: "key loads", 5: "deal+barriers",
+NAMES = {0: "prologue", 1: "queue+uv", 2: "bitmap loads", 3: "bit walk / counts", 4: "cell+key loads", 5: "narrow list",
          6: "dead stores+enqueue", 7: "info+uv reload", 8: "pass1: point loads", 9: "hist rest", 10: "triangle",
          11: "tail", 12: "stores+enqueue"}
 w = resident.build(B=int(sys.argv[1]) if len(sys.argv) > 1 else 1024)
