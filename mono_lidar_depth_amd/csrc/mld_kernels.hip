@@ -225,7 +225,10 @@ __device__ __forceinline__ void project(const Calib& c, V3 p, double& u, double&
 // K1: projection + pixel-map scatter
 // ------------------------------------------------------------------------------------------------
 constexpr int kProjThreads = 256;
-constexpr int kProjPerThread = 4;
+#ifndef MLD_PROJ_PER_THREAD
+#define MLD_PROJ_PER_THREAD 4
+#endif
+constexpr int kProjPerThread = MLD_PROJ_PER_THREAD;
 
 // tag_all != 0: every slot of the batch carries this map tag (the per-slot tag of the descriptor array is then not
 // kept up to date, which lets steady-state batches run without re-uploading the descriptors).
@@ -303,8 +306,12 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
             uint32_t inl = 0u;
             if (s.mask_in_key) inl = (GPTR(uint32_t, s.inlier_mask)[(size_t)i >> 5] >> ((uint32_t)i & 31u)) & 1u;
             const uint32_t key = make_key(s.tag, (uint32_t)i, inl);
+#ifndef MLD_DBG_NOMAPATOMIC
             __hip_atomic_fetch_max(GPTRW(uint32_t, s.map) + ((size_t)xi + (size_t)yi * (size_t)c.W), key,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+            if (key == 0x12345u) GPTRW(uint32_t, s.map)[0] = key;  // timing experiment only
+#endif
             bmw[r] = (xi >> 5) * c.bmStride + yi;
             bmb[r] = 1u << (xi & 31);
         }
@@ -1222,7 +1229,10 @@ constexpr int kK1MaxLimit = 64;  // upper bound of Calib::k1max, the per-feature
                                  // (LDS: k1max entries x 64 lanes x 4 B per wave; relative bins need k1max < 254)
 constexpr int kK2Max = 16;  // longest list the per-thread O(n^2) triangle search accepts
 constexpr int kTriSmall = 8;
-constexpr int kZc = 12;      // list entries whose depth stays in registers over the histogram passes
+#ifndef MLD_KZC
+#define MLD_KZC 12
+#endif
+constexpr int kZc = MLD_KZC;      // list entries whose depth stays in registers over the histogram passes
 #ifndef MLD_KEY_BATCH
 #define MLD_KEY_BATCH 4
 #endif
@@ -2022,6 +2032,15 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
                 if (window_bounds(c, u, v, c.halfX2, c.halfY2, a0, a1, anx, any_) && anx > 32) return CLS_OVF;
             }
             k1 = count_window(x0, y0, nx, ny);
+            // Lists beyond the fused kernel's capacities go straight to the wave kernel (dense clouds: every feature):
+            // the narrow count is known; the scanned (road) window holds ~2.6x as many cells, so it is counted only
+            // when the narrow one is already long.
+            if (k1 > c.kMain) return CLS_OVF;
+            if (road_on && 3 * k1 > c.k1max) {
+                int a0, a1, anx, any_;
+                if (window_bounds(c, u, v, c.halfX2, c.halfY2, a0, a1, anx, any_) && count_window(a0, a1, anx, any_) > c.k1max)
+                    return CLS_OVF;
+            }
         }
         if ((unsigned)k1 < c.countMin) return CLS_DEAD;
         int b = 0;
