@@ -85,6 +85,7 @@ struct mld_ctx {
     size_t lds_classify = 0;  // k_classify: bucket counters + the slot's bitmap
     bool classify_staged = true;  // the bitmap fits the LDS budget of k_classify
     int bm_ncol = 0, bm_ncolp = 0;  // bitmap word columns (incl. the slack column) / padded LDS row length
+    bool force_thread_path = false;  // test build only: single-slot calls use the lane-per-feature kernel too
     std::string err;
     // ground-plane estimation scratch (device)
     int32_t* rs_flags = nullptr;
@@ -275,9 +276,12 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
 #ifdef MLD_AB_SWITCHES
     // Test / measurement build only (libmld_hip_ab.so): the shipped library has one code path and reads no environment.
     //   MLD_FORCE_WAVE_PATH=1  every feature through the wave-cooperative kernel (the parity suite runs both paths)
+    //   MLD_FORCE_THREAD_PATH=1  single-frame calls through the lane-per-feature kernel as well (they default to the
+    //                            wave-cooperative one: launch_features)
     //   MLD_NO_XCD=1           plain block -> slot mapping        MLD_K1MAX / MLD_KMAIN   list capacities
     if (const char* e = std::getenv("MLD_FORCE_WAVE_PATH")) c.threadPath = (e[0] == '1') ? 0 : 1;
     if (const char* e = std::getenv("MLD_NO_XCD")) c.xcdAware = (e[0] == '1') ? 0 : 1;
+    if (const char* e = std::getenv("MLD_FORCE_THREAD_PATH")) ctx->force_thread_path = e[0] == '1';
     if (const char* e = std::getenv("MLD_K1MAX")) c.k1max = std::min(std::max(std::atoi(e), 8), kK1MaxLimit);
     if (const char* e = std::getenv("MLD_KMAIN")) c.kMain = std::min(std::max(std::atoi(e), 8), c.k1max);
 #endif
@@ -423,7 +427,12 @@ int ensure_queues(mld_ctx* ctx, Slot& s, int64_t F) {
 // k_classify sets both queue lengths, so no counter needs clearing.
 int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int slot, const Calib* override_calib = nullptr) {
     if (max_F <= 0) return MLD_OK;
-    const Calib& calib = override_calib ? *override_calib : ctx->calib;
+    Calib calib = override_calib ? *override_calib : ctx->calib;
+    // ONE frame per call (the ROS usage, the tracklet path): too few wavefronts for the lane-per-feature kernel to be
+    // anything but one wavefront's lifetime (41 us for 2000 features); the wave-cooperative kernel, one feature per
+    // wavefront, finishes the frame in the time of its slowest feature.  k_classify still settles the dead features.
+    const bool few = single && max_F <= 16384 && !ctx->force_thread_path;
+    if (few) calib.threadPath = 0;
     const int per_slot = (int)((max_F + kWave - 1) / kWave);
     const uint32_t tag_all = single ? 0u : common_tag(ctx, n_slots);
     const SlotDesc one = single ? ctx->slots[slot].d : SlotDesc{};
@@ -442,9 +451,10 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     }
     {
         ScopedTimer tm(ctx, 3);
-        // eight queue entries per block and iteration; about 4096 blocks in all (the queues are empty for KITTI-like
-        // clouds and hold every feature for dense ones)
-        const int chunk = 8;
+        // queue entries per block and iteration: a wavefront works on ONE feature at a time.  Batches: eight, about
+        // 4096 blocks in all (the queues are empty for KITTI-like clouds and hold every feature for dense ones); a
+        // single frame: as few as keep the grid near 2048 blocks.
+        const int chunk = few ? (int)std::min<int64_t>(8, std::max<int64_t>(1, (max_F + 2047) / 2048)) : 8;
         const int want = (int)((max_F + chunk - 1) / chunk);
         const int pw = std::max(1, std::min(want, std::max(4, 4096 / ns)));
         hipLaunchKernelGGL(k_feature_wave, dim3((unsigned)pw * (unsigned)ns), dim3(kWave), ctx->lds_bytes, ctx->stream,

@@ -2022,11 +2022,14 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
     // (Sorting the live features by list length as well, so that the lanes of a wavefront iterate equally long, was
     // measured: the fused kernel gained what the extra counting cost here.)
     auto classify = [&](double u, double v) -> int {
-        if (!c.threadPath) return CLS_OVF;
         int x0, y0, nx, ny;
         int k1 = 0;
         if (window_bounds(c, u, v, c.halfX1, c.halfY1, x0, y0, nx, ny)) {
             if (nx > 32) return CLS_OVF;
+            if (!c.threadPath) {  // wave-only processing: dead features are still settled here
+                k1 = count_window(x0, y0, nx, ny);
+                return ((unsigned)k1 < c.countMin) ? (int)CLS_DEAD : (int)CLS_OVF;
+            }
             if (road_on) {
                 int a0, a1, anx, any_;
                 if (window_bounds(c, u, v, c.halfX2, c.halfY2, a0, a1, anx, any_) && anx > 32) return CLS_OVF;
@@ -2043,6 +2046,7 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
             }
         }
         if ((unsigned)k1 < c.countMin) return CLS_DEAD;
+        if (!c.threadPath) return CLS_OVF;
         int b = 0;
         if (v > 0.0) b = (v < (double)c.H) ? (int)(v * scale) : kClsBuckets - 1;
         return b < kClsBuckets ? b : kClsBuckets - 1;

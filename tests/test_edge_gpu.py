@@ -128,5 +128,11 @@ def test_many_features_in_one_call():
     sel = np.r_[0:700, 150000:150700, 299300:300000]
     _, (d0, t0) = run_oracle(P, cloud, uv[sel], plane, n_threads=8)
     assert_depth_parity(d[sel], t[sel], d0, t0)
+    # the same features in a small call: calls of up to 16 384 features run on the wave-cooperative kernel (one feature
+    # per wavefront), larger ones on the lane-per-feature kernel.  Result types and main-path depths are identical bit for
+    # bit; the road estimator's sums are associated differently in the two kernels (both within 1e-4 m of the oracle).
     d2, t2 = est.CalculateDepth(uv[sel])
-    assert np.array_equal(d2, d[sel]) and np.array_equal(t2, t[sel])
+    assert np.array_equal(t2, t[sel])
+    road = t2 == 16
+    assert np.array_equal(d2[~road], d[sel][~road])
+    assert np.abs(d2[road] - d[sel][road]).max() < 1e-9

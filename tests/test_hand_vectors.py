@@ -207,6 +207,7 @@ def test_E2_road_path_oracle():
 
 
 @pytest.mark.gpu
+@pytest.mark.usefixtures("feature_kernel_path")
 def test_E1_E2_hip_path():
     from mono_lidar_depth_amd import DepthEstimator
     cam = CameraPinhole(*CAM)

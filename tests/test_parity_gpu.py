@@ -6,19 +6,7 @@ from mono_lidar_depth_amd import NO_PLANE, GroundPlane, capi, synth
 
 from helpers import assert_depth_parity, kitti_camera, make_estimator, make_oracle, run_oracle
 
-pytestmark = pytest.mark.gpu
-
-
-@pytest.fixture(autouse=True, params=["fused", "wave-only"])
-def feature_kernel_path(request, monkeypatch):
-    """Every test runs both ways:
-    fused       k_classify + k_feature_fused + the long-list k_feature_wave: the shipped library (libmld_hip.so)
-    wave-only   every feature through the wave-cooperative kernel: the test build of the same sources
-                (libmld_hip_ab.so, -DMLD_AB_SWITCHES) with MLD_FORCE_WAVE_PATH=1, read by its mld_create"""
-    if request.param == "wave-only":
-        monkeypatch.setenv("MLD_FORCE_WAVE_PATH", "1")
-        monkeypatch.setattr(capi, "_lib", capi.load_ab())
-    yield request.param
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("feature_kernel_path")]
 
 
 def _frame(scanner, seed, nfeat, frame=0, integer=False, stride=4):

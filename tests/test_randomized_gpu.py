@@ -8,7 +8,7 @@ from mono_lidar_depth_amd import CameraPinhole, GroundPlane, capi, synth
 
 from helpers import assert_depth_parity, make_estimator, run_oracle
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("feature_kernel_path")]
 
 
 def _rot(rx, ry, rz):
