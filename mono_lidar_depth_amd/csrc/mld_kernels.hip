@@ -2088,15 +2088,13 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
         int k1 = 0;
         if (window_bounds(c, u, v, c.halfX1, c.halfY1, x0, y0, nx, ny)) {
             if (nx > 32) return CLS_OVF;
-            if (!c.threadPath) {  // wave-only processing: dead features are still settled here
-                k1 = count_window(x0, y0, nx, ny);
+            k1 = count_window(x0, y0, nx, ny);
+            if (!c.threadPath)  // wave-only processing: dead features are still settled here
                 return ((unsigned)k1 < c.countMin) ? (int)CLS_DEAD : (int)CLS_OVF;
-            }
             if (road_on) {
                 int a0, a1, anx, any_;
                 if (window_bounds(c, u, v, c.halfX2, c.halfY2, a0, a1, anx, any_) && anx > 32) return CLS_OVF;
             }
-            k1 = count_window(x0, y0, nx, ny);
             // Lists beyond the fused kernel's capacities go straight to the wave kernel (dense clouds: every feature):
             // the narrow count is known; the scanned (road) window holds ~2.6x as many cells, so it is counted only
             // when the narrow one is already long.
