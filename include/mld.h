@@ -164,6 +164,25 @@ void* mld_get_stream(mld_ctx* ctx);
 int mld_synchronize(mld_ctx* ctx);
 
 /*
+ * Two (or more) contexts on one GPU, used alternately ("double buffering"; DESIGN.md §3 "Two contexts side by side").
+ * The projection kernel streams the clouds from HBM and leaves most of a CU's issue slots idle; the feature kernels are
+ * the opposite (gather- and issue-bound, ~10 % of the HBM bandwidth).  Run beside each other they finish sooner than
+ * one after the other -- the reference has no counterpart: its stage A is serial and its feature loop is the only
+ * parallel part (DepthEstimator.cpp:156-217 vs :455).  Schedule per batch, contexts taken round-robin:
+ *     mld_set_clouds_*_device(ctx_k, ...);      projection of batch i on context k
+ *     mld_order_after(ctx_next, ctx_k);          the NEXT context's projection starts when this one is done ...
+ *     mld_calculate_depths_device(ctx_k, ...);   ... i.e. beside these feature kernels
+ *
+ * mld_order_after: everything submitted to `ctx` from now on starts after everything submitted to `other` so far has
+ *   finished (one event; no host synchronisation).  Both contexts must live on the same device.
+ * mld_set_shared_gpu(ctx, 1): the lane-per-feature kernel of `ctx` keeps to two wavefronts per SIMD (it requests more
+ *   LDS per block), which leaves registers for the other context's projection wavefronts on every CU.  A context that
+ *   has the GPU to itself is ~5 % slower in this mode; the alternating pair is ~12 % faster (bench.py default).
+ */
+int mld_order_after(mld_ctx* ctx, mld_ctx* other);
+int mld_set_shared_gpu(mld_ctx* ctx, int shared);
+
+/*
  * setInputCloud (DepthEstimator.cpp:220-312): projection + pixel->point map for one slot.
  *   pts: x,y,z[,..] float32 records, stride_bytes 16 (packed xyzi) or 32 (pcl::PointXYZI layout,
  *   DepthEstimator.cpp:169 reads rows 0-2 of the 8-float map).

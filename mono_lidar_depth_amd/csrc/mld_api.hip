@@ -129,6 +129,8 @@ struct mld_ctx {
     uint32_t* rsb_seeds = nullptr;
     hipStream_t side = nullptr;  // the plane's inlier mask is built here while the cloud is still in flight
     hipEvent_t side_done = nullptr;
+    hipEvent_t order_ev = nullptr;  // mld_order_after
+    size_t lds_fused_pad = 0;       // mld_set_shared_gpu
     bool timing = false;
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
@@ -446,7 +448,7 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     if (calib.threadPath) {
         ScopedTimer tm(ctx, 1);
         auto kf = calib.roadMode ? mld::k_feature_fused<1> : mld::k_feature_fused<0>;
-        hipLaunchKernelGGL(kf, dim3((unsigned)per_slot * (unsigned)ns), dim3(kWave), ctx->lds_fused, ctx->stream, ctx->d_slots,
+        hipLaunchKernelGGL(kf, dim3((unsigned)per_slot * (unsigned)ns), dim3(kWave), ctx->lds_fused + ctx->lds_fused_pad, ctx->stream, ctx->d_slots,
                            one, use_single, calib, ns, per_slot, tag_all);
     }
     {
@@ -744,6 +746,7 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->fr_dev) (void)hipFree(ctx->fr_dev);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->side_done) (void)hipEventDestroy(ctx->side_done);
+    if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
     for (TimedLaunch& t : ctx->timed) {
         (void)hipEventDestroy(t.e0);
         (void)hipEventDestroy(t.e1);
@@ -760,6 +763,28 @@ void* mld_get_stream(mld_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; 
 int mld_synchronize(mld_ctx* ctx) {
     if (!ctx) return MLD_ERR_INVALID_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MLD_OK;
+}
+
+int mld_order_after(mld_ctx* ctx, mld_ctx* other) {
+    if (!ctx || !other) return MLD_ERR_INVALID_ARG;
+    if (ctx == other) return MLD_OK;
+    if (ctx->device != other->device) return fail(ctx, MLD_ERR_INVALID_ARG, "contexts live on different devices");
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    if (!ctx->order_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
+    HIP_TRY(ctx, hipEventRecord(ctx->order_ev, other->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->order_ev, 0));
+    return MLD_OK;
+}
+
+int mld_set_shared_gpu(mld_ctx* ctx, int shared) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    // k_feature_fused is capped by its LDS request: 14 KB per wavefront -> 11 per CU (3 per SIMD, which is all the
+    // VGPRs there are at 168 per wave); 20 KB -> 8 per CU, 2 per SIMD, and a third of the register file stays free
+    // for the projection wavefronts (56 VGPRs each) of a context running beside this one.
+    const size_t per_cu = 160 * 1024, want = per_cu / 8;
+    ctx->lds_fused_pad = (shared && ctx->lds_fused < want) ? want - ctx->lds_fused : 0;
     return MLD_OK;
 }
 

@@ -1567,7 +1567,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
         }
     }
     ST_USE_F64(sw);
-    ST_MARK(8);
+    ST_MARK(13);
     if (cand && (far || kk < 3)) {
         mytype = resultOld;  // :591
         mydepth = -1.0;
@@ -1584,7 +1584,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
         rr[3] = q0; rr[4] = q1; rr[5] = q2; rr[6] = q3; rr[7] = q4; rr[8] = q5;
         if (cand) finish_road_fast(c, myu, myv, rr, mytype, mydepth);
         ST_USE_F64(mydepth);
-        ST_MARK(11);
+        ST_MARK(14);
     } else {
         // RoadDepthEstimatorMaxSpanningTriangle::CalculateDepth (:24-75)
         if (cand && kk > kK2Max) {

@@ -238,6 +238,16 @@ class DepthEstimator:
     def synchronize(self):
         self._check(self._lib.mld_synchronize(self._ctx))
 
+    def orderAfter(self, other: "DepthEstimator"):
+        """Everything submitted to this context from now on starts after everything submitted to `other` so far has
+        finished (device-side; mld_order_after)."""
+        self._check(self._lib.mld_order_after(self._ctx, other._ctx))
+
+    def setSharedGpu(self, shared: bool = True):
+        """This context alternates with another one on the same GPU (see `runBatchesAlternating`): its feature kernel
+        leaves room on every CU for the other context's projection (mld_set_shared_gpu)."""
+        self._check(self._lib.mld_set_shared_gpu(self._ctx, 1 if shared else 0))
+
     # ------------------------------------------------------------------ setInputCloud
     @staticmethod
     def _cloud_view(cloud):
@@ -338,6 +348,18 @@ class DepthEstimator:
         self._after_torch(b["keep"][0][0])
         self._check(lib.mld_set_clouds_planes_device(ctx, n, b["cloud_ptrs"], b["cloud_n"], b["stride"],
                                                      b["coeffs"].ctypes.data_as(C.POINTER(C.c_float)), b["mask_ptrs"]))
+        self._check(lib.mld_calculate_depths_device(ctx, n, b["uv_ptrs"], b["F"], b["depth_ptrs"], b["type_ptrs"]))
+
+    def runBatchBeside(self, b, nxt: "DepthEstimator"):
+        """runBatch for a context that alternates with `nxt` on one GPU: `nxt`'s next projection is released when this
+        batch's projection is done, i.e. it runs beside this batch's feature kernels (HBM streaming beside gather / f64
+        work: include/mld.h "Two contexts").  Call `setSharedGpu()` on both contexts once."""
+        lib, ctx, n = self._lib, self._ctx, b["n"]
+        self._after_torch(b["keep"][0][0])
+        self._check(lib.mld_set_clouds_planes_device(ctx, n, b["cloud_ptrs"], b["cloud_n"], b["stride"],
+                                                     b["coeffs"].ctypes.data_as(C.POINTER(C.c_float)), b["mask_ptrs"]))
+        if nxt is not self:
+            nxt.orderAfter(self)
         self._check(lib.mld_calculate_depths_device(ctx, n, b["uv_ptrs"], b["F"], b["depth_ptrs"], b["type_ptrs"]))
 
     def estimateGroundPlane(self, slot: int = 0, seed: int = 0):

@@ -335,3 +335,47 @@ def test_batch_with_empty_and_ragged_slots():
             continue
         _, (d0, t0) = run_oracle(P, clouds[b], uvs[b], None if b == 7 else planes[b])
         assert_depth_parity(t_depth[b].cpu().numpy(), t_type[b].cpu().numpy(), d0, t0)
+
+
+def test_two_contexts_alternating_on_one_gpu():
+    """Two contexts used in turn (mld_order_after + mld_set_shared_gpu; include/mld.h "Two contexts"): the projection
+    of one runs beside the feature kernels of the other.  Every launch set of four rounds equals the oracle, whichever
+    context computed it, and the shared-GPU mode (more LDS per block of the lane-per-feature kernel) changes nothing."""
+    import torch
+    P = capi.params_c0()
+    S, F, rounds = 6, 1200, 4
+    dev = torch.device("cuda:0")
+    ests = [make_estimator(P, max_frames=S, max_features=F) for _ in range(2)]
+    for e in ests:
+        e.setSharedGpu(True)
+
+    def mask_of(inl, n):
+        m = np.zeros((n + 31) // 32, dtype=np.uint32)
+        np.bitwise_or.at(m, inl >> 5, (np.uint32(1) << (inl & 31).astype(np.uint32)))
+        return torch.from_numpy(m.view(np.int32)).to(dev)
+
+    sets = []
+    for r in range(rounds * 2):  # one launch set per (round, context)
+        clouds = [synth.make_cloud(synth.HDL64_KITTI, seed=300 + r, frame=b) for b in range(S)]
+        planes = [synth.make_ground_plane(c) for c in clouds]
+        uvs = [synth.make_features(F, seed=400 + 10 * r + b) for b in range(S)]
+        e = ests[r % 2]
+        d = [torch.empty(F, dtype=torch.float64, device=dev) for _ in range(S)]
+        t = [torch.empty(F, dtype=torch.int32, device=dev) for _ in range(S)]
+        batch = e.prepareBatch([torch.from_numpy(c).to(dev) for c in clouds], [torch.from_numpy(u).to(dev) for u in uvs],
+                               d, t, np.stack([p[0] for p in planes]),
+                               [mask_of(p[1], c.shape[0]) for p, c in zip(planes, clouds)])
+        sets.append((e, batch, clouds, planes, uvs, d, t))
+    torch.cuda.synchronize()
+    for r, (e, batch, *_rest) in enumerate(sets):
+        e.runBatchBeside(batch, ests[(r + 1) % 2])
+    for e in ests:
+        e.synchronize()
+    for e, batch, clouds, planes, uvs, d, t in sets:
+        for b in range(0, S, 2):
+            _, (d0, t0) = run_oracle(P, clouds[b], uvs[b], planes[b])
+            assert_depth_parity(d[b].cpu().numpy(), t[b].cpu().numpy(), d0, t0)
+    # argument checks of the C entry point
+    lib = ests[0]._lib
+    assert lib.mld_order_after(ests[0]._ctx, None) == capi.MLD_ERR_INVALID_ARG
+    assert lib.mld_order_after(ests[0]._ctx, ests[0]._ctx) == capi.MLD_OK
