@@ -377,14 +377,13 @@ def design_bytes_project(cloud, cam, T, inl):
 
 
 def pmc_traffic(kernel, frames_per_launch):
-    """HBM bytes per launch of `kernel` and the launch time they were measured with, from the committed rocprofv3 PMC
-    passes (profiles/traffic.json, written by profiles/summarize.py: FETCH_SIZE/WRITE_SIZE in separate --pmc runs,
-    gfx950 correction applied); None when no profile of the same launch size is on record."""
+    """HBM bytes per launch of `kernel` and the launch time they were measured with (the kernel alone on the GPU), from
+    the committed rocprofv3 PMC passes (profiles/traffic.json, written by profiles/summarize.py: FETCH_SIZE/WRITE_SIZE
+    in separate --pmc runs, gfx950 correction applied), scaled from the profile's frames per launch to this run's."""
     try:
         t = json.loads((ROOT / "profiles" / "traffic.json").read_text())
-        if int(t.get("frames_per_launch", -1)) != int(frames_per_launch):
-            return None
-        return float(t[kernel]["hbm_bytes_per_launch"]), float(t[kernel]["launch_s"]), t.get("source", "")
+        scale = float(frames_per_launch) / float(t["frames_per_launch"])  # traffic is proportional to the frames
+        return float(t[kernel]["hbm_bytes_per_launch"]) * scale, float(t[kernel]["launch_s"]) * scale, t.get("source", "")
     except Exception:  # noqa: BLE001
         return None
 

@@ -599,6 +599,9 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if (!params || !camera || !T_cam_lidar) return bail(MLD_ERR_INVALID_ARG, "null argument");
     if (max_frames < 1) return bail(MLD_ERR_INVALID_ARG, "max_frames must be >= 1");
     if (camera->width < 1 || camera->height < 1) return bail(MLD_ERR_INVALID_ARG, "bad image size");
+    // pixel-map cells are addressed with 32-bit offsets and 24-bit multiplies (k_project_scatter)
+    if (camera->width > 65535 || camera->height > 65535 || (int64_t)camera->width * camera->height > (int64_t)1 << 30)
+        return bail(MLD_ERR_CAPACITY, "image larger than 65535 pixels on a side or 2^30 pixels in all");
     // a singular or non-finite intrinsic matrix has no inverse (camera_pinhole.h:65 would produce NaN rays)
     if (!std::isfinite(camera->focal_length) || camera->focal_length == 0.0 || !std::isfinite(camera->principal_point_x) ||
         !std::isfinite(camera->principal_point_y))

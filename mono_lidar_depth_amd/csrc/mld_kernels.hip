@@ -239,26 +239,40 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
     decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
     SlotDesc s = use_single ? single : slots[slot];
     if (tag_all) s.tag = tag_all;
-    const long long base = (long long)j * (kProjThreads * kProjPerThread) + threadIdx.x;
+    // 32-bit index and offset arithmetic throughout: a cloud has at most 2^23 - 1 points of 16 or 32 bytes
+    const int n = (int)s.n;
+    const int base = j * (kProjThreads * kProjPerThread) + (int)threadIdx.x;
+    const uint32_t sh = (s.stride == 32) ? 5u : 4u;
+    const unsigned char* cl = s.cloud;
     float fx[kProjPerThread], fy[kProjPerThread], fz[kProjPerThread];
     const bool al16 = (((size_t)s.cloud) & 15) == 0;
 #pragma unroll
     for (int r = 0; r < kProjPerThread; r++) {
-        long long i = base + (long long)r * kProjThreads;
         fx[r] = 0;
         fy[r] = 0;
         fz[r] = 0;
-        if (i < s.n) {
-            const unsigned char* p = s.cloud + (size_t)i * (size_t)s.stride;
-            if (al16) {
-                f32x4 q = __builtin_nontemporal_load(GPTR(f32x4, p));  // streamed once: do not pollute the caches
+    }
+    if (al16) {
+#pragma unroll
+        for (int r = 0; r < kProjPerThread; r++) {
+            const int i = base + r * kProjThreads;
+            if (i < n) {
+                // streamed once: do not pollute the caches
+                f32x4 q = __builtin_nontemporal_load(GPTR(f32x4, cl + (size_t)((uint32_t)i << sh)));
                 fx[r] = q.x;
                 fy[r] = q.y;
                 fz[r] = q.z;
-            } else {
-                fx[r] = GPTR(float, p)[0];
-                fy[r] = GPTR(float, p)[1];
-                fz[r] = GPTR(float, p)[2];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kProjPerThread; r++) {
+            const int i = base + r * kProjThreads;
+            if (i < n) {
+                const auto* q = GPTR(float, cl + (size_t)((uint32_t)i << sh));
+                fx[r] = q[0];
+                fy[r] = q[1];
+                fz[r] = q[2];
             }
         }
     }
@@ -273,8 +287,8 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
     }
 #pragma unroll
     for (int r = 0; r < kProjPerThread; r++) {
-        long long i = base + (long long)r * kProjThreads;
-        if (i >= s.n) continue;
+        const int i = base + r * kProjThreads;
+        if (i >= n) continue;
         const float x = fx[r], y = fy[r], z = fz[r];
         // Conservative single-precision pre-cull.  86 % of a 360-degree scan is behind the camera or outside its
         // field of view; those points need none of the (half-rate) f64 work below.  Every f32 quantity here is
@@ -298,21 +312,21 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
         // exact path (identical to the CPU arithmetic)
         V3 pc = lidar_to_cam(c, (double)x, (double)y, (double)z);
         if (!(pc.z > 0.0)) continue;  // NeighborFinderPixel.cpp:51: only z > 0 enters the map
-        double u, v;
-        project(c, pc, u, v);
+        // camera_pinhole.h:88-90 without the six products by zero of K: for finite points q0 = (f x + 0 y) + cu z,
+        // q1 = (0 x + f y) + cv z and q2 = (0 x + 0 y) + 1 z are bit-identical to f x + cu z, f y + cv z and z (the
+        // sign of a zero sum cannot turn 0 < u into true), and a non-finite coordinate fails the bounds below either way
+        const double u = (c.f * pc.x + c.cu * pc.z) / pc.z;
+        const double v = (c.f * pc.y + c.cv * pc.z) / pc.z;
         // DepthEstimator.cpp:186-187 strict bounds (imply the inclusive test of camera_pinhole.h:93-95)
         if ((u > 0.0) && (u < Wd) && (v > 0.0) && (v < Hd)) {
             int xi = (int)u, yi = (int)v;  // truncation, NeighborFinderPixel.cpp:41-42
             uint32_t inl = 0u;
-            if (s.mask_in_key) inl = (GPTR(uint32_t, s.inlier_mask)[(size_t)i >> 5] >> ((uint32_t)i & 31u)) & 1u;
+            if (s.mask_in_key) inl = (GPTR(uint32_t, s.inlier_mask)[(uint32_t)i >> 5] >> ((uint32_t)i & 31u)) & 1u;
             const uint32_t key = make_key(s.tag, (uint32_t)i, inl);
-#ifndef MLD_DBG_NOMAPATOMIC
-            __hip_atomic_fetch_max(GPTRW(uint32_t, s.map) + ((size_t)xi + (size_t)yi * (size_t)c.W), key,
+            // (24-bit multiplies: image sides and the bitmap stride are far below 2^24)
+            __hip_atomic_fetch_max(GPTRW(uint32_t, s.map) + (uint32_t)__mul24(yi, c.W) + (uint32_t)xi, key,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-            if (key == 0x12345u) GPTRW(uint32_t, s.map)[0] = key;  // timing experiment only
-#endif
-            bmw[r] = (xi >> 5) * c.bmStride + yi;
+            bmw[r] = __mul24(xi >> 5, c.bmStride) + yi;
             bmb[r] = 1u << (xi & 31);
         }
     }
@@ -330,6 +344,9 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
     }
 #pragma unroll
     for (int r = 0; r < kProjPerThread; r++) {
+        // the four point groups of a wavefront are a quarter of a scan ring apart: usually only one or two of them are
+        // in the camera's field of view
+        if (!__any(bmb[r] != 0u)) continue;
         int w = bmw[r];
         uint32_t bits = bmb[r];
         // DPP row shifts (no LDS traffic): runs are merged inside 16-lane rows; a row's last lane always writes
@@ -346,7 +363,7 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
 #undef MLD_ROW_STEP
         const int wnext = __builtin_amdgcn_update_dpp((int)-0x40000000, w, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
         if ((wnext != w) && bits)
-            __hip_atomic_fetch_or(GPTRW(uint32_t, s.bitmap) + (size_t)w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_or(GPTRW(uint32_t, s.bitmap) + (uint32_t)w, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -2341,7 +2358,7 @@ __global__ __launch_bounds__(kWave, MLD_FUSED_WAVES) void k_feature_fused(const 
         const bool road_on = c.useRoad && s.has_plane && s.inlier_mask;
         // narrow window (DepthEstimator.cpp:509, scale 1 x 1) and the window that is scanned: the road window
         // (:585, scale 2.0 x 1.5), a superset, when the fallback is on
-        int xn0, yn0, nxn, nyn, x0, y0, nx, ny;
+        int xn0 = 0, yn0 = 0, nxn, nyn, x0 = 0, y0 = 0, nx, ny;
         const bool hasn = active && window_bounds(c, myu, myv, c.halfX1, c.halfY1, xn0, yn0, nxn, nyn);
         if (!hasn) {
             nxn = 0;

@@ -9,8 +9,12 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 COMMON="--cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0"
 ARGS="--steps 20 --warmup 3 $COMMON"
+# the bench default: two contexts alternating (a projection beside the other context's feature kernels)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
-PMCARGS="--steps 4 --warmup 1 $COMMON --no-kernel-timing"
+# one context, one kernel at a time: what each kernel takes with the GPU to itself (1024 frames per launch)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_x -- python3 $REPO/bench.py --contexts 1 $ARGS > $OUT/bench_trace_x.json 2> $OUT/trace_x.log
+# counters: rocprofv3 serialises the kernels in these passes, so they are collected on the one-context schedule
+PMCARGS="--contexts 1 --steps 4 --warmup 1 $COMMON --no-kernel-timing --no-estimated"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_sq.json 2> $OUT/pmc_sq.log

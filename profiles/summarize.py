@@ -19,25 +19,49 @@ def newest(pattern):
 
 stats = newest(f"{src}/trace/*/*kernel_stats.csv")
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
+stats_x = newest(f"{src}/trace_x/*/*kernel_stats.csv")
+if stats_x:
+    shutil.copy(stats_x, f"profiles/{tag}_kernel_stats_one_context.csv")
 lines = [f"# rocprofv3 summary — {tag}", "",
          "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 "
-         "--cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0` (see profiles/run_profile.sh); PMC "
-         "passes are separate runs of the same command with `--pmc` (4 steps).", ""]
-ks = pd.read_csv(stats)
-ks = ks[ks.Name.str.contains("mld::")]
-lines += ["## kernel-trace --stats", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
-for _, r in ks.iterrows():
-    lines.append(f"| `{r.Name.split('(')[0]}` | {r.Calls} | {r.AverageNs / 1e3:.1f} | {r.MinNs / 1e3:.1f} | "
-                 f"{r.MaxNs / 1e3:.1f} | {r.Percentage:.2f} |")
-try:
-    b = json.loads(open(f"{src}/bench_trace.json").read().strip().splitlines()[-1])
-    rk = b["roofline"]["kernels"]
-    lines += ["", "bench.py hipEvent averages in the same run: " +
-              ", ".join(f"`{k}` {v.get('avg_ms', 0) * 1e3:.1f} us" for k, v in rk.items()), ""]
-    lines += [f"bench.py line of that run: value {b['value'] / 1e9:.3f} G associations/s, ms_per_step {b['ms_per_step']:.4f}, "
-              f"verified {b['verified']}, roofline.frac {b['roofline']['frac']:.3f} ({b['roofline']['kernel']})", ""]
-except Exception as e:  # noqa: BLE001
-    lines += ["", f"(bench json not parsed: {e})", ""]
+         "--cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0` (see profiles/run_profile.sh): the "
+         "bench default, two contexts of 512 frame slots alternating, so a projection runs BESIDE the other context's "
+         "feature kernels and the launch durations below are durations of kernels that share the GPU.  The second table "
+         "is the same command with `--contexts 1` (one stream, 1024 frame slots per launch, every kernel alone).  PMC "
+         "passes are separate runs with `--contexts 1 --pmc ...` (4 steps; rocprofv3 serialises the kernels there).", ""]
+
+
+def table(path, title, bjson):
+    out = []
+    k = pd.read_csv(path)
+    k = k[k.Name.str.contains("mld::")]
+    out += [f"## kernel-trace --stats: {title}", "", "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
+    for _, r in k.iterrows():
+        out.append(f"| `{r.Name.split('(')[0]}` | {r.Calls} | {r.AverageNs / 1e3:.1f} | {r.MinNs / 1e3:.1f} | "
+                   f"{r.MaxNs / 1e3:.1f} | {r.Percentage:.2f} |")
+    bb = None
+    try:
+        bb = json.loads(open(bjson).read().strip().splitlines()[-1])
+        rk = bb["roofline"]["kernels"]
+        out += ["", "bench.py hipEvent averages in the same run: " +
+                ", ".join(f"`{kk}` {v.get('avg_ms', 0) * 1e3:.1f} us" for kk, v in rk.items()), ""]
+        ex = bb["roofline"].get("exclusive")
+        out += [f"bench.py line of that run: value {bb['value'] / 1e9:.3f} G associations/s, ms_per_step {bb['ms_per_step']:.4f}, "
+                f"verified {bb['verified']}, roofline.frac {bb['roofline']['frac']:.3f} ({bb['roofline']['kernel']}, "
+                f"{bb['config']['frame_slots_per_launch']} frames per launch)" +
+                (f", roofline.exclusive.frac {ex['frac']:.3f} ({ex['kernel_ms'] * 1e3:.1f} us alone)" if ex else ""), ""]
+    except Exception as e:  # noqa: BLE001
+        out += ["", f"(bench json not parsed: {e})", ""]
+    return k, bb, out
+
+
+ks2, b2, t2 = table(stats, "two contexts alternating (bench default)", f"{src}/bench_trace.json")
+lines += t2
+if stats_x:
+    ks, b, t1 = table(stats_x, "one context (`--contexts 1`)", f"{src}/bench_trace_x.json")
+    lines += t1
+else:
+    ks, b = ks2, b2
 lines += ["## PMC (per launch, mean over launches)", "",
           "FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane) "
           "coalesced read (MI355X_MICROARCH.md §HBM): `hbm_read_corrected` doubles it for k_project_scatter "
@@ -67,7 +91,8 @@ for k in ("k_project_scatter", "k_classify", "k_feature_fused"):
                      f"written = {(fc + w) / 1e6:,.1f} MB -> {(fc + w) / avg / 1e12:.2f} TB/s over the {avg * 1e6:.1f} us launch")
 try:
     traffic["frames_per_launch"] = b["config"].get("frame_slots_per_launch", b["config"]["frames_per_step"])
-    traffic["source"] = f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    traffic["source"] = (f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, one context; "
+                         "launch_s = that kernel alone, from the --contexts 1 trace)")
     json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
 except Exception as e:  # noqa: BLE001
     print("traffic.json not written:", e)
