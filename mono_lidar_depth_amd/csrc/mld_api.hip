@@ -230,6 +230,20 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     c.ff = (float)c.f;
     c.cuf = (float)c.cu;
     c.cvf = (float)c.cv;
+    {
+        // 1e-5 x (sum of the absolute values of the terms), the sums bounded by rowmax * m1 + |t|; evaluated in double
+        // and rounded up, so the margins are never below the 1e-5 * S the kernel's comment promises
+        const double e = 1e-5, up = 1.000001;
+        const double Wf = (double)(float)ctx->cam.width, Hf = (double)(float)ctx->cam.height;
+        const double tx = std::fabs((double)c.Tf[3]), ty = std::fabs((double)c.Tf[7]), tz = std::fabs((double)c.Tf[11]);
+        const double fa = std::fabs((double)c.ff), ua = std::fabs((double)c.cuf) + Wf, va = std::fabs((double)c.cvf) + Hf;
+        c.pcm[0] = (float)(e * (double)c.Tfmax[2] * up);
+        c.pcm[1] = (float)(e * tz * up);
+        c.pcm[2] = (float)(e * (fa * (double)c.Tfmax[0] + ua * (double)c.Tfmax[2]) * up);
+        c.pcm[3] = (float)(e * (fa * tx + ua * tz) * up);
+        c.pcm[4] = (float)(e * (fa * (double)c.Tfmax[1] + va * (double)c.Tfmax[2]) * up);
+        c.pcm[5] = (float)(e * (fa * ty + va * tz) * up);
+    }
     c.W = ctx->cam.width;
     c.H = ctx->cam.height;
     c.bmStride = (ctx->cam.height + 16 + 3) / 4 * 4;  // words per 32-pixel column: H rows + 16 rows of read slack

@@ -29,6 +29,9 @@ struct Calib {
     float Tfmax[3];  // max |Tf[r][0..2]| per row, rounded up (bounds of the f32 pre-cull)
     float ff, cuf, cvf;
     float padf_;
+    // margins of the pre-cull as linear functions of m1 = |x|+|y|+|z| (rounded up): z test pcm[0] m1 + pcm[1], u tests
+    // pcm[2] m1 + pcm[3], v tests pcm[4] m1 + pcm[5]
+    float pcm[6];
     double halfX1, halfY1;  // main search window half sizes  (scale 1.0, 1.0)
     double halfX2, halfY2;  // road search window half sizes  (scale 2.0, 1.5)
     double binW;

@@ -241,85 +241,79 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
     if (tag_all) s.tag = tag_all;
     // 32-bit index and offset arithmetic throughout: a cloud has at most 2^23 - 1 points of 16 or 32 bytes
     const int n = (int)s.n;
-    const int base = j * (kProjThreads * kProjPerThread) + (int)threadIdx.x;
+    const int blk0 = j * (kProjThreads * kProjPerThread);
+    if (blk0 >= n) return;  // block-uniform (the clouds of a batch may differ in size)
+    const int base = blk0 + (int)threadIdx.x;
     const uint32_t sh = (s.stride == 32) ? 5u : 4u;
     const unsigned char* cl = s.cloud;
     float fx[kProjPerThread], fy[kProjPerThread], fz[kProjPerThread];
-    const bool al16 = (((size_t)s.cloud) & 15) == 0;
-#pragma unroll
-    for (int r = 0; r < kProjPerThread; r++) {
-        fx[r] = 0;
-        fy[r] = 0;
-        fz[r] = 0;
-    }
-    if (al16) {
+    // every lane loads a valid point (index clamped to the cloud); lanes beyond the end are masked out of the result
+    if ((((size_t)s.cloud) & 15) == 0) {
 #pragma unroll
         for (int r = 0; r < kProjPerThread; r++) {
-            const int i = base + r * kProjThreads;
-            if (i < n) {
-                // streamed once: do not pollute the caches
-                f32x4 q = __builtin_nontemporal_load(GPTR(f32x4, cl + (size_t)((uint32_t)i << sh)));
-                fx[r] = q.x;
-                fy[r] = q.y;
-                fz[r] = q.z;
-            }
+            const int i = min(base + r * kProjThreads, n - 1);
+            // streamed once: do not pollute the caches
+            f32x4 q = __builtin_nontemporal_load(GPTR(f32x4, cl + (size_t)((uint32_t)i << sh)));
+            fx[r] = q.x;
+            fy[r] = q.y;
+            fz[r] = q.z;
         }
     } else {
 #pragma unroll
         for (int r = 0; r < kProjPerThread; r++) {
-            const int i = base + r * kProjThreads;
-            if (i < n) {
-                const auto* q = GPTR(float, cl + (size_t)((uint32_t)i << sh));
-                fx[r] = q[0];
-                fy[r] = q[1];
-                fz[r] = q[2];
-            }
+            const int i = min(base + r * kProjThreads, n - 1);
+            const auto* q = GPTR(float, cl + (size_t)((uint32_t)i << sh));
+            fx[r] = q[0];
+            fy[r] = q[1];
+            fz[r] = q[2];
         }
     }
     const double Wd = (double)c.W, Hd = (double)c.H;
     const float Wf = (float)c.W, Hf = (float)c.H;
+    // translation terms of the single-precision transform: used by every point, kept in vector registers
+    float t3 = c.Tf[3], t7 = c.Tf[7], t11 = c.Tf[11];
+    asm volatile("" : "+v"(t3), "+v"(t7), "+v"(t11));
     int bmw[kProjPerThread];       // occupancy-bitmap word of the point (or a unique negative value)
     uint32_t bmb[kProjPerThread];  // its bit
 #pragma unroll
     for (int r = 0; r < kProjPerThread; r++) {
         bmw[r] = -1 - (int)threadIdx.x;
         bmb[r] = 0u;
-    }
-#pragma unroll
-    for (int r = 0; r < kProjPerThread; r++) {
         const int i = base + r * kProjThreads;
-        if (i >= n) continue;
         const float x = fx[r], y = fy[r], z = fz[r];
         // Conservative single-precision pre-cull.  86 % of a 360-degree scan is behind the camera or outside its
-        // field of view; those points need none of the (half-rate) f64 work below.  Every f32 quantity here is
-        // within 1e-6 * S of its exact value, S being the sum of the absolute values of its terms; a point is
-        // dropped only if it misses the image by more than 1e-5 * S, so no point the exact test would keep is lost.
-        // NaN compares false: such points fall through to the exact path.
-        // (the sums S are bounded from above by rowmax * (|x|+|y|+|z|) + |t|: cheaper, still conservative)
+        // field of view; those points need none of the f64 work below.  Every f32 quantity here is within 1e-6 * S
+        // of its exact value, S being the sum of the absolute values of its terms; a point is dropped only if it
+        // misses the image by more than 1e-5 * S, so no point the exact test would keep is lost.  The sums S are
+        // bounded from above by rowmax * (|x|+|y|+|z|) + |t|, so each margin is linear in m1 with coefficients the host
+        // prepared (Calib::pcm, rounded up).  A NaN intermediate compares false: the point falls through to the exact path.  The
+        // stages are skipped per 64-point group (wave-uniform branches, no lane masking): consecutive points of a
+        // scan ring leave the field of view together.
         const float* T = c.Tf;
         const float m1 = fabsf(x) + fabsf(y) + fabsf(z);
-        const float zc = fmaf(T[8], x, fmaf(T[9], y, fmaf(T[10], z, T[11])));
-        const float sz = fmaf(c.Tfmax[2], m1, fabsf(T[11]));
-        if (zc < -1e-5f * sz) continue;
-        const float xc = fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, T[3])));
-        const float yc = fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, T[7])));
-        const float sx = fmaf(c.Tfmax[0], m1, fabsf(T[3]));
-        const float sy = fmaf(c.Tfmax[1], m1, fabsf(T[7]));
+        const float zc = fmaf(T[8], x, fmaf(T[9], y, fmaf(T[10], z, t11)));
+        // (m1 is NaN exactly when a coordinate is: such a point - a "no return" of an organised cloud - has a NaN camera
+        // depth on the exact path and is never visible; without this test a single one keeps its whole group on the
+        // exact path.  Infinite or overflowing coordinates still fall through.)
+        bool pass = (i < n) && (m1 == m1) && !(zc < -fmaf(c.pcm[0], m1, c.pcm[1]));
+        if (!__any(pass)) continue;
+        const float xc = fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, t3)));
+        const float yc = fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, t7)));
         const float qa = fmaf(c.ff, xc, c.cuf * zc), qb = fmaf(c.ff, yc, c.cvf * zc);  // ~ u*z, v*z
-        const float ma = 1e-5f * (fabsf(c.ff) * sx + (fabsf(c.cuf) + Wf) * sz);
-        const float mb = 1e-5f * (fabsf(c.ff) * sy + (fabsf(c.cvf) + Hf) * sz);
-        if (qa < -ma || qa - Wf * zc > ma || qb < -mb || qb - Hf * zc > mb) continue;
+        const float ma = fmaf(c.pcm[2], m1, c.pcm[3]), mb = fmaf(c.pcm[4], m1, c.pcm[5]);
+        pass = pass && !(qa < -ma) && !(fmaf(-Wf, zc, qa) > ma) && !(qb < -mb) && !(fmaf(-Hf, zc, qb) > mb);
+        if (!__any(pass)) continue;
         // exact path (identical to the CPU arithmetic)
-        V3 pc = lidar_to_cam(c, (double)x, (double)y, (double)z);
-        if (!(pc.z > 0.0)) continue;  // NeighborFinderPixel.cpp:51: only z > 0 enters the map
+        const V3 pc = lidar_to_cam(c, (double)x, (double)y, (double)z);
         // camera_pinhole.h:88-90 without the six products by zero of K: for finite points q0 = (f x + 0 y) + cu z,
         // q1 = (0 x + f y) + cv z and q2 = (0 x + 0 y) + 1 z are bit-identical to f x + cu z, f y + cv z and z (the
         // sign of a zero sum cannot turn 0 < u into true), and a non-finite coordinate fails the bounds below either way
         const double u = (c.f * pc.x + c.cu * pc.z) / pc.z;
         const double v = (c.f * pc.y + c.cv * pc.z) / pc.z;
-        // DepthEstimator.cpp:186-187 strict bounds (imply the inclusive test of camera_pinhole.h:93-95)
-        if ((u > 0.0) && (u < Wd) && (v > 0.0) && (v < Hd)) {
-            int xi = (int)u, yi = (int)v;  // truncation, NeighborFinderPixel.cpp:41-42
+        // NeighborFinderPixel.cpp:51: only z > 0 enters the map; DepthEstimator.cpp:186-187 strict bounds (imply the
+        // inclusive test of camera_pinhole.h:93-95)
+        if (pass && (pc.z > 0.0) && (u > 0.0) && (u < Wd) && (v > 0.0) && (v < Hd)) {
+            const int xi = (int)u, yi = (int)v;  // truncation, NeighborFinderPixel.cpp:41-42
             uint32_t inl = 0u;
             if (s.mask_in_key) inl = (GPTR(uint32_t, s.inlier_mask)[(uint32_t)i >> 5] >> ((uint32_t)i & 31u)) & 1u;
             const uint32_t key = make_key(s.tag, (uint32_t)i, inl);
