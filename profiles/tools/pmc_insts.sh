@@ -3,7 +3,7 @@
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 LIBS="$@"; [ -z "$LIBS" ] && LIBS=$REPO/mono_lidar_depth_amd/lib/libmld_hip.so
 cd /tmp && export TMPDIR=/tmp
-A="--contexts 1 --steps 3 --warmup 1 --cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0 --no-kernel-timing --no-estimated"
+A="--contexts 1 --steps 3 --warmup 1 --cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0 --no-kernel-timing --no-estimated --verify-slots 0"
 for lib in $LIBS; do
   OUT=$REPO/gpurun_out/pmci_$(basename $lib .so); rm -rf $OUT; mkdir -p $OUT
   export MLD_HIP_LIBRARY=$(cd $REPO && realpath $lib)
