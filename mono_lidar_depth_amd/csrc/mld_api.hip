@@ -453,7 +453,12 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     const uint32_t tag_all = single ? 0u : common_tag(ctx, n_slots);
     const SlotDesc one = single ? ctx->slots[slot].d : SlotDesc{};
     const int use_single = single ? 1 : 0, ns = single ? 1 : n_slots;
-    {
+    if (few) {
+        HIP_TRY(ctx, hipMemsetAsync(one.ovf_count, 0, sizeof(int32_t), ctx->stream));
+        ScopedTimer ts(ctx, 5);
+        hipLaunchKernelGGL(mld::k_classify_few, dim3((unsigned)((max_F + mld::kFewThreads - 1) / mld::kFewThreads)),
+                           dim3(mld::kFewThreads), 0, ctx->stream, one, calib);
+    } else {
         ScopedTimer ts(ctx, 5);
         auto kc = ctx->classify_staged ? mld::k_classify<true> : mld::k_classify<false>;
         hipLaunchKernelGGL(kc, dim3((unsigned)ns), dim3(kClsThreads), ctx->lds_classify, ctx->stream, ctx->d_slots, one,

@@ -2199,7 +2199,54 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
     }
 }
 
-constexpr int kKeyBatchF = 8;  // map keys fetched per round trip by the fused kernel
+// ONE frame per call (the wave-only mode of launch_features): what k_classify does for such a call - features with too
+// few neighbours are settled, the others go to the wave kernel's queue - without the staging and the sort, by as many
+// small blocks as the features need instead of one 1024-thread block (25 -> ~5 us of a 145 us call).  The bitmap rows
+// come straight from L2, where the projection has just left them.  *s.ovf_count must be zero on entry.
+constexpr int kFewThreads = 256;
+__global__ __launch_bounds__(kFewThreads) void k_classify_few(SlotDesc s, Calib c) {
+    apply_plane_dev(s);
+    long long Fn = s.F;
+    if (s.F_dev) {
+        const long long fd = *GPTR(long long, s.F_dev);
+        Fn = fd < Fn ? fd : Fn;
+    }
+    const long long i = (long long)blockIdx.x * kFewThreads + threadIdx.x;
+    const int lane = (int)threadIdx.x & (kWave - 1);
+    bool queue = false;
+    if (i < Fn) {
+        const auto* uv = GPTR(double, s.uv);
+        const double u = uv[2 * i], v = uv[2 * i + 1];
+        int x0, y0, nx, ny, k1 = 0;
+        if (window_bounds(c, u, v, c.halfX1, c.halfY1, x0, y0, nx, ny)) {
+            if (nx > 32) {
+                queue = true;  // (a 64-bit row mask would be needed; the wave kernel counts for itself)
+            } else {
+                const auto* bm = GPTR(uint32_t, s.bitmap) + (size_t)(x0 >> 5) * (size_t)c.bmStride;
+                const uint32_t sh = (uint32_t)(x0 & 31);
+                const uint32_t colmask = (nx >= 32) ? ~0u : ((1u << nx) - 1u);
+                for (int r = 0; r < ny; r++) {
+                    const uint32_t lo = bm[y0 + r], hi = bm[c.bmStride + y0 + r];
+                    k1 += __popc(__builtin_amdgcn_alignbit(hi, lo, sh) & colmask);
+                }
+            }
+        }
+        if (!queue) {
+            if ((unsigned)k1 < c.countMin) {  // DepthEstimator.cpp:680
+                GPTRW(double, s.depth)[i] = -1.0;
+                if (s.type) GPTRW(int32_t, s.type)[i] = MLD_RadiusSearchInsufficientPoints;
+            } else {
+                queue = true;
+            }
+        }
+    }
+    enqueue_features(s.ovf_queue, s.ovf_count, queue, lane, i, -1);
+}
+
+#ifndef MLD_KEY_BATCH_F
+#define MLD_KEY_BATCH_F 8
+#endif
+constexpr int kKeyBatchF = MLD_KEY_BATCH_F;  // map keys fetched per round trip by the fused kernel
 
 // One scan of the window (x0, y0, nx, ny) through the occupancy bitmap; entries in the reference's row-major order,
 // bit 31 set for the cells that also lie inside the narrow window (xn0, yn0, nxn, nyn).  The lane's list ends up
