@@ -515,30 +515,43 @@ __device__ int hist_segment(const Calib& c, int k, const Lists& L, int lane) {
 // (i,j)-lexicographic order and the first maximal k.
 __device__ bool max_spanning_triangle(int n, const Lists& L, int lane, int& ci, int& cj, int& ck) {
     if (n < 3) return false;
-    double best = -1.0;
-    int bi = -1, bj = -1;
-    const int total = n * n;
-    const float rn = 1.0f / (float)n;
-    for (int b = 0; b < total; b += kWave) {
-        int id = b + lane;
-        int i = (int)(((float)id + 0.5f) * rn);
-        int j = id - i * n;
-        bool valid = (id < total) && (i < j);
-        double d = -2.0;
-        if (valid) {
-            V3 pi = {L.x[i], L.y[i], L.z[i]}, pj = {L.x[j], L.y[j], L.z[j]};
-            d = vsqnorm(vsub(pi, pj));
-        }
-        double m = wave_max_f64(d);
-        if (m > best) {
-            unsigned long long who = __ballot(valid && d == m);
-            int first = __ffsll((long long)who) - 1;
-            int fid = b + first;
-            best = m;
-            bi = (int)(((float)fid + 0.5f) * rn);
-            bj = fid - bi * n;
+    // Farthest pair.  Every lane keeps the maximum of its own pairs and the smallest pair id (i * n + j) that reaches
+    // it; one reduction at the end.  The serial loop's strict '>' keeps the first maximal pair in (i,j) order, i.e. the
+    // smallest id among the pairs at the global maximum - which is what the final min over the lanes at the maximum
+    // returns.  Rows i and n-2-i hold n-1-i and i+1 pairs, n together: they share an iteration (n/2 iterations with
+    // n lanes busy instead of n*n/64 iterations of a half-empty square with a wave-wide reduction in each).
+    double bd = -2.0;
+    int bid = 0x7fffffff;
+    const int half = n >> 1;  // rows 0..n-2 in pairs (i, n-2-i); the middle row of an odd number of rows alone
+    for (int i = 0; i < half; i++) {
+        const int i2 = n - 2 - i;
+        const int na = n - 1 - i;                  // pairs of row i
+        const int nb = (i2 > i) ? n - 1 - i2 : 0;  // pairs of row i2
+        for (int l0 = 0; l0 < na + nb; l0 += kWave) {
+            const int l = l0 + lane;
+            int r = -1, j = 0;
+            if (l < na) {
+                r = i;
+                j = i + 1 + l;
+            } else if (l < na + nb) {
+                r = i2;
+                j = i2 + 1 + (l - na);
+            }
+            if (r >= 0) {
+                const V3 pr = {L.x[r], L.y[r], L.z[r]}, pj = {L.x[j], L.y[j], L.z[j]};
+                const double d = vsqnorm(vsub(pr, pj));
+                const int id = r * n + j;
+                if (d > bd || (d == bd && id < bid)) {
+                    bd = d;
+                    bid = id;
+                }
+            }
         }
     }
+    const double best = wave_max_f64(bd);
+    int cand_id = (bd == best) ? bid : 0x7fffffff;
+    cand_id = uniform(wave_min_i32(cand_id));
+    int bi = cand_id / n, bj = cand_id - (cand_id / n) * n;
     bi = uniform(bi);
     bj = uniform(bj);
     if (best <= 0.0) return false;  // :65
