@@ -474,10 +474,10 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         ScopedTimer tm(ctx, 3);
         // queue entries per block and iteration: a wavefront works on ONE feature at a time.  Batches: eight, about
         // 4096 blocks in all (the queues are empty for KITTI-like clouds and hold every feature for dense ones); a
-        // single frame: as few as keep the grid near 2048 blocks.
-        const int chunk = few ? (int)std::min<int64_t>(8, std::max<int64_t>(1, (max_F + 2047) / 2048)) : 8;
+        // single frame: one or two entries per block and up to 16384 blocks (config 5, 10 000 tracks: 65 -> 52 us)
+        const int chunk = few ? (int)std::min<int64_t>(8, std::max<int64_t>(1, (max_F + 8191) / 8192)) : 8;
         const int want = (int)((max_F + chunk - 1) / chunk);
-        const int pw = std::max(1, std::min(want, std::max(4, 4096 / ns)));
+        const int pw = std::max(1, std::min(want, std::max(4, (few ? 16384 : 4096) / ns)));
         hipLaunchKernelGGL(k_feature_wave, dim3((unsigned)pw * (unsigned)ns), dim3(kWave), ctx->lds_bytes, ctx->stream,
                            ctx->d_slots, one, use_single, calib, ns, pw, tag_all, chunk);
     }

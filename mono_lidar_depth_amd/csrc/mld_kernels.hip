@@ -1942,6 +1942,8 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
 // main path's result.
 // `chunk` (<= 64) queue entries per block and iteration: a wavefront works on ONE feature at a time, so small chunks
 // spread a long queue (dense clouds: every feature overflows) over many more wavefronts.
+// (171 VGPRs, two wavefronts per SIMD; 168 / 128 registers for three / four were measured: same time - the kernel is
+// bound by instruction issue, ~5000 VALU instructions per feature, not by occupancy)
 __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restrict__ slots, SlotDesc single, int use_single,
                                                         Calib c, int n_slots, int per_slot, uint32_t tag_all, int chunk) {
     extern __shared__ __align__(16) unsigned char smem[];
