@@ -1298,8 +1298,13 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
     }
 
     // ---------------- phase 4 (lane = feature) ----------------
-    if (mystate == ST_ROAD_MEST || mystate == ST_ROAD_TRI) {
-        finish_road(c, mystate == ST_ROAD_TRI, myu, myv, myr, mytype, mydepth);
+    // (the M-estimator's normal from the direct eigenvector solver of the lane-per-feature kernel: with one or two
+    // queue entries per block this tail runs on one or two lanes, and the cyclic Jacobi sweeps were a third of the
+    // kernel's instructions)
+    if (mystate == ST_ROAD_MEST) {
+        finish_road_fast(c, myu, myv, myr, mytype, mydepth);
+    } else if (mystate == ST_ROAD_TRI) {
+        finish_road(c, true, myu, myv, myr, mytype, mydepth);
     }
 }
 
