@@ -1098,7 +1098,7 @@ __device__ __forceinline__ void finish_road_fast(const Calib& c, double u, doubl
 __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, unsigned char* smem, const int lane,
                                        const unsigned long long mask, const double myu, const double myv, int& mytype,
                                        double& mydepth, const unsigned long long main_mask, double (&corners)[9],
-                                       bool& has_corners) {
+                                       bool& has_corners ST_ARG) {
     Lists L;
     L.x = reinterpret_cast<double*>(smem);
     L.y = L.x + c.cap;
@@ -1118,11 +1118,15 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
         const double u = readlane_f64(myu, fi), v = readlane_f64(myv, fi);
         int state = ST_FINAL, type = MLD_Unspecified;
         int k = gather_window(c, s, u, v, c.halfX1, c.halfY1, L, lane);
+        ST_USE_U32(k);
+        ST_MARK(1);
         if ((unsigned)k < c.countMin) {  // DepthEstimator.cpp:680
             type = MLD_RadiusSearchInsufficientPoints;
         } else {
             int ks = k;
             if (c.useHist) ks = hist_segment(c, k, L, lane);  // DepthEstimator.cpp:726-780
+            ST_USE_U32(ks);
+            ST_MARK(2);
             if (ks < 0) {
                 type = MLD_HistogramNoLocalMax;
             } else {
@@ -1131,6 +1135,8 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
                 bool ok = true;
                 if (!c.usePCA && c.useTriMax) {
                     ok = max_spanning_triangle(ks, L, lane, ci, cj, ck);
+                    ST_USE_U32(ci);
+                    ST_MARK(3);
                     if (!ok) type = MLD_TriangleNotPlanarInsufficientPoints;
                 } else if (ks < 3) {
                     ok = false;
@@ -1175,6 +1181,7 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
         }
     }
 
+    ST_MARK(4);
     // ---------------- phase 2 (lane = feature) ----------------
     if (mystate == ST_TRIANGLE || mystate == ST_PCA) {
         // debug vector of CalculatePlaneCorners (PlaneEstimationCalcMaxSpanningTriangle.cpp:20-35)
@@ -1185,6 +1192,8 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
         mystate = ST_FINAL;
     }
 
+    ST_USE_F64(mydepth);
+    ST_MARK(5);
     // ---------------- phase 3: road fallback (DepthEstimator.cpp:578-597) ----------------
     // Candidates: everything that is not Success and did not already return at :509-510.
     const bool road_on = c.useRoad && s.has_plane && s.inlier_mask;
@@ -1197,6 +1206,8 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
         const int resultOld = __builtin_amdgcn_readlane(mytype, fi);
         int state = ST_FINAL, type = resultOld;
         int k = gather_window(c, s, u, v, c.halfX2, c.halfY2, L, lane);  // :585 scale 2.0, 1.5
+        ST_USE_U32(k);
+        ST_MARK(6);
         if ((unsigned)k < c.countMin) {
             type = MLD_RadiusSearchInsufficientPoints;
         } else {
@@ -1234,6 +1245,8 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
                 kk += __popcll(m);
             }
             kk = uniform(kk);
+            ST_USE_U32(kk);
+            ST_MARK(7);
             if (anyFar || kk < 3) {
                 type = resultOld;  // :591
             } else {
@@ -1297,6 +1310,7 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
         }
     }
 
+    ST_MARK(8);
     // ---------------- phase 4 (lane = feature) ----------------
     // (the M-estimator's normal from the direct eigenvector solver of the lane-per-feature kernel: with one or two
     // queue entries per block this tail runs on one or two lanes, and the cyclic Jacobi sweeps were a third of the
@@ -1306,6 +1320,8 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
     } else if (mystate == ST_ROAD_TRI) {
         finish_road(c, true, myu, myv, myr, mytype, mydepth);
     }
+    ST_USE_F64(mydepth);
+    ST_MARK(9);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1978,7 +1994,11 @@ __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restri
         const unsigned long long full = __ballot(active && code < 0);
         double corners[9];
         bool has_corners = false;
-        wave_path(c, s, smem, lane, all, myu, myv, mytype, mydepth, full, corners, has_corners);
+#ifdef MLD_STAMPS
+        Stamps st;
+        st.begin(1);
+#endif
+        wave_path(c, s, smem, lane, all, myu, myv, mytype, mydepth, full, corners, has_corners ST_PASS);
         if (active) {
             GPTRW(double, s.depth)[f] = mydepth;
             if (s.type) GPTRW(int32_t, s.type)[f] = mytype;
@@ -1987,6 +2007,10 @@ __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restri
                 for (int t = 0; t < 9; t++) GPTRW(double, s.corners)[9 * f + t] = corners[t];
             }
         }
+#ifdef MLD_STAMPS
+        st.mark(12);
+        st.flush();
+#endif
     }
 }
 

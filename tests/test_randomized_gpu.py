@@ -82,6 +82,10 @@ def test_cloud_with_non_finite_and_duplicate_points():
     cloud[bad[300:450], 2] = -np.inf
     cloud[bad[450:500]] = 0.0                       # at the lidar origin
     cloud[bad[500:550], 0] = 0.27                   # z_cam == 0 for the synthetic mounting
+    # finite but enormous coordinates, straight ahead: the single-precision pre-cull overflows (inf / NaN intermediates)
+    # and must hand these points to the exact path, where they project into the image like any other point
+    cloud[bad[550:560], :3] = np.array([3e37, 1e35, -2e35], dtype=np.float32) * rng.uniform(0.5, 1.0, (10, 1)).astype(np.float32)
+    cloud[bad[560:570], :3] = np.array([2e38, -3e36, 1e36], dtype=np.float32) * rng.uniform(0.9, 1.0, (10, 1)).astype(np.float32)
     dup_src = rng.choice(n, 3000, replace=False)
     dup_dst = rng.choice(n, 3000, replace=False)
     cloud[dup_dst] = cloud[dup_src]
