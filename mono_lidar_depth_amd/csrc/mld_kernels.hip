@@ -294,14 +294,21 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
         const float zc = fmaf(T[8], x, fmaf(T[9], y, fmaf(T[10], z, t11)));
         // (m1 is NaN exactly when a coordinate is: such a point - a "no return" of an organised cloud - has a NaN camera
         // depth on the exact path and is never visible; without this test a single one keeps its whole group on the
-        // exact path.  Infinite or overflowing coordinates still fall through.)
-        bool pass = (i < n) && (m1 == m1) && !(zc < -fmaf(c.pcm[0], m1, c.pcm[1]));
-        if (!__any(pass)) continue;
-        const float xc = fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, t3)));
-        const float yc = fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, t7)));
-        const float qa = fmaf(c.ff, xc, c.cuf * zc), qb = fmaf(c.ff, yc, c.cvf * zc);  // ~ u*z, v*z
-        const float ma = fmaf(c.pcm[2], m1, c.pcm[3]), mb = fmaf(c.pcm[4], m1, c.pcm[5]);
-        pass = pass && !(qa < -ma) && !(fmaf(-Wf, zc, qa) > ma) && !(qb < -mb) && !(fmaf(-Hf, zc, qb) > mb);
+        // exact path.)
+        const bool fin = (m1 == m1);
+        bool pass = (i < n) && fin;
+        // A coordinate beyond 1e18 (or infinite) anywhere in the group: no tests for this group.  Single-precision
+        // products of such values overflow, and an overflowed +inf in "q - W z" would cull a point that the f64
+        // arithmetic projects into the image.  (Wave-uniform, and never taken for a real scan.)
+        if (!__any(fin && !(m1 < 1e18f))) {
+            pass = pass && !(zc < -fmaf(c.pcm[0], m1, c.pcm[1]));
+            if (!__any(pass)) continue;
+            const float xc = fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, t3)));
+            const float yc = fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, t7)));
+            const float qa = fmaf(c.ff, xc, c.cuf * zc), qb = fmaf(c.ff, yc, c.cvf * zc);  // ~ u*z, v*z
+            const float ma = fmaf(c.pcm[2], m1, c.pcm[3]), mb = fmaf(c.pcm[4], m1, c.pcm[5]);
+            pass = pass && !(qa < -ma) && !(fmaf(-Wf, zc, qa) > ma) && !(qb < -mb) && !(fmaf(-Hf, zc, qb) > mb);
+        }
         if (!__any(pass)) continue;
         // exact path (identical to the CPU arithmetic)
         const V3 pc = lidar_to_cam(c, (double)x, (double)y, (double)z);
