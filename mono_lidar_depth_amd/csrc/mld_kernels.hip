@@ -86,6 +86,8 @@ __device__ __forceinline__ int prefix_count(unsigned long long m) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// "any lane" straight from the comparison mask (__any() turns the predicate into an integer and compares it again)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, lane);
@@ -295,21 +297,26 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
         // (m1 is NaN exactly when a coordinate is: such a point - a "no return" of an organised cloud - has a NaN camera
         // depth on the exact path and is never visible; without this test a single one keeps its whole group on the
         // exact path.)
-        const bool fin = (m1 == m1);
-        bool pass = (i < n) && fin;
+        // (the lanes that are still candidates are kept as a 64-bit wave mask: every comparison lands in a scalar
+        // register pair and the combinations, the "any lane left?" tests included, run on the scalar unit)
+#define MLD_BALLOT(cond) __builtin_amdgcn_ballot_w64(cond)
+        unsigned long long pm = MLD_BALLOT(i < n) & MLD_BALLOT(m1 == m1);
         // A coordinate beyond 1e18 (or infinite) anywhere in the group: no tests for this group.  Single-precision
         // products of such values overflow, and an overflowed +inf in "q - W z" would cull a point that the f64
-        // arithmetic projects into the image.  (Wave-uniform, and never taken for a real scan.)
-        if (!__any(fin && !(m1 < 1e18f))) {
-            pass = pass && !(zc < -fmaf(c.pcm[0], m1, c.pcm[1]));
-            if (!__any(pass)) continue;
+        // arithmetic projects into the image.  (Never taken for a real scan.)
+        if (!(MLD_BALLOT(!(m1 < 1e18f)) & pm)) {
+            pm &= MLD_BALLOT(!(zc < -fmaf(c.pcm[0], m1, c.pcm[1])));
+            if (!pm) continue;
             const float xc = fmaf(T[0], x, fmaf(T[1], y, fmaf(T[2], z, t3)));
             const float yc = fmaf(T[4], x, fmaf(T[5], y, fmaf(T[6], z, t7)));
             const float qa = fmaf(c.ff, xc, c.cuf * zc), qb = fmaf(c.ff, yc, c.cvf * zc);  // ~ u*z, v*z
             const float ma = fmaf(c.pcm[2], m1, c.pcm[3]), mb = fmaf(c.pcm[4], m1, c.pcm[5]);
-            pass = pass && !(qa < -ma) && !(fmaf(-Wf, zc, qa) > ma) && !(qb < -mb) && !(fmaf(-Hf, zc, qb) > mb);
+            pm &= MLD_BALLOT(!(qa < -ma)) & MLD_BALLOT(!(fmaf(-Wf, zc, qa) > ma));
+            pm &= MLD_BALLOT(!(qb < -mb)) & MLD_BALLOT(!(fmaf(-Hf, zc, qb) > mb));
         }
-        if (!__any(pass)) continue;
+#undef MLD_BALLOT
+        if (!pm) continue;
+        const bool pass = (pm >> threadIdx.x % kWave) & 1ull;
         // exact path (identical to the CPU arithmetic)
         const V3 pc = lidar_to_cam(c, (double)x, (double)y, (double)z);
         // camera_pinhole.h:88-90 without the six products by zero of K: for finite points q0 = (f x + 0 y) + cu z,
@@ -341,13 +348,13 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
         uint32_t anyb = 0u;
 #pragma unroll
         for (int r = 0; r < kProjPerThread; r++) anyb |= bmb[r];
-        if (!__any(anyb != 0u)) return;
+        if (!wave_any(anyb != 0u)) return;
     }
 #pragma unroll
     for (int r = 0; r < kProjPerThread; r++) {
         // the four point groups of a wavefront are a quarter of a scan ring apart: usually only one or two of them are
         // in the camera's field of view
-        if (!__any(bmb[r] != 0u)) continue;
+        if (!wave_any(bmb[r] != 0u)) continue;
         int w = bmw[r];
         uint32_t bits = bmb[r];
         // DPP row shifts (no LDS traffic): runs are merged inside 16-lane rows; a row's last lane always writes
