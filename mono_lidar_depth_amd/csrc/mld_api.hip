@@ -131,6 +131,7 @@ struct mld_ctx {
     hipEvent_t side_done = nullptr;
     hipEvent_t order_ev = nullptr;  // mld_order_after
     size_t lds_fused_pad = 0;       // mld_set_shared_gpu
+    size_t lds_per_cu = 0;          // device property
     bool timing = false;
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
@@ -652,6 +653,7 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if ((e = hipSetDevice(device)) != hipSuccess) return hip_bail(e, "hipSetDevice");
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return hip_bail(e, "hipGetDeviceProperties");
+    ctx->lds_per_cu = (size_t)prop.maxSharedMemoryPerMultiProcessor;  // 160 KB on gfx950
     if (ctx->lds_bytes > (size_t)prop.sharedMemPerBlock) {
         mld_destroy(ctx);
         return bail(MLD_ERR_CAPACITY, "search window too large for the LDS-staged neighbour list");
@@ -804,8 +806,8 @@ int mld_set_shared_gpu(mld_ctx* ctx, int shared) {
     if (!ctx) return MLD_ERR_INVALID_ARG;
     // k_feature_fused is capped by its LDS request: 14 KB per wavefront -> 11 per CU (3 per SIMD, which is all the
     // VGPRs there are at 168 per wave); 20 KB -> 8 per CU, 2 per SIMD, and a third of the register file stays free
-    // for the projection wavefronts (56 VGPRs each) of a context running beside this one.
-    const size_t per_cu = 160 * 1024, want = per_cu / 8;
+    // for the projection wavefronts (48 VGPRs each) of a context running beside this one.
+    const size_t per_cu = ctx->lds_per_cu ? ctx->lds_per_cu : 160 * 1024, want = per_cu / 8;
     ctx->lds_fused_pad = (shared && ctx->lds_fused < want) ? want - ctx->lds_fused : 0;
     return MLD_OK;
 }
