@@ -237,6 +237,10 @@ constexpr int kProjPerThread = MLD_PROJ_PER_THREAD;
 __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc* __restrict__ slots, SlotDesc single,
                                                                   int use_single, Calib c, int n_slots, int per_slot,
                                                                   uint32_t tag_all) {
+    // Raised issue priority: beside another context's feature kernels (long f64 sequences, always ready to issue)
+    // the few instructions a projection wave needs between its loads and its atomics would otherwise wait their
+    // turn; measured side by side 0.843 -> 0.815 ms per 1024 frames, alone no difference.
+    __builtin_amdgcn_s_setprio(3);
     int slot, j;
     decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
     SlotDesc s = use_single ? single : slots[slot];
