@@ -285,8 +285,15 @@ class Resident:
         self.coeffs = np.stack([self.planes_h[b % U][0] for b in range(B)])
         torch.cuda.synchronize()
         NC = max(1, contexts)
-        self.S = S = slots if slots > 0 else B // NC
-        assert B % (S * NC) == 0, "--frames-per-step must be a multiple of --slots x --contexts"
+        # Default: every context holds the whole step (S = B frame slots) and consecutive steps alternate between the
+        # contexts, so the projection of step k+1 runs beside the feature kernels of step k.  With --slots S a step is
+        # cut into launch sets of S frames that are dealt to the contexts in turn.
+        self.whole = slots <= 0
+        self.S = S = B if self.whole else slots
+        assert B % S == 0 and (self.whole or (B // S) % NC == 0), "--frames-per-step must be a multiple of --slots x --contexts"
+        self.k = 0
+        self.est_batches = None
+        self.est_S = S if (not self.whole or NC == 1) else B // NC  # frame slots per launch of the plane-estimated leg
         self.ests = []
         for _ in range(NC):
             e = DepthEstimator(device=device, max_frames=S, max_features=F)  # queues allocated up front
@@ -298,16 +305,31 @@ class Resident:
         # a step walks the B resident frames in launch sets of S frame slots, dealt round-robin to the contexts (one HIP
         # stream each); the slots' pixel maps are reused from one launch set to the next
         rows = lambda t, i: [t[b] for b in range(i, i + S)]  # noqa: E731
-        self.batches = [(self.ests[(i // S) % NC], self.ests[(i // S) % NC].prepareBatch(
+        prep = lambda e, i: (e, e.prepareBatch(  # noqa: E731
             rows(self.all_clouds, i), rows(self.all_uvs, i), rows(self.all_depth, i), rows(self.all_type, i),
-            self.coeffs[i:i + S], rows(self.all_masks, i), stride_bytes=16)) for i in range(0, B, S)]
+            self.coeffs[i:i + S], rows(self.all_masks, i), stride_bytes=16))
+        if self.whole:
+            self.batches = [prep(e, 0) for e in self.ests]  # the same resident frames, one descriptor set per context
+        else:
+            self.batches = [prep(self.ests[(i // S) % NC], i) for i in range(0, B, S)]
 
     def run_step(self):
         # contexts in turn; the next context's projection is released by the end of this one's, so it streams its
         # clouds beside this context's feature kernels
         nb = len(self.batches)
+        if self.whole:
+            e, b = self.batches[self.k % nb]
+            e.runBatchBeside(b, self.batches[(self.k + 1) % nb][0])
+            self.k += 1
+            return
         for i, (e, b) in enumerate(self.batches):
             e.runBatchBeside(b, self.batches[(i + 1) % nb][0])
+
+    def last_context(self):
+        """The context whose slots hold the most recent launch set."""
+        if self.whole:
+            return self.batches[(self.k - 1) % len(self.batches)][0]
+        return self.batches[-1][0]
 
     def run_exclusive(self, n):
         """n passes of context 0's first launch set with nothing else on the GPU (kernel durations when each kernel has
@@ -321,7 +343,19 @@ class Resident:
         """The same pass with the ground plane of every frame ESTIMATED on the GPU (the reference's default call:
         the GroundPlane handed to setInputCloud is not segmented yet) instead of supplied."""
         import ctypes as C
-        for e, b in self.batches:
+        todo = self.batches
+        if self.whole and len(self.ests) > 1:
+            # (k_rs_batch does not fit beside the feature kernels - LDS -, so there is nothing to gain from alternating
+            # whole steps here: every context takes its share of the step's frames, side by side)
+            if self.est_batches is None:
+                NC, Sh = len(self.ests), self.B // len(self.ests)
+                rows = lambda t, i: [t[b] for b in range(i, i + Sh)]  # noqa: E731
+                self.est_batches = [(e, e.prepareBatch(rows(self.all_clouds, k * Sh), rows(self.all_uvs, k * Sh),
+                                                       rows(self.all_depth, k * Sh), rows(self.all_type, k * Sh),
+                                                       self.coeffs[k * Sh:(k + 1) * Sh], rows(self.all_masks, k * Sh),
+                                                       stride_bytes=16)) for k, e in enumerate(self.ests)]
+            todo = self.est_batches
+        for e, b in todo:
             n = b["n"]
             if "seeds" not in b:
                 b["seeds"] = (C.c_uint32 * n)(*range(1, n + 1))
@@ -388,39 +422,47 @@ def pmc_traffic(kernel, frames_per_launch):
         return None
 
 
-def kernel_times(est):
+def kernel_times(ests):
+    """Average launch duration per kernel over the timed launches of all the given contexts."""
+    ests = ests if isinstance(ests, (list, tuple)) else [ests]
     out = {}
     for name, k in (("k_project_scatter", K_PROJECT), ("k_classify", K_CLASSIFY), ("k_feature_fused", K_FUSED),
                     ("k_feature_wave", K_WAVE), ("k_rs_batch", K_RANSAC)):
-        ms, n = est.kernelTimeMs(k)
+        tot, n = 0.0, 0
+        for e in ests:
+            ms, m = e.kernelTimeMs(k)
+            tot += ms * m
+            n += m
         if n or k != K_RANSAC:
-            out[name] = {"avg_ms": ms, "launches": n}
+            out[name] = {"avg_ms": tot / n if n else 0.0, "launches": n}
     return out
 
 
 def timed_resident(res, steps, warmup, timing, timing_every, barrier=lambda: None, estimated=False):
     import torch
-    est = res.ests[0]
     step = res.run_step_estimated if estimated else res.run_step
     for _ in range(warmup):
         step()
     res.sync()
     if timing:
-        est.timingEnable(True)
-        est.timingReset()
+        for e in res.ests:
+            e.timingEnable(True)
+            e.timingReset()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(steps):
         if timing:
-            est.timingEnable(it % max(1, timing_every) == 0)  # sampled steps of the timed region
+            for e in res.ests:
+                e.timingEnable(it % max(1, timing_every) == 0)  # sampled steps of the timed region
         step()
     res.sync()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    kt = kernel_times(est) if timing else {}
-    est.timingEnable(False)
+    kt = kernel_times(res.ests) if timing else {}
+    for e in res.ests:
+        e.timingEnable(False)
     return elapsed, kt
 
 
@@ -641,7 +683,7 @@ def main():
         type_hist += est.resultHistogram(res.all_type[b])
     stat_slots = list(range(0, S, max(1, S // 4)))[:4]
     stats, design = [], []
-    last_est = res.batches[-1][0]
+    last_est = res.last_context()
     for b in stat_slots:
         fr = B - S + b  # the slots of the last launch set's context hold the last sub-batch of the step
         stats.append(traffic.frame_bytes(P, cam.width, cam.height, N, last_est.getVisibleCount(b), last_est.getPixelMap(b),
@@ -660,10 +702,12 @@ def main():
     # The dominant kernel by time.  k_project_scatter is the HBM-bound one (it streams every cloud once);
     # k_feature_fused is bound by the rate of divergent gathers and by f64 issue, not by HBM - its
     # figure below is the §8(d) per-feature formula over its launch time.
-    cand = {"k_project_scatter": ms("k_project_scatter"), "k_feature_fused": ms("k_feature_fused")}
-    dominant = max(cand, key=cand.get) if timing else "k_project_scatter"
-    dom_ms = cand.get(dominant, 0.0)
-    dom_bytes = design_project if dominant == "k_project_scatter" else formula_feature
+    # k_project_scatter is the kernel the HBM roof applies to (it streams every cloud once; 85 % of the step's HBM
+    # bytes); k_feature_fused, of about the same duration, is bound by the rate of divergent gathers and their latency
+    #  - it is listed under "kernels" with the §8(d) formula figure and its PMC traffic.
+    dominant = "k_project_scatter"
+    dom_ms = ms(dominant)
+    dom_bytes = design_project
     pmc = pmc_traffic(dominant, S)
     roofline = {
         "bound": "hbm",
@@ -677,8 +721,8 @@ def main():
         # two contexts: the projection of one runs beside the feature kernels of the other during the timed region, so
         # `frac` (priced on the launch duration measured THERE, as the contract asks) understates what the kernel does
         # with the chip to itself; `exclusive` prices the same bytes on the duration of a launch that runs alone
-        "concurrent": (f"{len(res.ests)} contexts: k_project_scatter of one beside k_classify / k_feature_fused / "
-                       "k_feature_wave of the other" if len(res.ests) > 1 else None),
+        "concurrent": (f"{len(res.ests)} contexts: k_project_scatter of one (step k+1) beside k_classify / k_feature_fused "
+                       "/ k_feature_wave of the other (step k)" if len(res.ests) > 1 else None),
         "exclusive": ({"kernel_ms": kt_x[dominant]["avg_ms"],
                        "achieved": gbps(dom_bytes, kt_x[dominant]["avg_ms"]),
                        "frac": gbps(dom_bytes, kt_x[dominant]["avg_ms"]) / HBM_PEAK_GBS,
@@ -701,7 +745,9 @@ def main():
                                   "formula_GBps": gbps(formula_project, ms("k_project_scatter"))},
             "k_classify": kt.get("k_classify", {}),
             "k_feature_fused": {**kt.get("k_feature_fused", {}), "formula_bytes_per_launch": formula_feature,
-                                "formula_GBps": gbps(formula_feature, ms("k_feature_fused"))},
+                                "formula_GBps": gbps(formula_feature, ms("k_feature_fused")),
+                                # not HBM-bound: what the counters saw it move (committed profile, kernel alone)
+                                "pmc_hbm_bytes_per_launch": (pmc_traffic("k_feature_fused", S) or [None])[0]},
             "k_feature_wave": kt.get("k_feature_wave", {}),
         },
         "whole_step_formula_GBps": ((formula_project + formula_feature) * (B // S) * args.steps / elapsed) / 1e9,
@@ -725,14 +771,15 @@ def main():
         for fr in (0, B - 1):
             ref = oracle.OracleDepthEstimator(P, cam_struct, T)
             ref.set_cloud(res.clouds_h[fr % U])
-            ref.estimate_ground_plane((fr % S) + 1)
+            ref.estimate_ground_plane((fr % res.est_S) + 1)
             d0, t0 = ref.calculate_depth(res.uvs_h[fr], 8)
             dg, tg = res.all_depth[fr].cpu().numpy(), res.all_type[fr].cpu().numpy()
             ok_e = ok_e and bool(np.array_equal(tg, t0) and np.allclose(dg, d0, rtol=0, atol=1e-4, equal_nan=True))
         n_e = max(2, args.steps // 2)
         estimated = {"plane": "estimated", "value": B * F * n_e / el_e, "ms_per_step": 1e3 * el_e / n_e,
                      "kernels_ms_per_launch": {k: v["avg_ms"] for k, v in kt_e.items()},
-                     "ransac_us_per_frame": 1e3 * kt_e.get("k_rs_batch", {}).get("avg_ms", 0.0) / S, "verified": ok_e}
+                     "ransac_us_per_frame": 1e3 * kt_e.get("k_rs_batch", {}).get("avg_ms", 0.0) / res.est_S,
+                     "frame_slots_per_launch": res.est_S, "verified": ok_e}
     if world == 1:
         if args.cpu_seconds > 0:
             cpu = cpu_baseline(P, cam_struct, T, res.clouds_h, res.planes_h, res.uvs_h, args.cpu_seconds)
@@ -773,7 +820,9 @@ def main():
             "frames_per_step": B,
             "frame_slots_per_launch": S,
             "contexts": args.contexts,
-            "schedule": ("contexts alternate; the projection of one runs beside the feature kernels of the other"
+            "schedule": (("consecutive steps alternate between the contexts" if args.slots <= 0 else
+                          "the launch sets of a step alternate between the contexts") +
+                         ": the projection of one runs beside the feature kernels of the other"
                          if args.contexts > 1 else "one stream, one kernel at a time"),
             "features_per_frame": F,
             "points_per_frame": N,

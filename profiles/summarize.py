@@ -25,8 +25,9 @@ if stats_x:
 lines = [f"# rocprofv3 summary — {tag}", "",
          "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 "
          "--cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0` (see profiles/run_profile.sh): the "
-         "bench default, two contexts of 512 frame slots alternating, so a projection runs BESIDE the other context's "
-         "feature kernels and the launch durations below are durations of kernels that share the GPU.  The second table "
+         "bench default, two contexts of 1024 frame slots, consecutive steps alternating between them, so the projection "
+         "of one step runs BESIDE the previous step's feature kernels and the launch durations below are durations of "
+         "kernels that share the GPU.  The second table "
          "is the same command with `--contexts 1` (one stream, 1024 frame slots per launch, every kernel alone).  PMC "
          "passes are separate runs with `--contexts 1 --pmc ...` (4 steps; rocprofv3 serialises the kernels there).", ""]
 
@@ -55,7 +56,7 @@ def table(path, title, bjson):
     return k, bb, out
 
 
-ks2, b2, t2 = table(stats, "two contexts alternating (bench default)", f"{src}/bench_trace.json")
+ks2, b2, t2 = table(stats, "two contexts, steps alternating (bench default)", f"{src}/bench_trace.json")
 lines += t2
 if stats_x:
     ks, b, t1 = table(stats_x, "one context (`--contexts 1`)", f"{src}/bench_trace_x.json")
