@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--slots", type=int, default=0,
                     help="frame slots of the context (0 = frames-per-step); a step runs frames-per-step/slots launch sets")
     ap.add_argument("--no-estimated", action="store_true", help="skip the plane-estimated leg")
+    ap.add_argument("--no-exclusive", action="store_true",
+                    help="skip the pass that times each kernel alone (profiling: keeps the kernel statistics of a trace "
+                         "to the launches of the timed schedule)")
     ap.add_argument("--contexts", type=int, default=2,
                     help="contexts (HIP streams) the frames of a step are dealt to in turn; with 2 the projection of one "
                          "context runs beside the feature kernels of the other (mld_order_after / mld_set_shared_gpu); "
@@ -670,7 +673,7 @@ def main():
     # runs a projection beside the other context's feature kernels, so a kernel's launch duration there is not its
     # speed; these are the durations one launch set takes alone
     kt_x = {}
-    if timing and len(res.ests) > 1:
+    if timing and len(res.ests) > 1 and not args.no_exclusive:
         res.run_exclusive(1)
         est.timingEnable(True)
         est.timingReset()

@@ -10,9 +10,12 @@ cd /tmp && export TMPDIR=/tmp
 COMMON="--cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0"
 ARGS="--steps 20 --warmup 3 $COMMON"
 # the bench default: two contexts alternating (a projection beside the other context's feature kernels)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.log
+# (only launches of the timed schedule in this trace: no plane-estimated leg, no kernels-alone pass)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS --no-estimated --no-exclusive > $OUT/bench_trace.json 2> $OUT/trace.log
 # one context, one kernel at a time: what each kernel takes with the GPU to itself (1024 frames per launch)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_x -- python3 $REPO/bench.py --contexts 1 $ARGS > $OUT/bench_trace_x.json 2> $OUT/trace_x.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_x -- python3 $REPO/bench.py --contexts 1 $ARGS --no-estimated > $OUT/bench_trace_x.json 2> $OUT/trace_x.log
+# the plane-estimated leg on its own (k_rs_batch)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_e -- python3 $REPO/bench.py --steps 2 --warmup 1 $COMMON --no-exclusive > $OUT/bench_trace_e.json 2> $OUT/trace_e.log
 # counters: rocprofv3 serialises the kernels in these passes, so they are collected on the one-context schedule
 PMCARGS="--contexts 1 --steps 4 --warmup 1 $COMMON --no-kernel-timing --no-estimated"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log

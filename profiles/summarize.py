@@ -25,7 +25,8 @@ if stats_x:
 lines = [f"# rocprofv3 summary — {tag}", "",
          "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 "
          "--cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0` (see profiles/run_profile.sh): the "
-         "bench default, two contexts of 1024 frame slots, consecutive steps alternating between them, so the projection "
+         "bench default (with `--no-estimated --no-exclusive`, so that only launches of the timed schedule are averaged), "
+         "two contexts of 1024 frame slots, consecutive steps alternating between them, so the projection "
          "of one step runs BESIDE the previous step's feature kernels and the launch durations below are durations of "
          "kernels that share the GPU.  The second table "
          "is the same command with `--contexts 1` (one stream, 1024 frame slots per launch, every kernel alone).  PMC "
@@ -63,6 +64,20 @@ if stats_x:
     lines += t1
 else:
     ks, b = ks2, b2
+stats_e = newest(f"{src}/trace_e/*/*kernel_stats.csv")
+if stats_e:
+    ke = pd.read_csv(stats_e)
+    ke = ke[ke.Name.str.contains("k_rs_batch")]
+    try:
+        be = json.loads(open(f"{src}/bench_trace_e.json").read().strip().splitlines()[-1])["plane_estimated"]
+        lines += ["## plane-estimated leg (same command with 2 steps; `k_rs_batch` only)", ""]
+        for _, r in ke.iterrows():
+            lines.append(f"`{r.Name.split('(')[0]}`: {r.Calls} calls, avg {r.AverageNs / 1e3:.1f} us "
+                         f"({be['frame_slots_per_launch']} frames per launch); bench.py: {be['ms_per_step']:.3f} ms per step, "
+                         f"{be['ransac_us_per_frame']:.2f} us of RANSAC per frame, verified {be['verified']}")
+        lines.append("")
+    except Exception as e:  # noqa: BLE001
+        lines += [f"(plane-estimated leg not parsed: {e})", ""]
 lines += ["## PMC (per launch, mean over launches)", "",
           "FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane) "
           "coalesced read (MI355X_MICROARCH.md §HBM): `hbm_read_corrected` doubles it for k_project_scatter "
