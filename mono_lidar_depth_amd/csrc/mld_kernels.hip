@@ -279,12 +279,10 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
     // translation terms of the single-precision transform: used by every point, kept in vector registers
     float t3 = c.Tf[3], t7 = c.Tf[7], t11 = c.Tf[11];
     asm volatile("" : "+v"(t3), "+v"(t7), "+v"(t11));
-    int bmw[kProjPerThread];       // occupancy-bitmap word of the point (or a unique negative value)
-    uint32_t bmb[kProjPerThread];  // its bit
 #pragma unroll
     for (int r = 0; r < kProjPerThread; r++) {
-        bmw[r] = -1 - (int)threadIdx.x;
-        bmb[r] = 0u;
+        int w = -1 - (int)threadIdx.x;  // occupancy-bitmap word of the point (or a unique negative value)
+        uint32_t bits = 0u;             // its bit
         const int i = base + r * kProjThreads;
         const float x = fx[r], y = fy[r], z = fz[r];
         // Conservative single-precision pre-cull.  86 % of a 360-degree scan is behind the camera or outside its
@@ -338,29 +336,16 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
             // (24-bit multiplies: image sides and the bitmap stride are far below 2^24)
             __hip_atomic_fetch_max(GPTRW(uint32_t, s.map) + (uint32_t)__mul24(yi, c.W) + (uint32_t)xi, key,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bmw[r] = __mul24(xi >> 5, c.bmStride) + yi;
-            bmb[r] = 1u << (xi & 31);
+            w = __mul24(xi >> 5, c.bmStride) + yi;
+            bits = 1u << (xi & 31);
         }
-    }
-    // Occupancy bits (lets the feature kernel skip the mostly empty key rows).  Consecutive lanes hold consecutive
-    // points of a scan ring, i.e. neighbouring pixels of one image row: bits of a run of lanes with the same bitmap
-    // word are OR-ed along the run and only the run's last lane issues the atomic (~10x fewer atomics).  Runs need
-    // not be exact: every lane's bit reaches the last lane of its contiguous run (within its 16-lane row), which
-    // always writes.
-    {
-        // three waves in four see no visible point at all (a 360-degree scan against an 81-degree camera)
-        uint32_t anyb = 0u;
-#pragma unroll
-        for (int r = 0; r < kProjPerThread; r++) anyb |= bmb[r];
-        if (!wave_any(anyb != 0u)) return;
-    }
-#pragma unroll
-    for (int r = 0; r < kProjPerThread; r++) {
-        // the four point groups of a wavefront are a quarter of a scan ring apart: usually only one or two of them are
-        // in the camera's field of view
-        if (!wave_any(bmb[r] != 0u)) continue;
-        int w = bmw[r];
-        uint32_t bits = bmb[r];
+        // Occupancy bits (lets the feature kernel skip the mostly empty key rows).  Consecutive lanes hold consecutive
+        // points of a scan ring, i.e. neighbouring pixels of one image row: bits of a run of lanes with the same
+        // bitmap word are OR-ed along the run and only the run's last lane issues the atomic (~10x fewer atomics).
+        // Runs need not be exact: every lane's bit reaches the last lane of its contiguous run (within its 16-lane
+        // row), which always writes.  (The four point groups of a wavefront are a quarter of a scan ring apart:
+        // usually only one or two of them reach this point.)
+        if (!wave_any(bits != 0u)) continue;
         // DPP row shifts (no LDS traffic): runs are merged inside 16-lane rows; a row's last lane always writes
 #define MLD_ROW_STEP(D)                                                                                     \
     {                                                                                                       \
