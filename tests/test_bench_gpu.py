@@ -40,3 +40,17 @@ def test_bench_single_rank_line_is_physical():
     assert 0.0 < r["frac"] <= 1.0
     assert r["kernels"]["k_project_scatter"]["frac"] <= 1.0
     assert out["verification"]["mismatching_frames"] == []
+
+
+def test_bench_schedules_agree():
+    """The default schedule (whole steps alternating between two contexts), launch sets of a step alternating
+    (`--slots`) and a single context produce verified lines with the schedule they name; the kernels-alone figures
+    appear only where two contexts share the GPU."""
+    a = _run(SMALL)
+    assert a["config"]["contexts"] == 2 and a["config"]["frame_slots_per_launch"] == 32
+    assert a["roofline"]["kernel"] == "k_project_scatter" and a["roofline"]["exclusive"]["frac"] > 0
+    b = _run(SMALL + ["--slots", "8"])
+    assert b["verified"] is True and b["config"]["frame_slots_per_launch"] == 8
+    c = _run(SMALL + ["--contexts", "1"])
+    assert c["verified"] is True and c["roofline"]["exclusive"] is None and c["config"]["contexts"] == 1
+    assert a["result_types"] == b["result_types"] == c["result_types"]
