@@ -177,7 +177,7 @@ int mld_synchronize(mld_ctx* ctx);
  *   finished (one event; no host synchronisation).  Both contexts must live on the same device.
  * mld_set_shared_gpu(ctx, 1): the lane-per-feature kernel of `ctx` keeps to two wavefronts per SIMD (it requests more
  *   LDS per block), which leaves registers for the other context's projection wavefronts on every CU.  A context that
- *   has the GPU to itself is ~5 % slower in this mode; the alternating pair is ~18 % faster (bench.py default:
+ *   has the GPU to itself is ~7 % slower in this mode; the alternating pair is ~18 % faster (bench.py default:
  *   0.78 instead of 0.95 ms per 1024 frames of config 2).
  */
 int mld_order_after(mld_ctx* ctx, mld_ctx* other);
