@@ -365,7 +365,8 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: per-feature depth.  One wavefront per 64 features.
+// Wave-cooperative per-feature depth (k_feature_wave: long lists, single frames, debug mode).  A wavefront takes the
+// queue entries of its block one feature at a time:
 //   phase 1 (lanes = window cells / neighbours, one feature at a time, wave-uniform control flow):
 //           window scan -> ordered neighbour list in LDS -> histogram segmentation -> max-spanning triangle
 //   phase 2 (lanes = features): planarity, viewing ray, ray/plane intersection, thresholds
@@ -1328,12 +1329,11 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
 }
 
 // ------------------------------------------------------------------------------------------------
-// Thread-per-feature path (lane = feature).  With the ~2-10 neighbours a 64-beam cloud gives a 7x10 window, a
-// wave-per-feature design leaves most lanes idle; here every lane walks its own short list.  The only per-thread
+// Lane-per-feature building blocks (k_feature_fused).  With the ~2-10 neighbours a 64-beam cloud gives a 7x10 window,
+// a wave-per-feature design leaves most lanes idle; here every lane walks its own short list.  The only per-lane
 // storage is the neighbour INDEX list in LDS (transposed, bank-conflict free); points are re-read from the cloud
-// (L1/L2 hits) and re-transformed where needed.  All loops over list entries run in the reference's serial order,
-// so even the weighted sums of the road path match the CPU order.  Features whose lists exceed the capacities
-// are flagged and handled by wave_path().
+// (L1/L2 hits) and re-transformed where needed.  All loops over list entries run in the reference's serial order.
+// Features whose lists exceed the capacities are queued for k_feature_wave.
 // ------------------------------------------------------------------------------------------------
 constexpr int kK1MaxLimit = 64;  // upper bound of Calib::k1max, the per-feature neighbour list capacity
                                  // (LDS: k1max entries x 64 lanes x 4 B per wave; relative bins need k1max < 254)
