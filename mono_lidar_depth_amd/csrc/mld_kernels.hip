@@ -193,20 +193,6 @@ __device__ __forceinline__ void load_point(const SlotDesc& s, long long i, doubl
         z = (double)GPTR(float, p)[2];
     }
 }
-// Streaming (non-temporal) variant for the one pass that reads every point exactly once.
-__device__ __forceinline__ void load_point_stream(const SlotDesc& s, long long i, double& x, double& y, double& z) {
-    const unsigned char* p = s.cloud + (size_t)i * (size_t)s.stride;
-    if ((((size_t)s.cloud) & 15) == 0) {
-        f32x4 q = __builtin_nontemporal_load(GPTR(f32x4, p));
-        x = (double)q.x;
-        y = (double)q.y;
-        z = (double)q.z;
-    } else {
-        x = (double)GPTR(float, p)[0];
-        y = (double)GPTR(float, p)[1];
-        z = (double)GPTR(float, p)[2];
-    }
-}
 __device__ __forceinline__ V3 lidar_to_cam(const Calib& c, double x, double y, double z) {
     V3 r;
     r.x = c.T[3] + ((c.T[0] * x + c.T[1] * y) + c.T[2] * z);
@@ -702,11 +688,6 @@ __device__ __forceinline__ double fast_rsq(double d) {  // d in (0, inf)
     e = fma(-h * y, y, 0.5);
     y = fma(y, e, y);
     return y;
-}
-__device__ __forceinline__ V3 fast_normalized(V3 a) {
-    const double z = vsqnorm(a);
-    if (z > 0.0) return vscale(a, fast_rsq(z));
-    return a;
 }
 
 // Cyclic Jacobi as jacobi_eig3 below, with the rotation angles from fast_rcp / fast_rsq: the rotations stay
@@ -1343,13 +1324,9 @@ constexpr int kTriSmall = 8;
 #define MLD_KZC 12
 #endif
 constexpr int kZc = MLD_KZC;      // list entries whose depth stays in registers over the histogram passes
-#ifndef MLD_KEY_BATCH
-#define MLD_KEY_BATCH 4
-#endif
 #ifndef MLD_ROAD_BATCH
 #define MLD_ROAD_BATCH 4
 #endif
-constexpr int kKeyBatch = MLD_KEY_BATCH;    // map keys fetched per round trip when cells become point indices
 constexpr int kRoadBatch = MLD_ROAD_BATCH;  // wide-window neighbours fetched per round trip by the road fallback
 constexpr int kBatch = 4;    // list entries fetched ahead of use in the per-lane list loops  // lists up to this length use the fully unrolled in-register triangle search
 
