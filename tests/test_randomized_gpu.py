@@ -126,3 +126,36 @@ def test_cloud_size_limit():
     d_big, t_big = est.CalculateDepth(uvd)
     d_small, t_small = small.CalculateDepth(uvd)
     assert torch.equal(t_big, t_small) and torch.equal(d_big, d_small)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_projection_over_extreme_magnitudes(seed):
+    """The single-precision pre-cull of k_project_scatter against the exact projection on coordinates spread over forty
+    decades (under- and overflowing its f32 intermediates), with a randomly rotated, slightly scaled lidar->camera
+    transform: the set of visible points and the pixel map are the oracle's, bit for bit."""
+    rng = np.random.default_rng(4200 + seed)
+    P = capi.params_c0().replace(do_use_ransac_plane=0)
+    n = 60000
+    mag = 10.0 ** rng.uniform(-20, 20, (n, 3))
+    sign = rng.choice([-1.0, 1.0], (n, 3))
+    pts = (mag * sign).astype(np.float32)
+    # half of the points: one dominant forward component, so that many land inside the image at every magnitude
+    fwd = rng.random(n) < 0.5
+    scale = 10.0 ** rng.uniform(-15, 30, n)
+    pts[fwd, 0] = (scale[fwd] * rng.uniform(1.0, 3.0, fwd.sum())).astype(np.float32)
+    pts[fwd, 1] = (scale[fwd] * rng.uniform(-1.0, 1.0, fwd.sum())).astype(np.float32)
+    pts[fwd, 2] = (scale[fwd] * rng.uniform(-0.4, 0.4, fwd.sum())).astype(np.float32)
+    cloud = np.zeros((n, 4), dtype=np.float32)
+    cloud[:, :3] = pts
+    base = synth.T_CAM_LIDAR[:, :3]
+    R = _rot(*np.deg2rad(rng.uniform(-10, 10, 3))) @ base * rng.uniform(0.5, 2.0)
+    T = np.concatenate([R, rng.uniform(-1, 1, 3)[:, None]], axis=1)
+    cam = CameraPinhole(1242, 375, 721.5377, 609.5593, 172.854)
+    uv = synth.make_features(50, seed=seed)
+    est = make_estimator(P, camera=cam, T=T)
+    d, t = est.CalculateDepth(cloud, uv, None)
+    ref, (d0, t0) = run_oracle(P, cloud, uv, None, camera=cam, T=T)
+    assert np.array_equal(est.getPointIndex(), ref.point_index())
+    assert np.array_equal(est.getPixelMap(), ref.pixel_map())
+    assert ref.point_index().size > 1000  # the case does exercise visible points
+    assert np.array_equal(t, t0)
