@@ -8,7 +8,7 @@ OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 COMMON="--cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0"
-ARGS="--steps 20 --warmup 3 $COMMON"
+ARGS="--steps 200 --warmup 5 $COMMON"
 # the bench default: two contexts alternating (a projection beside the other context's feature kernels)
 # (only launches of the timed schedule in this trace: no plane-estimated leg, no kernels-alone pass)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS --no-estimated --no-exclusive > $OUT/bench_trace.json 2> $OUT/trace.log

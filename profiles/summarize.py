@@ -23,7 +23,7 @@ stats_x = newest(f"{src}/trace_x/*/*kernel_stats.csv")
 if stats_x:
     shutil.copy(stats_x, f"profiles/{tag}_kernel_stats_one_context.csv")
 lines = [f"# rocprofv3 summary — {tag}", "",
-         "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 20 --warmup 3 "
+         "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 5 "
          "--cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0` (see profiles/run_profile.sh): the "
          "bench default (with `--no-estimated --no-exclusive`, so that only launches of the timed schedule are averaged), "
          "two contexts of 1024 frame slots, consecutive steps alternating between them, so the projection "
