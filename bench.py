@@ -55,6 +55,12 @@ def parse_args():
                     help="contexts (HIP streams) the frames of a step are dealt to in turn; with 2 the projection of one "
                          "context runs beside the feature kernels of the other (mld_order_after / mld_set_shared_gpu); "
                          "1 = everything on one stream, one kernel at a time")
+    ap.add_argument("--shared-mode", type=int, default=1,
+                    help="mld_set_shared_gpu argument of the alternating contexts: 1 = on; + 256 * n = n feature-kernel "
+                         "wavefronts per CU instead of 8")
+    ap.add_argument("--no-pair", action="store_true",
+                    help="two contexts: hand the projection over with mld_order_after (one event across streams) instead "
+                         "of running both contexts' projections on one shared stream (mld_pair_contexts)")
     ap.add_argument("--unique-frames", type=int, default=16, help="distinct synthetic clouds generated per rank")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -263,11 +269,13 @@ def streaming_leg(P, cam, T, clouds, planes, uvs, device, frames_per_batch, n_ba
 class Resident:
     """B device-resident frames (U distinct clouds, B distinct feature sets) and a context with S frame slots."""
 
-    def __init__(self, P, cam, T, scanner, B, U, F, seq, device, integer_uv=False, slots=0, contexts=1):
+    def __init__(self, P, cam, T, scanner, B, U, F, seq, device, integer_uv=False, slots=0, contexts=1, shared_mode=1,
+                 pair=True):
         import torch
         from mono_lidar_depth_amd import DepthEstimator, synth
         dev = torch.device("cuda", device)
         self.P, self.cam, self.T, self.B, self.F = P, cam, T, B, F
+        self.shared_mode = shared_mode
         self.clouds_h = [synth.make_cloud(scanner, seed=seq, frame=f) for f in range(U)]
         self.planes_h = [synth.make_ground_plane(c) for c in self.clouds_h]
         self.uvs_h = [synth.make_features(F, seed=seq * 100000 + b, integer=integer_uv) for b in range(B)]
@@ -305,8 +313,10 @@ class Resident:
             e.InitConfig(P)
             e.Initialize(cam, T)
             if NC > 1:
-                e.setSharedGpu(True)
+                e.setSharedGpu(shared_mode)
             self.ests.append(e)
+        if NC == 2 and pair:
+            self.ests[0].pairWith(self.ests[1])  # projections back to back on one stream
         # a step walks the B resident frames in launch sets of S frame slots, dealt round-robin to the contexts (one HIP
         # stream each); the slots' pixel maps are reused from one launch set to the next
         rows = lambda t, i: [t[b] for b in range(i, i + S)]  # noqa: E731
@@ -373,7 +383,7 @@ class Resident:
             e.synchronize()
 
     def close(self):
-        for e in self.ests:
+        for e in reversed(self.ests):  # a pair's borrower before the owner of the projection stream
             e.close()
 
     def verify(self, n_slots):
@@ -648,7 +658,8 @@ def main():
     B, F = args.frames_per_step, args.features
     U = max(1, min(args.unique_frames, B))
     seq = sharding.assign_sequences(world, world)[rank][0]  # one sequence per rank (config 4 layout)
-    res = Resident(P, cam, T, synth.HDL64, B, U, F, seq, gpu_index, slots=args.slots, contexts=args.contexts)
+    res = Resident(P, cam, T, synth.HDL64, B, U, F, seq, gpu_index, slots=args.slots, contexts=args.contexts,
+                   shared_mode=args.shared_mode, pair=not args.no_pair)
     S, N = res.S, res.N
 
     def barrier():
@@ -771,7 +782,7 @@ def main():
             e.setSharedGpu(False)
         el_e, kt_e = timed_resident(res, max(2, args.steps // 2), 2, timing, 2, estimated=True)
         for e in res.ests:
-            e.setSharedGpu(len(res.ests) > 1)
+            e.setSharedGpu(res.shared_mode if len(res.ests) > 1 else 0)
         ok_e = True
         for fr in (0, B - 1):
             ref = oracle.OracleDepthEstimator(P, cam_struct, T)

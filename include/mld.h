@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MLD_ABI_VERSION 4
+#define MLD_ABI_VERSION 5
 
 typedef enum mld_status {
     MLD_OK = 0,
@@ -178,9 +178,19 @@ int mld_synchronize(mld_ctx* ctx);
  * mld_set_shared_gpu(ctx, 1): the lane-per-feature kernel of `ctx` keeps to two wavefronts per SIMD (it requests more
  *   LDS per block), which leaves registers for the other context's projection wavefronts on every CU.  A context that
  *   has the GPU to itself is ~7 % slower in this mode; the alternating pair is ~18 % faster (bench.py default:
- *   0.78 instead of 0.95 ms per 1024 frames of config 2).
+ *   0.78 instead of 0.95 ms per 1024 frames of config 2).  `shared`: bit 0 = on; bits 8..15 = wavefronts of the
+ *   lane-per-feature kernel per CU in that mode (0 = the default, 8): fewer leave more of every CU to the projection.
  */
 int mld_order_after(mld_ctx* ctx, mld_ctx* other);
+/*
+ * mld_pair_contexts(a, b): the batched setInputCloud entry points (mld_set_clouds_*_device) of BOTH contexts run their
+ *   projection on one stream created here (owned by `a`), back to back in call order, while each context's feature
+ *   kernels stay on its own stream (two events per batch join them).  With the schedule above this replaces
+ *   mld_order_after: the projection of batch i+1 follows that of batch i without a cross-stream hand-over (~50 us per
+ *   1024-frame batch) and still runs beside the feature kernels of batch i.  A projection waits for everything queued on
+ *   its own context before (the kernels still reading the slots' maps).  Destroy `b` before `a`.
+ */
+int mld_pair_contexts(mld_ctx* a, mld_ctx* b);
 int mld_set_shared_gpu(mld_ctx* ctx, int shared);
 
 /*
@@ -316,6 +326,27 @@ int mld_tracklets_depth(mld_ctx* ctx, int slot_cur, int slot_last, const float* 
                         const float* u_old, const float* v_old, const uint8_t* is_new, int64_t n_tracks,
                         float* d_cur_out, float* d_last_out, int32_t* type_cur_out, int32_t* type_last_out,
                         int64_t* n_new_host);
+/*
+ * The tracklet layer at batch size: the current frames of n_seq independent SEQUENCES in one launch set
+ * (TrackletDepthModule::process, tracklet_depth_module.cpp:261-396, once per sequence).  The context's frame slots are
+ * used as two banks of n_seq slots (create the context with max_frames >= 2 * n_seq): sequence s keeps its current
+ * frame in slot bank_cur * n_seq + s and its previous frame, still resident, in slot (1 - bank_cur) * n_seq + s; the
+ * caller flips bank_cur every frame.
+ *   mld_set_clouds_planes_range_device  setInputCloud(cloud, plane) for the slots [first_slot, first_slot + n_slots)
+ *                                       (coeffs / mask_dev: both or neither), i.e. for one bank
+ *   mld_tracklets_depths_device         gather -> depth of every track's newest feature on the current frame and of the
+ *                                       NEW tracks' previous features on the previous frame (have_last == 0: no previous
+ *                                       clouds yet, those depths are -1) -> float32 scatter; arrays of n_seq device
+ *                                       pointers / counts, indexing and meaning per sequence as mld_tracklets_depth_device
+ * Asynchronous on the context's stream; per-sequence results equal n_seq single-sequence calls.
+ */
+int mld_set_clouds_planes_range_device(mld_ctx* ctx, int first_slot, int n_slots, const void* const* pts_dev,
+                                       const int64_t* n, int stride_bytes, const float* coeffs,
+                                       const uint32_t* const* mask_dev);
+int mld_tracklets_depths_device(mld_ctx* ctx, int n_seq, int bank_cur, int have_last, const float* const* u_new,
+                                const float* const* v_new, const float* const* u_old, const float* const* v_old,
+                                const uint8_t* const* is_new, const int64_t* n_tracks, float* const* d_cur_out,
+                                float* const* d_last_out, int32_t* const* type_cur_out, int32_t* const* type_last_out);
 
 /*
  * Debug / parity getters (host buffers; each synchronises).

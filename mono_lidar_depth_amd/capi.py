@@ -12,7 +12,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libmld_hip.so"
 
-MLD_ABI_VERSION = 4  # include/mld.h
+MLD_ABI_VERSION = 5  # include/mld.h
 MLD_OK = 0
 MLD_ERR_INVALID_ARG = -1
 MLD_ERR_NOT_INITIALIZED = -2
@@ -120,6 +120,7 @@ _SIGNATURES = [
     ("mld_get_stream", C.c_void_p, [C.c_void_p]),
     ("mld_synchronize", C.c_int, [C.c_void_p]),
     ("mld_order_after", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("mld_pair_contexts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mld_set_shared_gpu", C.c_int, [C.c_void_p, C.c_int]),
     ("mld_set_cloud", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     ("mld_set_cloud_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
@@ -150,6 +151,10 @@ _SIGNATURES = [
      [C.c_void_p] * 4 + [_P(C.c_int64)]),
     ("mld_tracklets_depth", C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int64] +
      [C.c_void_p] * 4 + [_P(C.c_int64)]),
+    ("mld_set_clouds_planes_range_device", C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_void_p), _P(C.c_int64), C.c_int,
+                                                     _P(C.c_float), _P(C.c_void_p)]),
+    ("mld_tracklets_depths_device", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [_P(C.c_void_p)] * 5 +
+     [_P(C.c_int64)] + [_P(C.c_void_p)] * 4),
     ("mld_get_visible_count", C.c_int, [C.c_void_p, C.c_int, _P(C.c_int64)]),
     ("mld_get_visible_image_points", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),
     ("mld_get_point_index", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]),

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -115,6 +116,12 @@ struct mld_ctx {
     int32_t* trk_rank = nullptr;
     long long* trk_n_new = nullptr;
     size_t trk_cap = 0;
+    // batched tracklet layer (mld_tracklets_depths_device): per-sequence scratch, one allocation per kind
+    unsigned char* trkb = nullptr;   // [uv_cur | uv_last | depth_cur | depth_last | type_cur | type_last | rank | n_new]
+    size_t trkb_cap = 0;             // tracks per sequence
+    int trkb_seqs = 0;
+    TrkSeq* trkb_desc = nullptr;     // device copy of the per-sequence descriptors
+    std::vector<TrkSeq> trkb_host;
     // staging for the host-pointer tracklet entry point
     unsigned char* trk_stage = nullptr;
     size_t trk_stage_cap = 0;
@@ -130,7 +137,14 @@ struct mld_ctx {
     hipStream_t side = nullptr;  // the plane's inlier mask is built here while the cloud is still in flight
     hipEvent_t side_done = nullptr;
     hipEvent_t order_ev = nullptr;  // mld_order_after
+    // mld_pair_contexts: the batched projections of two contexts share ONE stream (back to back, no cross-stream
+    // hand-over between them); each context's feature kernels stay on its own stream, joined by two events per batch
+    hipStream_t proj_stream = nullptr;  // nullptr: projections run on `stream`
+    bool proj_owned = false;
+    hipEvent_t proj_fork = nullptr, proj_join = nullptr;
     size_t lds_fused_pad = 0;       // mld_set_shared_gpu
+    int fused_blocks_per_cu = 8;    // mld_set_shared_gpu: wavefronts of k_feature_fused per CU in the shared mode
+    int classify_threads = 1024;    // mld_set_shared_gpu bits 1..2: 256- / 512-thread k_classify blocks
     size_t lds_per_cu = 0;          // device property
     bool timing = false;
     std::vector<TimedLaunch> timed;
@@ -245,6 +259,39 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
         c.pcm[4] = (float)(e * (fa * (double)c.Tfmax[1] + va * (double)c.Tfmax[2]) * up);
         c.pcm[5] = (float)(e * (fa * ty + va * tz) * up);
     }
+    {
+        // How far T^-1 (T p + t) + t' can land from p when evaluated in f64 (DepthEstimator.cpp:810 after :169-173): the
+        // residual of the computed inverse (in long double) plus a generous bound on the roundings of the two products.
+        // k_project_scatter's single-precision far test treats a point as undecided within a margin built on this.
+        long double lin = 0.0L, cst = 0.0L, mlin = 0.0L, mcst = 0.0L;
+        for (int i = 0; i < 3; i++) {
+            long double rl = 0.0L, ml = 0.0L;
+            for (int j = 0; j < 3; j++) {
+                long double rij = (i == j) ? -1.0L : 0.0L, mij = 0.0L;
+                for (int k = 0; k < 3; k++) {
+                    rij += (long double)c.Tinv[4 * i + k] * (long double)T[4 * k + j];
+                    mij += fabsl((long double)c.Tinv[4 * i + k]) * fabsl((long double)T[4 * k + j]);
+                }
+                rl += fabsl(rij);
+                ml += mij;
+            }
+            long double ri = (long double)c.Tinv[4 * i + 3], mi = fabsl((long double)c.Tinv[4 * i + 3]);
+            for (int k = 0; k < 3; k++) {
+                ri += (long double)c.Tinv[4 * i + k] * (long double)T[4 * k + 3];
+                mi += fabsl((long double)c.Tinv[4 * i + k]) * fabsl((long double)T[4 * k + 3]);
+            }
+            lin = std::max(lin, rl);
+            mlin = std::max(mlin, ml);
+            cst = std::max(cst, fabsl(ri));
+            mcst = std::max(mcst, mi);
+        }
+        const long double u64 = 1.1102230246251565e-16L;
+        const long double el = lin + 64.0L * u64 * mlin, ec = cst + 64.0L * u64 * mcst;
+        const float inf = std::numeric_limits<float>::infinity();
+        c.far_elin = (std::isfinite((double)el) && el < 1e30L) ? (float)((double)el * 1.000001) : inf;
+        c.far_econst = (std::isfinite((double)ec) && ec < 1e30L) ? (float)((double)ec * 1.000001) : inf;
+        if (!(c.far_elin > 0.f)) c.far_elin = 1e-37f;  // (never below what a float can hold)
+    }
     c.W = ctx->cam.width;
     c.H = ctx->cam.height;
     c.bmStride = (ctx->cam.height + 16 + 3) / 4 * 4;  // words per 32-pixel column: H rows + 16 rows of read slack
@@ -311,6 +358,27 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     ctx->lds_classify = cls_fixed + (ctx->classify_staged ? cls_bitmap : 0);
 }
 
+// Batched projections of a paired context (mld_pair_contexts) run on the pair's projection stream: it first waits for
+// everything queued on the context's own stream so far (the feature kernels that still read the slots' maps), and the
+// context's stream then waits for the projection.  Unpaired: both are the context's own stream, nothing to do.
+hipStream_t projection_fork(mld_ctx* ctx, int& rc) {
+    rc = MLD_OK;
+    if (!ctx->proj_stream) return ctx->stream;
+    hipError_t e = hipEventRecord(ctx->proj_fork, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->proj_stream, ctx->proj_fork, 0);
+    if (e != hipSuccess) {
+        ctx->err = std::string("projection stream (fork): ") + hipGetErrorString(e);
+        rc = MLD_ERR_HIP;
+    }
+    return ctx->proj_stream;
+}
+int projection_join(mld_ctx* ctx) {
+    if (!ctx->proj_stream) return MLD_OK;
+    HIP_TRY(ctx, hipEventRecord(ctx->proj_join, ctx->proj_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->proj_join, 0));
+    return MLD_OK;
+}
+
 int check_slot(mld_ctx* ctx, int slot) {
     if (!ctx) return MLD_ERR_INVALID_ARG;
     if (slot < 0 || slot >= (int)ctx->slots.size()) return fail(ctx, MLD_ERR_INVALID_ARG, "slot out of range");
@@ -351,33 +419,40 @@ struct ScopedTimer {
     mld_ctx* ctx;
     TimedLaunch t{};
     bool on;
-    ScopedTimer(mld_ctx* c, int which) : ctx(c), on(c->timing) {
+    hipStream_t st;
+    ScopedTimer(mld_ctx* c, int which, hipStream_t stream = nullptr) : ctx(c), on(c->timing), st(stream ? stream : c->stream) {
         if (on) {
             t.e0 = get_event(ctx);
             t.e1 = get_event(ctx);
             t.which = which;
-            (void)hipEventRecord(t.e0, ctx->stream);
+            (void)hipEventRecord(t.e0, st);
         }
     }
     ~ScopedTimer() {
         if (on) {
-            (void)hipEventRecord(t.e1, ctx->stream);
+            (void)hipEventRecord(t.e1, st);
             ctx->timed.push_back(t);
         }
     }
 };
 
-// New cloud for a slot: bump the map tag (zero-fill on wrap), forget the previous plane / debug data.
-int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int stride, bool clear_bitmap = true) {
+int check_cloud_args(mld_ctx* ctx, const void* dev_ptr, int64_t n, int stride) {
     if (n < 0 || n > kMaxPoints) return fail(ctx, MLD_ERR_CAPACITY, "cloud larger than 8 388 607 points");
     if (stride != 16 && stride != 32) return fail(ctx, MLD_ERR_INVALID_ARG, "stride_bytes must be 16 or 32");
     if (!dev_ptr && n > 0) return fail(ctx, MLD_ERR_INVALID_ARG, "null cloud pointer");
     if (((size_t)dev_ptr & 3) != 0) return fail(ctx, MLD_ERR_INVALID_ARG, "cloud pointer must be 4-byte aligned");
-    if (clear_bitmap) HIP_TRY(ctx, hipMemsetAsync(s.d.bitmap, 0, ctx->bitmap_words * sizeof(uint32_t), ctx->stream));
+    return MLD_OK;
+}
+
+// New cloud for a slot: bump the map tag (zero-fill on wrap), forget the previous plane / debug data.
+int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int stride, bool clear_bitmap = true,
+                hipStream_t st = nullptr) {
+    if (!st) st = ctx->stream;
+    if (int rc = check_cloud_args(ctx, dev_ptr, n, stride)) return rc;
+    if (clear_bitmap) HIP_TRY(ctx, hipMemsetAsync(s.d.bitmap, 0, ctx->bitmap_words * sizeof(uint32_t), st));
     if (s.d.tag >= kMaxTag) {
         HIP_TRY(ctx, hipMemsetAsync(s.d.map, 0,
-                                    ((size_t)ctx->cam.width * ctx->cam.height + kMapPadCells) * sizeof(uint32_t),
-                                    ctx->stream));
+                                    ((size_t)ctx->cam.width * ctx->cam.height + kMapPadCells) * sizeof(uint32_t), st));
         s.d.tag = 1;
     } else {
         s.d.tag += 1;
@@ -399,24 +474,26 @@ int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int strid
 
 // The map tag shared by slots [0, n_slots), or 0 when they differ (then the per-slot tags of the uploaded
 // descriptors are used).
-uint32_t common_tag(mld_ctx* ctx, int n_slots) {
-    const uint32_t t = ctx->slots[0].d.tag;
+uint32_t common_tag(mld_ctx* ctx, int n_slots, int first = 0) {
+    const uint32_t t = ctx->slots[first].d.tag;
     for (int i = 1; i < n_slots; i++)
-        if (ctx->slots[i].d.tag != t) return 0u;
+        if (ctx->slots[first + i].d.tag != t) return 0u;
     return t;
 }
 
-int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int slot) {
+int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int slot, hipStream_t st = nullptr) {
+    if (!st) st = ctx->stream;
     if (max_n <= 0) return MLD_OK;
     const int per_block = kProjThreads * kProjPerThread;
     int per_slot = (int)((max_n + per_block - 1) / per_block);
-    ScopedTimer tm(ctx, 0);
+    ScopedTimer tm(ctx, 0, st);
     if (single) {
-        hipLaunchKernelGGL(k_project_scatter, dim3(per_slot), dim3(kProjThreads), 0, ctx->stream, ctx->d_slots,
+        hipLaunchKernelGGL(k_project_scatter, dim3(per_slot), dim3(kProjThreads), 0, st, ctx->d_slots,
                            ctx->slots[slot].d, 1, ctx->calib, 1, per_slot, 0u);
     } else {
-        hipLaunchKernelGGL(k_project_scatter, dim3((unsigned)per_slot * n_slots), dim3(kProjThreads), 0, ctx->stream,
-                           ctx->d_slots, SlotDesc{}, 0, ctx->calib, n_slots, per_slot, common_tag(ctx, n_slots));
+        // (batch: the slots [slot, slot + n_slots))
+        hipLaunchKernelGGL(k_project_scatter, dim3((unsigned)per_slot * n_slots), dim3(kProjThreads), 0, st,
+                           ctx->d_slots + slot, SlotDesc{}, 0, ctx->calib, n_slots, per_slot, common_tag(ctx, n_slots, slot));
     }
     HIP_TRY(ctx, hipGetLastError());
     return MLD_OK;
@@ -461,9 +538,18 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
                            dim3(mld::kFewThreads), 0, ctx->stream, one, calib);
     } else {
         ScopedTimer ts(ctx, 5);
-        auto kc = ctx->classify_staged ? mld::k_classify<true> : mld::k_classify<false>;
-        hipLaunchKernelGGL(kc, dim3((unsigned)ns), dim3(kClsThreads), ctx->lds_classify, ctx->stream, ctx->d_slots, one,
-                           use_single, calib, ctx->bm_ncol, ctx->bm_ncolp);
+        if (ctx->classify_staged && ctx->classify_threads == 256) {
+            hipLaunchKernelGGL((mld::k_classify<true, 256, 8>), dim3((unsigned)ns), dim3(256), ctx->lds_classify, ctx->stream,
+                               ctx->d_slots, one, use_single, calib, ctx->bm_ncol, ctx->bm_ncolp);
+        } else if (ctx->classify_staged && ctx->classify_threads == 512) {
+            hipLaunchKernelGGL((mld::k_classify<true, 512, 4>), dim3((unsigned)ns), dim3(512), ctx->lds_classify, ctx->stream,
+                               ctx->d_slots, one, use_single, calib, ctx->bm_ncol, ctx->bm_ncolp);
+        } else {
+            auto kc = ctx->classify_staged ? mld::k_classify<true, kClsThreads, kClsKeep>
+                                           : mld::k_classify<false, kClsThreads, kClsKeep>;
+            hipLaunchKernelGGL(kc, dim3((unsigned)ns), dim3(kClsThreads), ctx->lds_classify, ctx->stream, ctx->d_slots, one,
+                               use_single, calib, ctx->bm_ncol, ctx->bm_ncolp);
+        }
     }
     if (calib.threadPath) {
         ScopedTimer tm(ctx, 1);
@@ -486,12 +572,13 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     return MLD_OK;
 }
 
-int upload_descs(mld_ctx* ctx, int n_slots) {
+int upload_descs(mld_ctx* ctx, int n_slots, hipStream_t st = nullptr, int first = 0, bool tags_in_descs = false) {
+    if (!st) st = ctx->stream;
     // Steady-state batches (same buffers every step) change nothing but the map tags, and a tag common to the
     // batch travels as a kernel argument: skip the upload when the device copy is still right.
-    const bool tags_by_arg = common_tag(ctx, n_slots) != 0u;
+    const bool tags_by_arg = !tags_in_descs && common_tag(ctx, n_slots, first) != 0u;
     bool dirty = false;
-    for (int i = 0; i < n_slots; i++) {
+    for (int i = first; i < first + n_slots; i++) {
         SlotDesc d = ctx->slots[i].d;
         if (tags_by_arg) d.tag = 0;
         if (std::memcmp(&d, &ctx->h_descs[i], sizeof(SlotDesc)) != 0) {
@@ -501,8 +588,8 @@ int upload_descs(mld_ctx* ctx, int n_slots) {
     }
     if (!dirty) return MLD_OK;
     // pageable source: the runtime stages it before returning, so h_descs may be rewritten afterwards
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slots, ctx->h_descs.data(), sizeof(SlotDesc) * n_slots, hipMemcpyHostToDevice,
-                                ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slots + first, ctx->h_descs.data() + first, sizeof(SlotDesc) * n_slots,
+                                hipMemcpyHostToDevice, st));
     return MLD_OK;
 }
 
@@ -666,8 +753,14 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
         if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute(k_feature_wave)");
     }
     if (ctx->lds_classify > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_classify<true>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_classify<true, kClsThreads, kClsKeep>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_classify);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_classify<true, 256, 8>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_classify);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_classify<true, 512, 4>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_classify);
         if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute(k_classify)");
     }
     if (ctx->lds_fused > 48 * 1024) {
@@ -759,6 +852,8 @@ void mld_destroy(mld_ctx* ctx) {
                    ctx->rs_counts, ctx->rs_inl, ctx->rs_res, ctx->sem_img, ctx->sem_coeffs, ctx->sem_res};
     for (void* p : rsp)
         if (p) (void)hipFree(p);
+    if (ctx->trkb) (void)hipFree(ctx->trkb);
+    if (ctx->trkb_desc) (void)hipFree(ctx->trkb_desc);
     void* trk[] = {ctx->trk_uv_cur, ctx->trk_uv_last, ctx->trk_depth_cur, ctx->trk_depth_last, ctx->trk_type_cur,
                    ctx->trk_type_last, ctx->trk_rank, ctx->trk_n_new, ctx->trk_stage};
     for (void* p : trk)
@@ -771,6 +866,10 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->side_done) (void)hipEventDestroy(ctx->side_done);
     if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
+    if (ctx->proj_stream) (void)hipStreamSynchronize(ctx->proj_stream);
+    if (ctx->proj_fork) (void)hipEventDestroy(ctx->proj_fork);
+    if (ctx->proj_join) (void)hipEventDestroy(ctx->proj_join);
+    if (ctx->proj_stream && ctx->proj_owned) (void)hipStreamDestroy(ctx->proj_stream);
     for (TimedLaunch& t : ctx->timed) {
         (void)hipEventDestroy(t.e0);
         (void)hipEventDestroy(t.e1);
@@ -786,7 +885,24 @@ void* mld_get_stream(mld_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; 
 
 int mld_synchronize(mld_ctx* ctx) {
     if (!ctx) return MLD_ERR_INVALID_ARG;
+    // (work on a pair's projection stream is always joined into the context's own stream before the call returns)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MLD_OK;
+}
+
+int mld_pair_contexts(mld_ctx* a, mld_ctx* b) {
+    if (!a || !b || a == b) return MLD_ERR_INVALID_ARG;
+    if (a->device != b->device) return fail(a, MLD_ERR_INVALID_ARG, "contexts live on different devices");
+    if (a->proj_stream || b->proj_stream) return fail(a, MLD_ERR_INVALID_ARG, "context already paired");
+    int rc = bind_device(a);
+    if (rc) return rc;
+    HIP_TRY(a, hipStreamCreateWithFlags(&a->proj_stream, hipStreamNonBlocking));
+    a->proj_owned = true;
+    b->proj_stream = a->proj_stream;
+    for (mld_ctx* c : {a, b}) {
+        HIP_TRY(c, hipEventCreateWithFlags(&c->proj_fork, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->proj_join, hipEventDisableTiming));
+    }
     return MLD_OK;
 }
 
@@ -807,8 +923,12 @@ int mld_set_shared_gpu(mld_ctx* ctx, int shared) {
     // k_feature_fused is capped by its LDS request: 14 KB per wavefront -> 11 per CU (3 per SIMD, which is all the
     // VGPRs there are at 168 per wave); 20 KB -> 8 per CU, 2 per SIMD, and a third of the register file stays free
     // for the projection wavefronts (48 VGPRs each) of a context running beside this one.
-    const size_t per_cu = ctx->lds_per_cu ? ctx->lds_per_cu : 160 * 1024, want = per_cu / 8;
-    ctx->lds_fused_pad = (shared && ctx->lds_fused < want) ? want - ctx->lds_fused : 0;
+    ctx->classify_threads = (shared & 2) ? 256 : ((shared & 4) ? 512 : 1024);
+    int blocks = (shared >> 8) & 0xFF;  // bits 8..15: wavefronts per CU (0 = the default, 8)
+    if (blocks <= 0) blocks = 8;
+    ctx->fused_blocks_per_cu = blocks;
+    const size_t per_cu = ctx->lds_per_cu ? ctx->lds_per_cu : 160 * 1024, want = (per_cu / (size_t)blocks) & ~(size_t)255;
+    ctx->lds_fused_pad = ((shared & 1) && ctx->lds_fused < want) ? want - ctx->lds_fused : 0;
     return MLD_OK;
 }
 
@@ -839,21 +959,27 @@ int mld_set_cloud(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, int s
 // setInputCloud for slots [0, n_slots) in one launch; coeffs / mask_dev (both or neither): the ground planes, known
 // before the projection, whose inlier flags then travel in the map keys.
 static int set_clouds_common(mld_ctx* ctx, int n_slots, const void* const* pts_dev, const int64_t* n, int stride_bytes,
-                             const float* coeffs, const uint32_t* const* mask_dev) {
+                             const float* coeffs, const uint32_t* const* mask_dev, int first = 0) {
     if (!ctx) return MLD_ERR_INVALID_ARG;
-    if (n_slots < 1 || n_slots > (int)ctx->slots.size() || !pts_dev || !n)
+    if (n_slots < 1 || first < 0 || first + n_slots > (int)ctx->slots.size() || !pts_dev || !n)
         return fail(ctx, MLD_ERR_INVALID_ARG, "bad slot count / null arrays");
     int rc = bind_device(ctx);
     if (rc) return rc;
     if (mask_dev)
         for (int i = 0; i < n_slots; i++)
             if (!mask_dev[i]) return fail(ctx, MLD_ERR_INVALID_ARG, "null mask");
+    // every slot's arguments are checked before anything is queued or any slot state changes
+    for (int i = 0; i < n_slots; i++)
+        if ((rc = check_cloud_args(ctx, pts_dev[i], n[i], stride_bytes))) return rc;
     int64_t max_n = 0;
+    hipStream_t st = projection_fork(ctx, rc);
+    if (rc) return rc;
     // the slots' occupancy bitmaps are contiguous: one fill for the whole batch
-    HIP_TRY(ctx, hipMemsetAsync(ctx->bitmaps, 0, ctx->bitmap_words * (size_t)n_slots * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->bitmaps + (size_t)first * ctx->bitmap_words, 0,
+                                ctx->bitmap_words * (size_t)n_slots * sizeof(uint32_t), st));
     for (int i = 0; i < n_slots; i++) {
-        Slot& s = ctx->slots[i];
-        if ((rc = begin_cloud(ctx, s, pts_dev[i], n[i], stride_bytes, false))) return rc;
+        Slot& s = ctx->slots[first + i];
+        if ((rc = begin_cloud(ctx, s, pts_dev[i], n[i], stride_bytes, false, st))) return rc;
         if (coeffs) {
             set_plane_coeffs(s, coeffs + 4 * i);
             s.d.inlier_mask = mask_dev[i];
@@ -861,8 +987,9 @@ static int set_clouds_common(mld_ctx* ctx, int n_slots, const void* const* pts_d
         }
         max_n = std::max(max_n, n[i]);
     }
-    if ((rc = upload_descs(ctx, n_slots))) return rc;
-    return launch_project(ctx, n_slots, max_n, false, 0);
+    if ((rc = upload_descs(ctx, n_slots, st, first))) return rc;
+    if ((rc = launch_project(ctx, n_slots, max_n, false, first, st))) return rc;
+    return projection_join(ctx);
 }
 
 int mld_set_clouds_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev, const int64_t* n, int stride_bytes) {
@@ -873,6 +1000,15 @@ int mld_set_clouds_planes_device(mld_ctx* ctx, int n_slots, const void* const* p
                                  const float* coeffs, const uint32_t* const* mask_dev) {
     if (ctx && (!coeffs || !mask_dev)) return fail(ctx, MLD_ERR_INVALID_ARG, "null plane arrays");
     return set_clouds_common(ctx, n_slots, pts_dev, n, stride_bytes, coeffs, mask_dev);
+}
+
+// The same for the slots [first_slot, first_slot + n_slots): the batched tracklet layer keeps the current frames of its
+// sequences in one bank of slots and the previous frames in the other.
+int mld_set_clouds_planes_range_device(mld_ctx* ctx, int first_slot, int n_slots, const void* const* pts_dev,
+                                       const int64_t* n, int stride_bytes, const float* coeffs,
+                                       const uint32_t* const* mask_dev) {
+    if (ctx && ((coeffs == nullptr) != (mask_dev == nullptr))) return fail(ctx, MLD_ERR_INVALID_ARG, "coeffs and masks: both or neither");
+    return set_clouds_common(ctx, n_slots, pts_dev, n, stride_bytes, coeffs, mask_dev, first_slot);
 }
 
 // setInputCloud for slots [0, n_slots) with the ground plane ESTIMATED for every slot (the reference's default: the
@@ -903,6 +1039,9 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
         }
         return MLD_OK;
     }
+    // every slot's arguments are checked before anything is queued or any slot state changes
+    for (int i = 0; i < n_slots; i++)
+        if ((rc = check_cloud_args(ctx, pts_dev[i], n[i], stride_bytes))) return rc;
     int64_t max_n = 0;
     for (int i = 0; i < n_slots; i++) max_n = std::max(max_n, n[i]);
     const size_t words = (size_t)((max_n + 31) / 32) + 1;
@@ -921,31 +1060,34 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
     }
+    hipStream_t st = projection_fork(ctx, rc);
+    if (rc) return rc;
     // occupancy bitmaps and inlier masks of the batch: one fill each
-    HIP_TRY(ctx, hipMemsetAsync(ctx->bitmaps, 0, ctx->bitmap_words * (size_t)n_slots * sizeof(uint32_t), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->rsb_masks, 0, ctx->rsb_mask_words * (size_t)n_slots * sizeof(uint32_t), ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->rsb_seeds, seeds, (size_t)n_slots * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->bitmaps, 0, ctx->bitmap_words * (size_t)n_slots * sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->rsb_masks, 0, ctx->rsb_mask_words * (size_t)n_slots * sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->rsb_seeds, seeds, (size_t)n_slots * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     for (int i = 0; i < n_slots; i++) {
         Slot& s = ctx->slots[i];
-        if ((rc = begin_cloud(ctx, s, pts_dev[i], n[i], stride_bytes, false))) return rc;
+        if ((rc = begin_cloud(ctx, s, pts_dev[i], n[i], stride_bytes, false, st))) return rc;
         s.d.inlier_mask = ctx->rsb_masks + (size_t)i * ctx->rsb_mask_words;
         s.d.mask_in_key = 1;
         s.d.plane_dev = ctx->rsb_planes + i;
         s.d.has_plane = 1;  // the device copy decides (PlaneDev::has_plane)
         s.plane_decided = true;
     }
-    if ((rc = upload_descs(ctx, n_slots))) return rc;
+    if ((rc = upload_descs(ctx, n_slots, st))) return rc;
     {
-        ScopedTimer tm(ctx, 4);
+        ScopedTimer tm(ctx, 4, st);
         const size_t lds = (size_t)kSample * 4 * sizeof(float) + (size_t)kPartials * 9 * sizeof(float) +
                            (2 * kRsRound + 8) * sizeof(int);
-        hipLaunchKernelGGL(k_rs_batch, dim3((unsigned)n_slots), dim3(kRsThreads), lds, ctx->stream, ctx->d_slots, ctx->rsb_seeds,
+        hipLaunchKernelGGL(k_rs_batch, dim3((unsigned)n_slots), dim3(kRsThreads), lds, st, ctx->d_slots, ctx->rsb_seeds,
                            n_draws, P.ransac_plane_max_iterations, P.ransac_plane_probability,
                            P.ransac_plane_distance_treshold, P.ransac_plane_refinement_treshold,
                            P.ransac_plane_use_refinement, ctx->rsb_planes);
         HIP_TRY(ctx, hipGetLastError());
     }
-    return launch_project(ctx, n_slots, max_n, false, 0);
+    if ((rc = launch_project(ctx, n_slots, max_n, false, 0, st))) return rc;
+    return projection_join(ctx);
 }
 
 // The planes of the last mld_set_clouds_estimate_planes_device: coefficients (n_slots x 4), inlier counts and status
@@ -1598,6 +1740,112 @@ int mld_tracklets_depth_device(mld_ctx* ctx, int slot_cur, int slot_last, const 
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         *n_new_host = (int64_t)nn;
     }
+    return MLD_OK;
+}
+
+// TrackletDepthModule::process (tracklet_depth_module.cpp:261-396) for the current frames of n_seq SEQUENCES in one
+// launch set.  The context's frame slots form two banks of n_seq slots: sequence s has its current frame in slot
+// bank_cur * n_seq + s (cloud and plane set with mld_set_clouds_planes_range_device) and its previous frame, still
+// resident, in slot (1 - bank_cur) * n_seq + s.  One gather launch, k_classify -> k_feature_fused -> k_feature_wave over
+// all 2 * n_seq slots (the previous-frame slots evaluate the previous features of the NEW tracks only), one scatter
+// launch.  Asynchronous; per-sequence results are identical to n_seq calls of mld_tracklets_depth_device.
+int mld_tracklets_depths_device(mld_ctx* ctx, int n_seq, int bank_cur, int have_last, const float* const* u_new,
+                                const float* const* v_new, const float* const* u_old, const float* const* v_old,
+                                const uint8_t* const* is_new, const int64_t* n_tracks, float* const* d_cur_out,
+                                float* const* d_last_out, int32_t* const* type_cur_out, int32_t* const* type_last_out) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    if (n_seq < 1 || 2 * n_seq > (int)ctx->slots.size() || (bank_cur != 0 && bank_cur != 1))
+        return fail(ctx, MLD_ERR_INVALID_ARG, "bad sequence count / bank (the context needs 2 * n_seq frame slots)");
+    if (!u_new || !v_new || !u_old || !v_old || !is_new || !n_tracks || !d_cur_out || !d_last_out)
+        return fail(ctx, MLD_ERR_INVALID_ARG, "null tracklet array");
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    int64_t max_n = 0;
+    const int cur0 = bank_cur * n_seq, last0 = (1 - bank_cur) * n_seq;
+    for (int q = 0; q < n_seq; q++) {
+        if (n_tracks[q] < 0) return fail(ctx, MLD_ERR_INVALID_ARG, "negative track count");
+        if (n_tracks[q] > 0 && (!u_new[q] || !v_new[q] || !u_old[q] || !v_old[q] || !is_new[q] || !d_cur_out[q] || !d_last_out[q]))
+            return fail(ctx, MLD_ERR_INVALID_ARG, "null tracklet array");
+        if ((rc = precheck_calc(ctx, ctx->slots[cur0 + q], n_tracks[q]))) return rc;
+        if (have_last && (rc = precheck_calc(ctx, ctx->slots[last0 + q], n_tracks[q]))) return rc;
+        max_n = std::max(max_n, n_tracks[q]);
+    }
+    if (max_n == 0) return MLD_OK;
+    if (ctx->P.set_all_depths_to_zero) return fail(ctx, MLD_ERR_UNSUPPORTED_MODE, "set_all_depths_to_zero: use the per-sequence call");
+    // scratch: per sequence cap tracks of [uv_cur 16 | uv_last 16 | depth_cur 8 | depth_last 8 | type_cur 4 | type_last 4 |
+    // rank 4] bytes, then the new-track counters
+    if ((size_t)max_n > ctx->trkb_cap || n_seq > ctx->trkb_seqs || !ctx->trkb) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->trkb) HIP_TRY(ctx, hipFree(ctx->trkb));
+        if (ctx->trkb_desc) HIP_TRY(ctx, hipFree(ctx->trkb_desc));
+        ctx->trkb = nullptr;
+        ctx->trkb_desc = nullptr;
+        const size_t cap = ((size_t)std::max<int64_t>(max_n, (int64_t)ctx->trkb_cap) + 63) & ~(size_t)63;
+        const int seqs = std::max(n_seq, ctx->trkb_seqs);
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->trkb, (size_t)seqs * (cap * 60 + 64)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->trkb_desc, (size_t)seqs * sizeof(TrkSeq)));
+        ctx->trkb_cap = cap;
+        ctx->trkb_seqs = seqs;
+    }
+    const size_t cap = ctx->trkb_cap, per_seq = cap * 60 + 64;
+    ctx->trkb_host.resize((size_t)n_seq);
+    for (int q = 0; q < n_seq; q++) {
+        unsigned char* base = ctx->trkb + (size_t)q * per_seq;
+        TrkSeq& t = ctx->trkb_host[(size_t)q];
+        t.u_new = u_new[q];
+        t.v_new = v_new[q];
+        t.u_old = u_old[q];
+        t.v_old = v_old[q];
+        t.is_new = is_new[q];
+        t.n = n_tracks[q];
+        t.uv_cur = reinterpret_cast<double*>(base);
+        t.uv_last = reinterpret_cast<double*>(base + cap * 16);
+        double* depth_cur = reinterpret_cast<double*>(base + cap * 32);
+        double* depth_last = reinterpret_cast<double*>(base + cap * 40);
+        int32_t* type_cur = reinterpret_cast<int32_t*>(base + cap * 48);
+        int32_t* type_last = reinterpret_cast<int32_t*>(base + cap * 52);
+        t.rank = reinterpret_cast<int32_t*>(base + cap * 56);
+        t.n_new = reinterpret_cast<long long*>(base + cap * 60);
+        t.depth_cur = depth_cur;
+        t.depth_last = depth_last;
+        t.type_cur = type_cur;
+        t.type_last = type_last;
+        t.d_cur_out = d_cur_out[q];
+        t.d_last_out = d_last_out[q];
+        t.type_cur_out = type_cur_out ? type_cur_out[q] : nullptr;
+        t.type_last_out = type_last_out ? type_last_out[q] : nullptr;
+        t.have_last = have_last ? 1 : 0;
+        t.pad_ = 0;
+        // the two slots of the sequence: every track on the current frame, the new tracks' previous features on the
+        // previous frame (their number is only known on the device)
+        Slot& sc = ctx->slots[cur0 + q];
+        sc.d.uv = t.uv_cur;
+        sc.d.F = t.n;
+        sc.d.F_dev = nullptr;
+        sc.d.depth = depth_cur;
+        sc.d.type = type_cur;
+        if ((rc = ensure_queues(ctx, sc, t.n))) return rc;
+        Slot& sl = ctx->slots[last0 + q];
+        sl.d.uv = t.uv_last;
+        sl.d.F = have_last ? t.n : 0;
+        sl.d.F_dev = have_last ? t.n_new : nullptr;
+        sl.d.depth = depth_last;
+        sl.d.type = type_last;
+        if (have_last && (rc = ensure_queues(ctx, sl, t.n))) return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->trkb_desc, ctx->trkb_host.data(), (size_t)n_seq * sizeof(TrkSeq), hipMemcpyHostToDevice,
+                                ctx->stream));
+    const unsigned chunks = (unsigned)((max_n + kTrkBlock - 1) / kTrkBlock);
+    hipLaunchKernelGGL(k_tracklets_gather, dim3(chunks, (unsigned)n_seq), dim3(kTrkBlock), 0, ctx->stream, ctx->trkb_desc);
+    HIP_TRY(ctx, hipGetLastError());
+    // one launch set over both banks; the banks carry different map tags, so the descriptors hold them
+    if ((rc = upload_descs(ctx, 2 * n_seq, nullptr, 0, true))) return rc;
+    rc = launch_features(ctx, 2 * n_seq, max_n, false, 0);
+    for (int q = 0; q < n_seq; q++) ctx->slots[last0 + q].d.F_dev = nullptr;  // (the uploaded copy keeps it)
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tracklets_scatter, dim3((unsigned)((max_n + 255) / 256), (unsigned)n_seq), dim3(256), 0, ctx->stream,
+                       ctx->trkb_desc);
+    HIP_TRY(ctx, hipGetLastError());
     return MLD_OK;
 }
 

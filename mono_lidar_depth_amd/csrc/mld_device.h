@@ -6,17 +6,24 @@
 namespace mld {
 
 constexpr int kWave = 64;
-// pixel-map key: [tag:8 | (0x7FFFFF - origIdx):23 | ground-plane inlier:1]; atomicMax keeps the smallest original
-// index of the newest tag (indices are unique, so the flag bit never decides)
+// pixel-map key: [tag:7 | (0x7FFFFF - origIdx):23 | ground-plane state:2]; atomicMax keeps the smallest original index
+// of the newest tag (indices are unique, so the state bits never decide).  The state is valid when the plane was known
+// at projection time (SlotDesc::mask_in_key): what CalculateDepthSegmentationPlane (DepthEstimator.cpp:782-900) asks
+// about the point - 0 near the plane, not an inlier; 1 near, inlier; 2 farther than the distance threshold (:810-815);
+// 3 too close to the threshold for the projection's single-precision test: the feature kernel decides exactly.
 constexpr uint32_t kIdxBits = 24;
 constexpr uint32_t kIdxMask = (1u << kIdxBits) - 1u;  // list entries keep the point index in their low 24 bits
+constexpr uint32_t kTagShift = 25;                    // map keys: the tag sits above index and flags
 constexpr uint32_t kKeyIdxMax = (1u << 23) - 1u;
 constexpr int64_t kMaxPoints = (int64_t)kKeyIdxMax;  // points per cloud representable in a key
-__host__ __device__ inline uint32_t make_key(uint32_t tag, uint32_t idx, uint32_t inlier) {
-    return (tag << kIdxBits) | ((kKeyIdxMax - idx) << 1) | (inlier & 1u);
+enum : uint32_t { kPtNear = 0u, kPtInlier = 1u, kPtFar = 2u, kPtUnsure = 3u };
+__host__ __device__ inline uint32_t make_key(uint32_t tag, uint32_t idx, uint32_t flags) {
+    return (tag << kTagShift) | ((kKeyIdxMax - idx) << 2) | (flags & 3u);
 }
-__host__ __device__ inline uint32_t key_index(uint32_t key) { return kKeyIdxMax - ((key & kIdxMask) >> 1); }
-constexpr uint32_t kMaxTag = 255;
+__host__ __device__ inline uint32_t key_index(uint32_t key) { return kKeyIdxMax - ((key >> 2) & kKeyIdxMax); }
+constexpr uint32_t kMaxTag = 127;
+// list entries of the fused kernel: [narrow window:1 | ground-plane state:2 | ... | point index:24]
+constexpr uint32_t kEntStateShift = 29, kEntNarrow = 1u << 31;
 constexpr int kMapPadCells = 16;  // the thread path reads rows with 16-byte loads that may overrun the last cell
 
 // Per-context constants, passed to every kernel by value (kernarg segment -> SGPRs / scalar loads).
@@ -28,10 +35,12 @@ struct Calib {
     float Tf[12];           // single-precision copies for the conservative pre-cull of k_project_scatter
     float Tfmax[3];  // max |Tf[r][0..2]| per row, rounded up (bounds of the f32 pre-cull)
     float ff, cuf, cvf;
-    float padf_;
+    float far_elin;  // |T^-1 (T p + t) + t' - p| <= far_elin * (|x|+|y|+|z|) + far_econst in the f64 round trip of
+                     // DepthEstimator.cpp:810 (host-computed residual + rounding bound; k_project_scatter's far test)
     // margins of the pre-cull as linear functions of m1 = |x|+|y|+|z| (rounded up): z test pcm[0] m1 + pcm[1], u tests
     // pcm[2] m1 + pcm[3], v tests pcm[4] m1 + pcm[5]
     float pcm[6];
+    float far_econst;
     double halfX1, halfY1;  // main search window half sizes  (scale 1.0, 1.0)
     double halfX2, halfY2;  // road search window half sizes  (scale 2.0, 1.5)
     double binW;
@@ -94,7 +103,23 @@ struct SlotDesc {
     int stride;
     uint32_t tag;  // current map tag, 1..255
     int has_plane;
-    int mask_in_key;  // 1: the inlier flag of every map key is valid (the plane was known when the cloud was projected)
+    int mask_in_key;  // 1: the inlier / far flags of every map key are valid (the plane was known when the cloud was projected)
+};
+
+// One sequence of the batched tracklet layer (mld_tracklets_depths_device): the arrays of
+// TrackletDepthModule::process (tracklet_depth_module.cpp:261-396) for that sequence's current frame.
+struct TrkSeq {
+    const float *u_new, *v_new, *u_old, *v_old;  // newest / previous feature of every track
+    const uint8_t* is_new;
+    long long n;                    // tracks
+    double *uv_cur, *uv_last;       // marshalled features (2 x n column-major; uv_last compacted to the new tracks)
+    int32_t* rank;                  // rank among the new tracks, or -1
+    long long* n_new;               // number of new tracks (device)
+    const double *depth_cur, *depth_last;
+    const int32_t *type_cur, *type_last;
+    float *d_cur_out, *d_last_out;  // FeaturePoint.d of the newest / previous features
+    int32_t *type_cur_out, *type_last_out;
+    int have_last, pad_;
 };
 
 }  // namespace mld

@@ -17,10 +17,10 @@
 // Pixel map encoding.  The reference map holds the VISIBLE index of the first point (in cloud order,
 // with z_cam > 0) that falls into the pixel.  Visible indices preserve cloud order, so "first visible
 // index" == "smallest ORIGINAL index".  The device map stores
-//     key = tag << 24 | (0x7FFFFF - origIdx) << 1 | inlier     (atomicMax: smallest origIdx of the newest tag wins;
-//                                                                 inlier = ground-plane flag, when known at projection)
+//     key = tag << 25 | (0x7FFFFF - origIdx) << 2 | state   (atomicMax: smallest origIdx of the newest tag wins;
+//                                      state = the point's relation to the ground plane, when known at projection)
 // where tag is bumped per setInputCloud, which makes clearing the 1.86 MB map unnecessary (a stale key has
-// a smaller tag and loses / is ignored).  The map is zero-filled when the tag wraps (every 255 frames).
+// a smaller tag and loses / is ignored).  The map is zero-filled when the tag wraps (every 127 frames).
 // Neighbours are re-derived from the raw float point at gather time (bit-identical arithmetic), so no
 // camera-frame copy of the cloud is ever written.
 #include "mld_device.h"
@@ -212,7 +212,10 @@ __device__ __forceinline__ void project(const Calib& c, V3 p, double& u, double&
 // ------------------------------------------------------------------------------------------------
 // K1: projection + pixel-map scatter
 // ------------------------------------------------------------------------------------------------
-constexpr int kProjThreads = 256;
+#ifndef MLD_PROJ_THREADS
+#define MLD_PROJ_THREADS 256
+#endif
+constexpr int kProjThreads = MLD_PROJ_THREADS;
 #ifndef MLD_PROJ_PER_THREAD
 #define MLD_PROJ_PER_THREAD 4
 #endif
@@ -229,8 +232,28 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
     __builtin_amdgcn_s_setprio(3);
     int slot, j;
     decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
-    SlotDesc s = use_single ? single : slots[slot];
+    SlotDesc s = use_single ? single : slots[slot];  // block-uniform: scalar loads, field by field
     if (tag_all) s.tag = tag_all;
+    // Ground-plane state of the visible points (rides in the map keys when the plane is already known).  "Far" is the
+    // distance test of CalculateDepthSegmentationPlane (DepthEstimator.cpp:810-815): camera -> lidar in f64, float,
+    // un-normalised float plane distance > threshold - a property of the point alone.  The f64 round trip returns the
+    // raw float coordinates up to e = far_elin * m1 + far_econst (host bound), so the distance evaluated on the RAW
+    // floats differs from the reference's by at most cs (2^-24 m1 + 2 e) + 8 * 2^-24 (cs m1 + |d|), cs = |a|+|b|+|c|: a
+    // point is marked far / near only beyond a margin of several times that, otherwise "unsure" (exact test in the
+    // feature kernel; a handful of points per frame at most).
+    const bool flags_on = s.mask_in_key != 0;
+    float pa = s.coeffs[0], pb = s.coeffs[1], pcz = s.coeffs[2], pd = s.coeffs[3];
+    if (flags_on && s.plane_dev) {  // the plane of a batched estimation lives in device memory
+        const auto* q = GPTR(PlaneDev, s.plane_dev);
+        pa = q->coeffs[0];
+        pb = q->coeffs[1];
+        pcz = q->coeffs[2];
+        pd = q->coeffs[3];
+    }
+    const float thrf = (float)c.roadDistThr;
+    const float pcs = (fabsf(pa) + fabsf(pb) + fabsf(pcz)) * 1.001f;
+    const float fmg0 = (2e-6f * pcs + 4.f * pcs * c.far_elin) * 1.001f;
+    const float fmg1 = (2e-6f * fabsf(pd) + 4.f * pcs * c.far_econst + 2e-7f * fabsf(thrf)) * 1.001f + 1e-30f;
     // 32-bit index and offset arithmetic throughout: a cloud has at most 2^23 - 1 points of 16 or 32 bytes
     const int n = (int)s.n;
     const int blk0 = j * (kProjThreads * kProjPerThread);
@@ -316,9 +339,14 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
         // inclusive test of camera_pinhole.h:93-95)
         if (pass && (pc.z > 0.0) && (u > 0.0) && (u < Wd) && (v > 0.0) && (v < Hd)) {
             const int xi = (int)u, yi = (int)v;  // truncation, NeighborFinderPixel.cpp:41-42
-            uint32_t inl = 0u;
-            if (s.mask_in_key) inl = (GPTR(uint32_t, s.inlier_mask)[(uint32_t)i >> 5] >> ((uint32_t)i & 31u)) & 1u;
-            const uint32_t key = make_key(s.tag, (uint32_t)i, inl);
+            uint32_t fl = 0u;
+            if (flags_on) {
+                const uint32_t inl = (GPTR(uint32_t, s.inlier_mask)[(uint32_t)i >> 5] >> ((uint32_t)i & 31u)) & 1u;
+                const float dr = fabsf(pa * x + pb * y + pcz * z + pd);
+                fl = (dr > thrf) ? (uint32_t)kPtFar : inl;
+                if (!(fabsf(dr - thrf) > fmaf(fmg0, m1, fmg1))) fl = kPtUnsure;  // (a NaN distance is "unsure" too)
+            }
+            const uint32_t key = make_key(s.tag, (uint32_t)i, fl);
             // (24-bit multiplies: image sides and the bitmap stride are far below 2^24)
             __hip_atomic_fetch_max(GPTRW(uint32_t, s.map) + (uint32_t)__mul24(yi, c.W) + (uint32_t)xi, key,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -402,7 +430,7 @@ __device__ int gather_window(const Calib& c, const SlotDesc& s, double u, double
             int row = (int)(((float)cidx + 0.5f) * rnx);
             int col = cidx - row * nx;
             uint32_t key = GPTR(uint32_t, s.map)[(size_t)(x0 + col) + (size_t)(y0 + row) * (size_t)c.W];
-            has = (key >> kIdxBits) == s.tag;
+            has = (key >> kTagShift) == s.tag;
             orig = (int)key_index(key);
         }
         unsigned long long m = __ballot(has);
@@ -1538,7 +1566,68 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
     double sw = 0, mx = 0, my = 0, mz = 0;
     double q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
     const V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
-    const bool keyInl = s.mask_in_key != 0;
+    // one inlier of the plane: depth / lateral extent of the set and West's update of the weighted mean and scatter
+    auto add_inlier = [&](const V3 p) {
+        if (p.z < zmn) zmn = p.z;
+        if (p.z > zmx) zmx = p.z;
+        if (p.x < xmn) xmn = p.x;
+        if (p.x > xmx) xmx = p.x;
+        if (roadMode == 0) {
+            const double w = fast_rcp(fabs(vdot(pn, p) + s.prior_off));  // PlaneEstimationMEstimator.cpp:32
+            const double swn = sw + w;
+            const double r = w * fast_rcp(swn);
+            const double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
+            mx = fma(dx, r, mx);
+            my = fma(dy, r, my);
+            mz = fma(dz, r, mz);
+            const double ex = p.x - mx, ey = p.y - my, ez = p.z - mz;
+            const double wdx = w * dx, wdy = w * dy, wdz = w * dz;
+            q0 = fma(wdx, ex, q0);
+            q1 = fma(wdx, ey, q1);
+            q2 = fma(wdx, ez, q2);
+            q3 = fma(wdy, ey, q3);
+            q4 = fma(wdy, ez, q4);
+            q5 = fma(wdz, ez, q5);
+            sw = swn;
+        }
+    };
+    // The plane was known when the cloud was projected: every entry carries its point's state (k_project_scatter).
+    // Whether the estimator runs at all (:591: no far point, at least three inliers) is then decided from the list
+    // alone, and only the inliers' points are fetched - in list order, as the serial loop meets them.  A wavefront
+    // that holds an "unsure" entry (|distance - threshold| within the projection's single-precision margin) takes the
+    // general loop below.
+    bool by_state = false;
+    if (s.mask_in_key) {
+        bool unsure = false;
+        for (int e = 0; e < n2max; e++) {
+            const uint32_t st = (e < n2) ? ((LST(min(e, c.k1max - 1)) >> kEntStateShift) & 3u) : 0u;
+            far = far || (st == kPtFar);
+            unsure = unsure || (st == kPtUnsure);
+        }
+        by_state = !wave_any(unsure);
+        if (!by_state) far = false;
+    }
+    if (by_state) {
+        const int n2f = far ? 0 : n2;  // :591 a far point in the window: the feature keeps the main path's result
+        const int n2fmax = uniform(wave_max_i32(n2f));
+        for (int e = 0; e < n2fmax; e++) {
+            const uint32_t ent = (e < n2f) ? LST(min(e, c.k1max - 1)) : 0u;
+            if (((ent >> kEntStateShift) & 3u) == kPtInlier) {
+                LST(kk) = ent & kIdxMask;  // kk <= e: entries not yet read are never overwritten
+                kk++;
+            }
+        }
+        const int ni = (cand && !far && kk >= 3) ? kk : 0;
+        const int nimax = uniform(wave_max_i32(ni));
+        for (int e0 = 0; e0 < nimax; e0 += kRoadBatch) {
+            RawP rp[kRoadBatch];
+#pragma unroll
+            for (int q = 0; q < kRoadBatch; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ni));
+#pragma unroll
+            for (int q = 0; q < kRoadBatch; q++)
+                if (e0 + q < ni) add_inlier(raw_point(c, rp[q]));
+        }
+    } else {
     for (int e0 = 0; e0 < n2max; e0 += kRoadBatch) {
         RawP rp[kRoadBatch];
         uint32_t ids[kRoadBatch], mw[kRoadBatch];
@@ -1547,8 +1636,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
             const uint32_t ent = (e0 + q < n2) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
             ids[q] = ent & kIdxMask;
             rp[q] = load_raw(s, ids[q]);
-            // the inlier flag travels in the map key when the plane was known at projection time (bit 30 of the entry)
-            mw[q] = keyInl ? ((ent >> 30) << (ids[q] & 31u)) : GPTR(uint32_t, s.inlier_mask)[ids[q] >> 5];
+            mw[q] = GPTR(uint32_t, s.inlier_mask)[ids[q] >> 5];
         }
 #pragma unroll
         for (int q = 0; q < kRoadBatch; q++) {
@@ -1565,31 +1653,11 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
             if (inl) {
                 LST(kk) = id;
                 kk++;
-                if (p.z < zmn) zmn = p.z;
-                if (p.z > zmx) zmx = p.z;
-                if (p.x < xmn) xmn = p.x;
-                if (p.x > xmx) xmx = p.x;
-                if (roadMode == 0) {
-                    const double w = fast_rcp(fabs(vdot(pn, p) + s.prior_off));  // PlaneEstimationMEstimator.cpp:32
-                    const double swn = sw + w;
-                    const double r = w * fast_rcp(swn);
-                    const double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
-                    mx = fma(dx, r, mx);
-                    my = fma(dy, r, my);
-                    mz = fma(dz, r, mz);
-                    const double ex = p.x - mx, ey = p.y - my, ez = p.z - mz;
-                    const double wdx = w * dx, wdy = w * dy, wdz = w * dz;
-                    q0 = fma(wdx, ex, q0);
-                    q1 = fma(wdx, ey, q1);
-                    q2 = fma(wdx, ez, q2);
-                    q3 = fma(wdy, ey, q3);
-                    q4 = fma(wdy, ez, q4);
-                    q5 = fma(wdz, ez, q5);
-                    sw = swn;
-                }
+                add_inlier(p);
             }
           }
         }
+    }
     }
     ST_USE_F64(sw);
     ST_MARK(13);
@@ -2045,7 +2113,7 @@ enum : int { CLS_DEAD = -1, CLS_OVF = -2, CLS_NONE = -3 };
 
 // STAGED: the slot's bitmap is copied to LDS (row-major there: word [y * ncolp + column], ncolp odd) and read from
 // it; otherwise (bitmap larger than the LDS budget: very large images) it is read in place.
-template <bool STAGED>
+template <bool STAGED, int kClsThreads, int kClsKeep>
 __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __restrict__ slots, SlotDesc single,
                                                           int use_single, Calib c, int ncol, int ncolp) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -2374,7 +2442,7 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDes
         for (int q = 0; q < kKeyBatchF; q++) key[q] = (e0 + q < kk) ? mp[cell[q] & 0x7FFFFFFFu] : 0u;
 #pragma unroll
         for (int q = 0; q < kKeyBatchF; q++)
-            if (e0 + q < kk) LST(e0 + q) = key_index(key[q]) | ((key[q] & 1u) << 30) | (cell[q] & 0x80000000u);
+            if (e0 + q < kk) LST(e0 + q) = key_index(key[q]) | ((key[q] & 3u) << kEntStateShift) | (cell[q] & kEntNarrow);
     }
     ST_MARK(4);
     kflag = kf;
@@ -2591,6 +2659,61 @@ __global__ void k_tracklet_scatter(const double* __restrict__ depth_cur, const i
     }
 }
 
+// The same marshalling for MANY sequences at once (mld_tracklets_depths_device): block (c, s) handles tracks
+// [c * 1024, (c + 1) * 1024) of sequence s.  The order-preserving rank of a new track = new tracks in the chunks before
+// (recounted by every block from the flag bytes: at most a few KB) + the ballot scan inside the chunk.
+__global__ __launch_bounds__(kTrkBlock) void k_tracklets_gather(const TrkSeq* __restrict__ seqs) {
+    __shared__ int wsum[kTrkBlock / kWave];
+    __shared__ int before_s;
+    const TrkSeq q = seqs[blockIdx.y];
+    const long long c0 = (long long)blockIdx.x * kTrkBlock;
+    if (c0 >= q.n) return;
+    const int w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    if (threadIdx.x == 0) before_s = 0;
+    __syncthreads();
+    int mine = 0;
+    for (long long i = threadIdx.x; i < c0; i += kTrkBlock) mine += q.is_new[i] != 0 ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0 && mine) atomicAdd(&before_s, mine);
+    const long long i = c0 + threadIdx.x;
+    const bool in = i < q.n;
+    const bool nw = in && q.is_new[i] != 0;
+    const unsigned long long m = __ballot(nw);
+    if (lane == 0) wsum[w] = __popcll(m);
+    __syncthreads();
+    int off = before_s;
+    for (int k = 0; k < w; k++) off += wsum[k];
+    const int r = off + prefix_count(m);
+    if (in) {
+        q.uv_cur[2 * i] = (double)(int)q.u_new[i];
+        q.uv_cur[2 * i + 1] = (double)(int)q.v_new[i];
+        q.rank[i] = nw ? r : -1;
+        if (nw) {
+            q.uv_last[2 * (long long)r] = (double)(int)q.u_old[i];
+            q.uv_last[2 * (long long)r + 1] = (double)(int)q.v_old[i];
+        }
+    }
+    if (c0 + kTrkBlock >= q.n && threadIdx.x == 0) {  // the sequence's last chunk knows the total
+        int t = before_s;
+        for (int k = 0; k < kTrkBlock / kWave; k++) t += wsum[k];
+        *q.n_new = t;
+    }
+}
+
+__global__ void k_tracklets_scatter(const TrkSeq* __restrict__ seqs) {
+    const TrkSeq q = seqs[blockIdx.y];
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q.n) return;
+    q.d_cur_out[i] = (float)q.depth_cur[i];
+    if (q.type_cur_out) q.type_cur_out[i] = q.type_cur[i];
+    const int r = q.rank[i];
+    if (r >= 0) {
+        q.d_last_out[i] = q.have_last ? (float)q.depth_last[r] : -1.0f;
+        if (q.type_last_out) q.type_last_out[i] = q.have_last ? q.type_last[r] : (int32_t)MLD_Unspecified;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Lazy debug getters: full PointcloudData (PointcloudData.h:13-68)
 // ------------------------------------------------------------------------------------------------
@@ -2675,7 +2798,7 @@ __global__ void k_export_map(const uint32_t* __restrict__ map, uint32_t tag, con
     if (i >= cells) return;
     uint32_t key = map[i];
     int32_t r = -1;
-    if ((key >> kIdxBits) == tag) r = rank[key_index(key)];
+    if ((key >> kTagShift) == tag) r = rank[key_index(key)];
     out[i] = r;
 }
 

@@ -243,10 +243,16 @@ class DepthEstimator:
         finished (device-side; mld_order_after)."""
         self._check(self._lib.mld_order_after(self._ctx, other._ctx))
 
+    def pairWith(self, other: "DepthEstimator"):
+        """The batched projections of this context and `other` run back to back on one stream (owned by this context),
+        each context's feature kernels on its own (mld_pair_contexts).  Close `other` first."""
+        self._check(self._lib.mld_pair_contexts(self._ctx, other._ctx))
+        self._paired = other._paired = True
+
     def setSharedGpu(self, shared: bool = True):
         """This context alternates with another one on the same GPU (see `runBatchesAlternating`): its feature kernel
         leaves room on every CU for the other context's projection (mld_set_shared_gpu)."""
-        self._check(self._lib.mld_set_shared_gpu(self._ctx, 1 if shared else 0))
+        self._check(self._lib.mld_set_shared_gpu(self._ctx, int(shared)))  # bit 0: on; bits 8..15: feature wavefronts per CU
 
     # ------------------------------------------------------------------ setInputCloud
     @staticmethod
@@ -358,8 +364,8 @@ class DepthEstimator:
         self._after_torch(b["keep"][0][0])
         self._check(lib.mld_set_clouds_planes_device(ctx, n, b["cloud_ptrs"], b["cloud_n"], b["stride"],
                                                      b["coeffs"].ctypes.data_as(C.POINTER(C.c_float)), b["mask_ptrs"]))
-        if nxt is not self:
-            nxt.orderAfter(self)
+        if nxt is not self and not getattr(self, "_paired", False):
+            nxt.orderAfter(self)  # (a pair's projections are already in call order on their shared stream)
         self._check(lib.mld_calculate_depths_device(ctx, n, b["uv_ptrs"], b["F"], b["depth_ptrs"], b["type_ptrs"]))
 
     def estimateGroundPlane(self, slot: int = 0, seed: int = 0):

@@ -337,10 +337,13 @@ def test_batch_with_empty_and_ragged_slots():
         assert_depth_parity(t_depth[b].cpu().numpy(), t_type[b].cpu().numpy(), d0, t0)
 
 
-def test_two_contexts_alternating_on_one_gpu():
-    """Two contexts used in turn (mld_order_after + mld_set_shared_gpu; include/mld.h "Two contexts"): the projection
-    of one runs beside the feature kernels of the other.  Every launch set of four rounds equals the oracle, whichever
-    context computed it, and the shared-GPU mode (more LDS per block of the lane-per-feature kernel) changes nothing."""
+@pytest.mark.parametrize("paired", [False, True])
+def test_two_contexts_alternating_on_one_gpu(paired):
+    """Two contexts used in turn (mld_order_after or mld_pair_contexts, + mld_set_shared_gpu; include/mld.h "Two
+    contexts"): the projection of one runs beside the feature kernels of the other.  Every launch set of four rounds
+    equals the oracle, whichever context computed it, and the shared-GPU mode (more LDS per block of the lane-per-feature
+    kernel) changes nothing.  Paired: both contexts' projections on one stream; the same slots are re-projected while
+    the previous round's feature kernels may still be queued (the fork event orders them)."""
     import torch
     P = capi.params_c0()
     S, F, rounds = 6, 1200, 4
@@ -348,6 +351,8 @@ def test_two_contexts_alternating_on_one_gpu():
     ests = [make_estimator(P, max_frames=S, max_features=F) for _ in range(2)]
     for e in ests:
         e.setSharedGpu(True)
+    if paired:
+        ests[0].pairWith(ests[1])
 
     def mask_of(inl, n):
         m = np.zeros((n + 31) // 32, dtype=np.uint32)
@@ -379,3 +384,9 @@ def test_two_contexts_alternating_on_one_gpu():
     lib = ests[0]._lib
     assert lib.mld_order_after(ests[0]._ctx, None) == capi.MLD_ERR_INVALID_ARG
     assert lib.mld_order_after(ests[0]._ctx, ests[0]._ctx) == capi.MLD_OK
+    assert lib.mld_pair_contexts(ests[0]._ctx, None) == capi.MLD_ERR_INVALID_ARG
+    assert lib.mld_pair_contexts(ests[0]._ctx, ests[0]._ctx) == capi.MLD_ERR_INVALID_ARG
+    if paired:
+        assert lib.mld_pair_contexts(ests[0]._ctx, ests[1]._ctx) == capi.MLD_ERR_INVALID_ARG  # already paired
+    ests[1].close()  # the borrower of the projection stream first
+    ests[0].close()
