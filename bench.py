@@ -40,9 +40,7 @@ K_PROJECT, K_FUSED, K_WAVE, K_RANSAC, K_CLASSIFY = 0, 1, 3, 4, 5  # mld_kernel_t
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200,
-                    help="timed steps (0.16 s of GPU time at the default; the first projection and the last feature "
-                         "kernels of the timed region run without a partner, which 20 steps would still show)")
+    ap.add_argument("--steps", type=int, default=200, help="timed steps per loop (0.15 s of GPU time at the default)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames-per-step", type=int, default=1024, help="resident frames processed per step")
     ap.add_argument("--slots", type=int, default=0,
@@ -73,7 +71,11 @@ def parse_args():
                     help="resident frames of the config-3 leg / sequence length of the config-5 leg (0 = skip both)")
     ap.add_argument("--only-config", type=int, default=0, choices=[0, 3, 5],
                     help="run only that BASELINE config's leg and print its object (for per-config rocprofv3 runs)")
-    ap.add_argument("--verify-slots", type=int, default=4, help="slots of the timed batch checked against the oracle")
+    ap.add_argument("--verify-slots", type=int, default=16,
+                    help="frames of the timed batch checked against the oracle, spread over the output sets of all contexts")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed loop of --steps steps runs this many times back to back; value / ms_per_step are the "
+                         "median loop, ms_per_step_min / _max the spread")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-every", type=int, default=4,
                     help="record hipEvents around the kernels of every n-th timed step (event records cost ~6 us each)")
@@ -258,7 +260,7 @@ def streaming_leg(P, cam, T, clouds, planes, uvs, device, frames_per_batch, n_ba
     return {
         "path": "pinned host batches, double-buffered H2D on a copy stream overlapped with the kernels, depths/types "
                 "copied back",
-        "frames_per_batch": S, "batches": n_batches,
+        "frames_per_batch": S, "batches": n_batches, "frames": frames,
         "frames_per_s": frames / el,
         "associations_per_s": frames * F / el,
         "ms_per_frame": 1e3 * el / frames,
@@ -286,8 +288,13 @@ class Resident:
         self.all_clouds = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
         self.all_masks = torch.empty((B, words), dtype=torch.int32, device=dev)
         self.all_uvs = torch.empty((B, F, 2), dtype=torch.float64, device=dev)
-        self.all_depth = torch.empty((B, F), dtype=torch.float64, device=dev)
-        self.all_type = torch.empty((B, F), dtype=torch.int32, device=dev)
+        # results: in the default schedule both contexts process the same resident frames in turn, so each context gets
+        # its own output set (nothing is written twice concurrently, and the check below sees both); with --slots the
+        # launch sets are disjoint rows of one set
+        n_out = max(1, contexts) if slots <= 0 else 1
+        self.out_depth = [torch.empty((B, F), dtype=torch.float64, device=dev) for _ in range(n_out)]
+        self.out_type = [torch.empty((B, F), dtype=torch.int32, device=dev) for _ in range(n_out)]
+        self.all_depth, self.all_type = self.out_depth[0], self.out_type[0]
         d_unique = [torch.from_numpy(c).to(dev) for c in self.clouds_h]
         m_unique = [torch.from_numpy(mask_words(p[1], N)).to(dev) for p in self.planes_h]
         for b in range(B):
@@ -320,13 +327,33 @@ class Resident:
         # a step walks the B resident frames in launch sets of S frame slots, dealt round-robin to the contexts (one HIP
         # stream each); the slots' pixel maps are reused from one launch set to the next
         rows = lambda t, i: [t[b] for b in range(i, i + S)]  # noqa: E731
-        prep = lambda e, i: (e, e.prepareBatch(  # noqa: E731
-            rows(self.all_clouds, i), rows(self.all_uvs, i), rows(self.all_depth, i), rows(self.all_type, i),
+        prep = lambda e, i, o: (e, e.prepareBatch(  # noqa: E731
+            rows(self.all_clouds, i), rows(self.all_uvs, i), rows(self.out_depth[o], i), rows(self.out_type[o], i),
             self.coeffs[i:i + S], rows(self.all_masks, i), stride_bytes=16))
         if self.whole:
-            self.batches = [prep(e, 0) for e in self.ests]  # the same resident frames, one descriptor set per context
+            # the same resident frames, one descriptor set and one output set per context
+            self.batches = [prep(e, 0, c) for c, e in enumerate(self.ests)]
         else:
-            self.batches = [prep(self.ests[(i // S) % NC], i) for i in range(0, B, S)]
+            self.batches = [prep(self.ests[(i // S) % NC], i, 0) for i in range(0, B, S)]
+        self.primed = False
+
+    def poison(self):
+        """Results that are not rewritten by the timed region cannot pass the check."""
+        for d, t in zip(self.out_depth, self.out_type):
+            d.fill_(float("nan"))
+            t.fill_(-77)
+
+    def prime(self):
+        """Steady-state start of a timed loop (default schedule only): the projection of one UNTIMED step is submitted
+        and finished here; its feature kernels are submitted by the first timed run_step, beside that step's
+        projection - as in every later step.  The clock therefore starts with the pipeline full, and the timed region
+        holds the feature kernels of steps+1 steps and the projections of `steps` (never less work than it counts)."""
+        if not (self.whole and len(self.batches) > 1):
+            return
+        e, b = self.batches[self.k % len(self.batches)]
+        e.projectBatch(b)
+        e.synchronize()
+        self.primed = True
 
     def run_step(self):
         # contexts in turn; the next context's projection is released by the end of this one's, so it streams its
@@ -334,7 +361,14 @@ class Resident:
         nb = len(self.batches)
         if self.whole:
             e, b = self.batches[self.k % nb]
-            e.runBatchBeside(b, self.batches[(self.k + 1) % nb][0])
+            nxt = self.batches[(self.k + 1) % nb][0]
+            if self.primed:  # the primed step's projection is done: its feature kernels, then a whole step
+                self.primed = False
+                e.featuresBatchBeside(b, nxt)
+                self.k += 1
+                e, b = self.batches[self.k % nb]
+                nxt = self.batches[(self.k + 1) % nb][0]
+            e.runBatchBeside(b, nxt)
             self.k += 1
             return
         for i, (e, b) in enumerate(self.batches):
@@ -388,24 +422,31 @@ class Resident:
 
     def verify(self, n_slots):
         """Frames of the timed batch against the CPU oracle (checker only, outside every timed region): result types
-        identical, depths bit-exact on the main path and within 1e-4 m on the road path.  Returns (ok, report)."""
+        identical, depths bit-exact on the main path and within 1e-4 m on the road path.  The picks are spread over the
+        output sets of all contexts (each holds the last step that context ran).  Returns (ok, report)."""
         from oracle import oracle
         ref = oracle.OracleDepthEstimator(self.P, self.cam.as_struct(), self.T)
-        picks = sorted({int(x) for x in np.linspace(0, self.B - 1, max(1, n_slots))})
-        worst, bad = 0.0, []
-        for fr in picks:
-            ref.set_cloud(self.clouds_h[fr % self.U])
-            ref.set_ground_plane(*self.planes_h[fr % self.U])
-            d0, t0 = ref.calculate_depth(self.uvs_h[fr], 8)
-            d, t = self.all_depth[fr].cpu().numpy(), self.all_type[fr].cpu().numpy()
-            same_t = np.array_equal(t, t0)
-            diff = np.abs(np.nan_to_num(d, nan=-7.0) - np.nan_to_num(d0, nan=-7.0))
-            main = t0 != 16
-            ok = same_t and diff.max(initial=0.0) <= 1e-4 and np.array_equal(d[main], d0[main], equal_nan=True)
-            worst = max(worst, float(diff.max(initial=0.0)))
-            if not ok:
-                bad.append(fr)
-        return (not bad), {"frames_checked": picks, "max_abs_depth_diff_m": worst, "mismatching_frames": bad}
+        n_out = len(self.out_depth)
+        per = max(1, (n_slots + n_out - 1) // n_out)
+        worst, bad, checked = 0.0, [], []
+        for o in range(n_out):
+            lo = (self.B * o) // (2 * n_out) if n_out > 1 else 0  # different frames per output set
+            picks = sorted({int(x) for x in np.linspace(lo, self.B - 1, per)})
+            for fr in picks:
+                ref.set_cloud(self.clouds_h[fr % self.U])
+                ref.set_ground_plane(*self.planes_h[fr % self.U])
+                d0, t0 = ref.calculate_depth(self.uvs_h[fr], 8)
+                d, t = self.out_depth[o][fr].cpu().numpy(), self.out_type[o][fr].cpu().numpy()
+                same_t = np.array_equal(t, t0)
+                diff = np.abs(np.nan_to_num(d, nan=-7.0) - np.nan_to_num(d0, nan=-7.0))
+                main = t0 != 16
+                ok = same_t and diff.max(initial=0.0) <= 1e-4 and np.array_equal(d[main], d0[main], equal_nan=True)
+                worst = max(worst, float(diff.max(initial=0.0)))
+                checked.append([o, fr])
+                if not ok:
+                    bad.append([o, fr])
+        return (not bad), {"frames_checked": checked, "output_sets": n_out, "max_abs_depth_diff_m": worst,
+                           "mismatching_frames": bad}
 
 
 def design_bytes_project(cloud, cam, T, inl):
@@ -437,6 +478,13 @@ def pmc_traffic(kernel, frames_per_launch):
         return None
 
 
+def traffic_profile_json():
+    try:
+        return json.loads((ROOT / "profiles" / "traffic.json").read_text())
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def kernel_times(ests):
     """Average launch duration per kernel over the timed launches of all the given contexts."""
     ests = ests if isinstance(ests, (list, tuple)) else [ests]
@@ -453,32 +501,44 @@ def kernel_times(ests):
     return out
 
 
-def timed_resident(res, steps, warmup, timing, timing_every, barrier=lambda: None, estimated=False):
+def timed_resident(res, steps, warmup, timing, timing_every, barrier=lambda: None, estimated=False, repeats=1,
+                   reduce_max=lambda x: x):
+    """`repeats` timed loops of `steps` steps each, every loop bracketed by barrier + synchronize on both sides.  Returns
+    (per-loop elapsed seconds, each the max over ranks; kernel times averaged over the sampled steps of all loops)."""
     import torch
     step = res.run_step_estimated if estimated else res.run_step
     for _ in range(warmup):
         step()
     res.sync()
+    res.poison()
     if timing:
         for e in res.ests:
             e.timingEnable(True)
             e.timingReset()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for it in range(steps):
-        if timing:
-            for e in res.ests:
-                e.timingEnable(it % max(1, timing_every) == 0)  # sampled steps of the timed region
-        step()
-    res.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
+            e.timingEnable(False)
+    loops, local = [], []
+    res.local_loops = local
+    for _ in range(max(1, repeats)):
+        barrier()
+        torch.cuda.synchronize()
+        if not estimated:
+            res.prime()  # pipeline full when the clock starts (default schedule)
+        t0 = time.perf_counter()
+        for it in range(steps):
+            if timing:
+                for e in res.ests:
+                    e.timingEnable(it % max(1, timing_every) == 0)  # sampled steps of the timed region
+            step()
+        res.sync()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        local.append(el)
+        loops.append(reduce_max(el))
+        barrier()
     kt = kernel_times(res.ests) if timing else {}
     for e in res.ests:
         e.timingEnable(False)
-    return elapsed, kt
+    return loops, kt
 
 
 def config3_leg(cam, T, device, B, steps=8):
@@ -494,7 +554,8 @@ def config3_leg(cam, T, device, B, steps=8):
                      ("adjust_absolute", dict(treshold_depth_mode=1, treshold_depth_local_mode=1,
                                               treshold_depth_local_valuetype=0))):
         res = Resident(P0.replace(**kw), cam, T, synth.VLP16, B, 8, 5000, 3, device)
-        el, kt = timed_resident(res, steps, 2, True, 2)
+        loops, kt = timed_resident(res, steps, 2, True, 2)
+        el = loops[0]
         ok, rep = res.verify(2)
         hist = np.zeros(capi.MLD_RESULT_TYPE_COUNT, dtype=np.int64)
         for b in range(0, B, max(1, B // 16)):
@@ -607,6 +668,97 @@ def config5_leg(cam, T, device, n_frames):
     }
 
 
+def config5_batched_leg(cam, T, device, S, steps=6):
+    """BASELINE config 5 at batch size: the current frames of S independent sequences (128x4096 cloud, 10 000 tracks, 10 %
+    new) per step through mld_set_clouds_planes_range_device + mld_tracklets_depths_device; every sequence's previous
+    frame stays resident in the other bank of slots.  Distinct HBM per slot; checked per sequence against the oracle."""
+    import torch
+    from mono_lidar_depth_amd import TrackletBatch, capi, synth
+    from oracle import oracle
+    dev = torch.device("cuda", device)
+    P = capi.params_c0()
+    U, n_tracks, K = 4, 10000, 8
+    clouds_h = [synth.make_cloud(synth.DENSE128, seed=5, frame=f) for f in range(U)]
+    planes_h = [synth.make_ground_plane(c) for c in clouds_h]
+    N = clouds_h[0].shape[0]
+    words = (N + 31) // 32
+    all_clouds = torch.empty((2, S, N, 4), dtype=torch.float32, device=dev)  # two banks of S slots
+    all_masks = torch.empty((2, S, words), dtype=torch.int32, device=dev)
+    d_unique = [torch.from_numpy(c).to(dev) for c in clouds_h]
+    m_unique = [torch.from_numpy(mask_words(p[1], N)).to(dev) for p in planes_h]
+    for b in range(2):
+        for q in range(S):
+            all_clouds[b, q].copy_(d_unique[(b + 2 * q) % U])
+            all_masks[b, q].copy_(m_unique[(b + 2 * q) % U])
+    del d_unique, m_unique
+    rng = np.random.default_rng(5)
+    sets_h, sets_d = [], []
+    for k in range(K):
+        u0 = rng.integers(0, cam.width, n_tracks).astype(np.float32)
+        v0 = rng.integers(100, cam.height, n_tracks).astype(np.float32)
+        u1 = (u0 + rng.integers(-3, 4, n_tracks)).astype(np.float32)
+        v1 = (v0 + rng.integers(-2, 3, n_tracks)).astype(np.float32)
+        new = np.zeros(n_tracks, dtype=np.uint8)
+        new[rng.choice(n_tracks, n_tracks // 10, replace=False)] = 1
+        sets_h.append((u0, v0, u1, v1, new))
+        sets_d.append(tuple(torch.from_numpy(a).to(dev) for a in (u0, v0, u1, v1, new)))
+    d_cur = torch.empty((S, n_tracks), dtype=torch.float32, device=dev)
+    d_last = torch.zeros((S, n_tracks), dtype=torch.float32, device=dev)
+    t_cur = torch.empty((S, n_tracks), dtype=torch.int32, device=dev)
+    t_last = torch.zeros((S, n_tracks), dtype=torch.int32, device=dev)
+    # (dense cloud: 16 neighbours in the road window on average, 48 at most: list capacities 48 / 24, include/mld.h)
+    tb = TrackletBatch(P, cam, T, S, n_tracks, device=device, list_capacity=(48, 24))
+    rows = lambda t: [t[q] for q in range(S)]  # noqa: E731
+    prep = []
+    for b in range(2):  # one prepared frame per bank
+        pick = lambda j: [sets_d[(b + q) % K][j] for q in range(S)]  # noqa: E731
+        prep.append(tb.prepare(rows(all_clouds[b]), np.stack([planes_h[(b + 2 * q) % U][0] for q in range(S)]),
+                               rows(all_masks[b]), pick(0), pick(1), pick(2), pick(3), pick(4), rows(d_cur), rows(d_last),
+                               rows(t_cur), rows(t_last)))
+    torch.cuda.synchronize()
+    for it in range(3):
+        tb.run(prep[it % 2])
+    tb.est.synchronize()
+    tb.est.timingEnable(True)
+    tb.est.timingReset()
+    t0 = time.perf_counter()
+    for it in range(3, 3 + steps):
+        tb.run(prep[it % 2])
+    tb.est.synchronize()
+    el = time.perf_counter() - t0
+    kt = kernel_times(tb.est)
+    tb.est.timingEnable(False)
+    # the last step's bank against the oracle, two sequences, both slots
+    b = (3 + steps - 1) % 2
+    ok = True
+    for q in sorted({0, S - 1}):
+        ref = oracle.OracleDepthEstimator(P, cam.as_struct(), T)
+        i = (b + 2 * q) % U
+        ref.set_cloud(clouds_h[i])
+        ref.set_ground_plane(*planes_h[i])
+        ref_l = oracle.OracleDepthEstimator(P, cam.as_struct(), T)
+        j = ((1 - b) + 2 * q) % U
+        ref_l.set_cloud(clouds_h[j])
+        ref_l.set_ground_plane(*planes_h[j])
+        u0, v0, u1, v1, new = sets_h[(b + q) % K]
+        e_cur, e_last, et_cur, et_last = oracle.tracklets_depth(ref, ref_l, u0, v0, u1, v1, new.astype(bool), n_threads=8)
+        nw = new.astype(bool)
+        ok = ok and bool(np.array_equal(t_cur[q].cpu().numpy(), et_cur) and
+                         np.allclose(d_cur[q].cpu().numpy(), e_cur, rtol=0, atol=1e-4, equal_nan=True) and
+                         np.array_equal(t_last[q].cpu().numpy()[nw], et_last[nw]) and
+                         np.allclose(d_last[q].cpu().numpy()[nw], e_last[nw], rtol=0, atol=1e-4, equal_nan=True))
+    tb.close()
+    assoc = (n_tracks + n_tracks // 10) * S
+    db = design_bytes_project(clouds_h[0], cam, T, planes_h[0][1])
+    pms = kt["k_project_scatter"]["avg_ms"]
+    return {"sequences": S, "ms_per_step": 1e3 * el / steps, "ms_per_frame": 1e3 * el / steps / S,
+            "associations_per_s": assoc * steps / el,
+            "kernels_ms_per_launch": {k: v["avg_ms"] for k, v in kt.items()},
+            "roofline_project": {"design_bytes_per_launch": db["bytes"] * S, "kernel_ms": pms,
+                                 "frac": db["bytes"] * S / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS if pms > 0 else None},
+            "verified": ok}
+
+
 # ------------------------------------------------------------------------------------------------ worker
 def main():
     args = parse_args()
@@ -649,8 +801,12 @@ def main():
                         cam_struct.principal_point_y)
 
     if args.only_config:
-        leg = (config3_leg(cam, T, gpu_index, args.config_frames) if args.only_config == 3
-               else config5_leg(cam, T, gpu_index, min(args.config_frames, 200)))
+        if args.only_config == 3:
+            leg = config3_leg(cam, T, gpu_index, args.config_frames)
+        else:
+            leg = config5_leg(cam, T, gpu_index, min(args.config_frames, 200))
+            leg["batched"] = {str(S5): config5_batched_leg(cam, T, gpu_index, S5) for S5 in (16, 64, 256)}
+            leg["verified"] = bool(leg["verified"] and all(v["verified"] for v in leg["batched"].values()))
         print(json.dumps({"config": str(args.only_config), **leg}), flush=True)
         sys.exit(0 if leg.get("verified") else 1)
 
@@ -667,13 +823,35 @@ def main():
             dist.barrier()
 
     timing = not args.no_kernel_timing
-    elapsed, kt = timed_resident(res, args.steps, args.warmup, timing, args.timing_every, barrier)
-    elapsed = sharding.max_over_ranks(elapsed, device=coll_dev)
+    loops, kt = timed_resident(res, args.steps, args.warmup, timing, args.timing_every, barrier, repeats=args.repeats,
+                               reduce_max=lambda x: sharding.max_over_ranks(x, device=coll_dev))
+    elapsed = float(np.median(loops))  # every loop: exactly --steps steps, max over ranks
+    loop_start = ("pipeline full: one untimed step's projection done, its feature kernels inside the timed region"
+                  if (res.whole and len(res.ests) > 1) else "idle GPU")
+    elapsed_local = float(np.median(res.local_loops)) if getattr(res, "local_loops", None) else elapsed
     units = sharding.sum_over_ranks(float(B * F * args.steps), device=coll_dev)
 
     # ---- the timed batch against the oracle (every rank checks its own sequence) ---------------------------
     verified, vrep = res.verify(args.verify_slots) if args.verify_slots > 0 else (None, {})
     n_bad = sharding.sum_over_ranks(0.0 if verified in (True, None) else 1.0, device=coll_dev)
+    per_rank_value = sharding.gather_over_ranks(B * F * args.steps / elapsed_local, device=coll_dev)
+    distributed = None
+    streaming_ranks = None
+    if world > 1:
+        distributed = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                       "ranks_verified": int(world - n_bad) if args.verify_slots > 0 else 0,
+                       "resident_associations_per_s_per_rank": {"min": min(per_rank_value), "max": max(per_rank_value)}}
+        if args.streaming_batches > 0:
+            # BASELINE config 4 as written: every rank STREAMS its own sequence from pinned host memory (PCIe-inclusive)
+            barrier()
+            st = streaming_leg(P, cam, T, res.clouds_h, res.planes_h, res.uvs_h, gpu_index, args.streaming_frames,
+                               args.streaming_batches)
+            fps = sharding.gather_over_ranks(st["frames_per_s"], device=coll_dev)
+            slowest = sharding.max_over_ranks(st["frames"] / st["frames_per_s"], device=coll_dev)
+            streaming_ranks = {**st, "ranks": world, "frames_per_s": st["frames"] * world / slowest,
+                               "associations_per_s": st["frames"] * world * F / slowest,
+                               "frames_per_s_per_rank": {"min": min(fps), "max": max(fps)},
+                               "aggregate": "frames of all ranks / the slowest rank's elapsed time"}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -715,55 +893,82 @@ def main():
     def gbps(nbytes, t_ms):
         return (nbytes / (t_ms * 1e-3)) / 1e9 if t_ms > 0 else 0.0
 
-    # The dominant kernel by time.  k_project_scatter is the HBM-bound one (it streams every cloud once);
-    # k_feature_fused is bound by the rate of divergent gathers and by f64 issue, not by HBM - its
-    # figure below is the §8(d) per-feature formula over its launch time.
-    # k_project_scatter is the kernel the HBM roof applies to (it streams every cloud once; 85 % of the step's HBM
-    # bytes); k_feature_fused, of about the same duration, is bound by the rate of divergent gathers and their latency
-    #  - it is listed under "kernels" with the §8(d) formula figure and its PMC traffic.
-    dominant = "k_project_scatter"
-    dom_ms = ms(dominant)
-    dom_bytes = design_project
+    # Both long kernels on their roofs; the line's top-level roofline is the one that takes longer in the timed schedule.
+    #   k_project_scatter  HBM: the bytes THIS design moves (cloud once + map / bitmap / mask words) over its launch time
+    #   k_feature_fused    HBM by SURVEY 8(d)'s per-feature formula (algorithmic bytes), and - what actually bounds it - a
+    #                      gather roof: the cache-line requests its divergent loads make (PMC profile) against the line
+    #                      rates random gathers reach on this part (profiles/tools/randgather.hip, same profile session)
+    tj = traffic_profile_json()
+    gather = None
+    fj = (tj or {}).get("k_feature_fused", {})
+    ceil = (tj or {}).get("gather_ceilings")
+    if ceil and fj.get("tcp_tcc_read_req") and ms("k_feature_fused") > 0:
+        scale = float(S) / float(tj["frames_per_launch"])
+        l2_req = fj["tcp_tcc_read_req"] * scale           # L1 misses: lines requested from L2
+        hbm_req = fj.get("tcc_ea_rdreq", 0.0) * scale      # of those, lines L2 had to fetch from memory (64 B each)
+        t_s = ms("k_feature_fused") * 1e-3
+        # time the requests take at the measured random-gather rates (L2-resident lines / memory-resident lines)
+        t_floor = max(l2_req - hbm_req, 0.0) / (ceil["l2_Glines_s"] * 1e9) + hbm_req / (ceil["hbm_Glines_s"] * 1e9)
+        gather = {"requests_per_launch": l2_req, "memory_fetches_per_launch": hbm_req,
+                  "l1_accesses_per_launch": fj.get("tcp_total_cache_accesses", 0.0) * scale,
+                  "achieved_Glines_s": l2_req / t_s / 1e9,
+                  "ceiling_Glines_s": l2_req / t_floor / 1e9 if t_floor > 0 else None,
+                  "frac": t_floor / t_s,
+                  "ceilings": ceil,
+                  "model": "lines requested from L2 (TCP_TCC_READ_REQ) priced at the random-gather rate of L2-resident lines, "
+                           "the share fetched from memory (TCC_EA0_RDREQ) at the rate of memory-resident lines; frac = "
+                           "that service time / the launch time measured in this run",
+                  "source": (tj or {}).get("source", "")}
+
+    def hbm_entry(name, nbytes, model):
+        return {"bound": "hbm", "achieved": gbps(nbytes, ms(name)), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbps(nbytes, ms(name)) / HBM_PEAK_GBS, "kernel": name, "kernel_ms": ms(name),
+                "bytes_per_launch": nbytes, "bytes_model": model}
+
+    entries = {
+        "k_project_scatter": hbm_entry("k_project_scatter", design_project,
+                                       "design: 16 B/point + 4 B per map entry + occupancy and inlier-mask words touched"),
+        "k_feature_fused": hbm_entry("k_feature_fused", formula_feature, "SURVEY 8(d) per-feature formula (algorithmic bytes)"),
+    }
+    dominant = max(entries, key=lambda k: ms(k))
     pmc = pmc_traffic(dominant, S)
+    pmc_p = pmc_traffic("k_project_scatter", S)
     roofline = {
-        "bound": "hbm",
-        "achieved": gbps(dom_bytes, dom_ms),
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": gbps(dom_bytes, dom_ms) / HBM_PEAK_GBS,
+        **entries[dominant],
         "traffic": pmc[0] if pmc else None,
-        "kernel": dominant,
-        "kernel_ms": dom_ms,
+        "dominant_by": "longest average launch in the timed schedule (hipEvents, this run)",
         # two contexts: the projection of one runs beside the feature kernels of the other during the timed region, so
-        # `frac` (priced on the launch duration measured THERE, as the contract asks) understates what the kernel does
+        # `frac` (priced on the launch duration measured THERE, as the contract asks) understates what a kernel does
         # with the chip to itself; `exclusive` prices the same bytes on the duration of a launch that runs alone
         "concurrent": (f"{len(res.ests)} contexts: k_project_scatter of one (step k+1) beside k_classify / k_feature_fused "
                        "/ k_feature_wave of the other (step k)" if len(res.ests) > 1 else None),
         "exclusive": ({"kernel_ms": kt_x[dominant]["avg_ms"],
-                       "achieved": gbps(dom_bytes, kt_x[dominant]["avg_ms"]),
-                       "frac": gbps(dom_bytes, kt_x[dominant]["avg_ms"]) / HBM_PEAK_GBS,
+                       "achieved": gbps(entries[dominant]["bytes_per_launch"], kt_x[dominant]["avg_ms"]),
+                       "frac": gbps(entries[dominant]["bytes_per_launch"], kt_x[dominant]["avg_ms"]) / HBM_PEAK_GBS,
                        "kernels_ms": {k: v.get("avg_ms", 0.0) for k, v in kt_x.items()}}
                       if kt_x.get(dominant, {}).get("avg_ms", 0.0) > 0 else None),
-        "bytes_per_launch": dom_bytes,
-        "bytes_model": ("design: 16 B/point + 4 B per map entry + occupancy and inlier-mask words touched"
-                        if dominant == "k_project_scatter" else "SURVEY 8(d) per-feature formula"),
         # the committed PMC profile of the same launch size, priced with ITS OWN kernel time (reproducible from
         # profiles/: traffic.json and the kernel-stats summary it names)
         "traffic_profile": ({"hbm_bytes_per_launch": pmc[0], "launch_ms": pmc[1] * 1e3,
                              "frac": pmc[0] / pmc[1] / 1e9 / HBM_PEAK_GBS, "source": pmc[2]} if pmc else None),
         "kernels": {
-            "k_project_scatter": {**kt.get("k_project_scatter", {}), "design_bytes_per_launch": design_project,
+            "k_project_scatter": {**kt.get("k_project_scatter", {}), **entries["k_project_scatter"],
+                                  "design_bytes_per_launch": design_project,
                                   "design_GBps": gbps(design_project, ms("k_project_scatter")),
-                                  "frac": gbps(design_project, ms("k_project_scatter")) / HBM_PEAK_GBS,
+                                  "exclusive_frac": (gbps(design_project, kt_x["k_project_scatter"]["avg_ms"]) / HBM_PEAK_GBS
+                                                     if kt_x.get("k_project_scatter", {}).get("avg_ms", 0.0) > 0 else None),
+                                  "traffic": pmc_p[0] if pmc_p else None,
                                   # 16 N + 4 W H + 28 Nvis - charges a map clear and a camera-frame copy
                                   # that this design does not perform, so it may exceed the peak
                                   "formula_bytes_per_launch": formula_project,
                                   "formula_GBps": gbps(formula_project, ms("k_project_scatter"))},
             "k_classify": kt.get("k_classify", {}),
-            "k_feature_fused": {**kt.get("k_feature_fused", {}), "formula_bytes_per_launch": formula_feature,
+            "k_feature_fused": {**kt.get("k_feature_fused", {}), **entries["k_feature_fused"],
+                                "formula_bytes_per_launch": formula_feature,
                                 "formula_GBps": gbps(formula_feature, ms("k_feature_fused")),
-                                # not HBM-bound: what the counters saw it move (committed profile, kernel alone)
-                                "pmc_hbm_bytes_per_launch": (pmc_traffic("k_feature_fused", S) or [None])[0]},
+                                # what the counters saw it move (committed profile, kernel alone)
+                                "pmc_hbm_bytes_per_launch": (pmc_traffic("k_feature_fused", S) or [None])[0],
+                                "gather": gather},
             "k_feature_wave": kt.get("k_feature_wave", {}),
         },
         "whole_step_formula_GBps": ((formula_project + formula_feature) * (B // S) * args.steps / elapsed) / 1e9,
@@ -780,7 +985,8 @@ def main():
         # contexts without the alternating schedule)
         for e in res.ests:
             e.setSharedGpu(False)
-        el_e, kt_e = timed_resident(res, max(2, args.steps // 2), 2, timing, 2, estimated=True)
+        loops_e, kt_e = timed_resident(res, max(2, args.steps // 2), 2, timing, 2, estimated=True)
+        el_e = loops_e[0]
         for e in res.ests:
             e.setSharedGpu(res.shared_mode if len(res.ests) > 1 else 0)
         ok_e = True
@@ -811,6 +1017,9 @@ def main():
     if world == 1 and args.config_frames > 0:
         configs["3"] = config3_leg(cam, T, gpu_index, args.config_frames)
         configs["5"] = config5_leg(cam, T, gpu_index, min(args.config_frames, 200))
+        configs["5"]["batched"] = {str(S5): config5_batched_leg(cam, T, gpu_index, S5) for S5 in (16, 64, 256)}
+        configs["5"]["verified"] = bool(configs["5"]["verified"] and
+                                        all(v["verified"] for v in configs["5"]["batched"].values()))
 
     value = units / elapsed
     out = {
@@ -821,6 +1030,10 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step_min": 1e3 * min(loops) / args.steps,
+        "ms_per_step_max": 1e3 * max(loops) / args.steps,
+        "timed_loops": {"repeats": len(loops), "ms_per_step": [1e3 * x / args.steps for x in loops],
+                        "start": loop_start},
         "ms_per_frame": 1e3 * elapsed / args.steps / (B * world),  # whole job: all ranks' frames
         "higher_is_better": True,
         "scaling": "weak",
@@ -854,7 +1067,8 @@ def main():
         "cpu_baseline": cpu,
         "plane_estimated": estimated,
         "latency": latency,
-        "streaming": streaming,
+        "streaming": streaming if world == 1 else streaming_ranks,
+        "distributed": distributed,
         "configs": configs,
     }
     print(json.dumps(out), flush=True)

@@ -192,6 +192,15 @@ int mld_order_after(mld_ctx* ctx, mld_ctx* other);
  */
 int mld_pair_contexts(mld_ctx* a, mld_ctx* b);
 int mld_set_shared_gpu(mld_ctx* ctx, int shared);
+/*
+ * Capacities (entries per feature) of the lane-per-feature kernel's two neighbour lists: the scanned window (the road
+ * window, 2.0 x 1.5 the search window, when the fallback is on) and the narrow search window.  Features whose lists are
+ * longer are handled by the wave-cooperative kernel (same results, ~10x the cost per feature).  Default 32 / 24: right
+ * for 64-beam clouds (config 2: 11 / 2.3 neighbours on average).  Dense clouds (128 beams x 4096: 16 / 6 on average, 48
+ * at most in the road window) want 48 / 24: BASELINE config 5 at batch size runs 1.8x faster with it.  LDS per wavefront
+ * = (wide + narrow) * 256 bytes.  8 <= narrow <= wide <= 64.
+ */
+int mld_set_list_capacity(mld_ctx* ctx, int wide_entries, int narrow_entries);
 
 /*
  * setInputCloud (DepthEstimator.cpp:220-312): projection + pixel->point map for one slot.

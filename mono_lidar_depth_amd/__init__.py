@@ -8,7 +8,7 @@ from .capi import MldCamera, MldParams, params_c0, params_default, params_from_f
 from .depth_estimator import (NO_PLANE, CameraPinhole, DepthEstimator, DepthEstimatorError, ExceptionPclInvalid,
                               GroundPlane, RansacPlane, SemanticPlane)
 
-from .tracklets import TrackletDepthModule
+from .tracklets import TrackletBatch, TrackletDepthModule
 
 __all__ = ["TrackletDepthModule", "MldCamera", "MldParams", "params_c0", "params_default", "params_from_file", "RESULT_TYPE_NAMES",
            "NO_PLANE", "RansacPlane", "SemanticPlane", "CameraPinhole", "DepthEstimator", "DepthEstimatorError", "ExceptionPclInvalid", "GroundPlane"]

@@ -122,6 +122,7 @@ _SIGNATURES = [
     ("mld_order_after", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mld_pair_contexts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mld_set_shared_gpu", C.c_int, [C.c_void_p, C.c_int]),
+    ("mld_set_list_capacity", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("mld_set_cloud", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     ("mld_set_cloud_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     ("mld_set_clouds_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64), C.c_int]),

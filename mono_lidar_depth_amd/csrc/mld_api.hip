@@ -134,6 +134,8 @@ struct mld_ctx {
     size_t rsb_mask_words = 0;       // per slot
     PlaneDev* rsb_planes = nullptr;  // one per slot
     uint32_t* rsb_seeds = nullptr;
+    int32_t* rsb_sample_idx = nullptr;  // z pass-through: original indices of every slot's sample (kSample each)
+    size_t rsb_lds = 0;                 // dynamic LDS the kernel has been enabled for
     hipStream_t side = nullptr;  // the plane's inlier mask is built here while the cloud is still in flight
     hipEvent_t side_done = nullptr;
     hipEvent_t order_ev = nullptr;  // mld_order_after
@@ -143,6 +145,7 @@ struct mld_ctx {
     bool proj_owned = false;
     hipEvent_t proj_fork = nullptr, proj_join = nullptr;
     size_t lds_fused_pad = 0;       // mld_set_shared_gpu
+    int shared_arg = 0;             // its last argument (re-applied when the list capacities change)
     int fused_blocks_per_cu = 8;    // mld_set_shared_gpu: wavefronts of k_feature_fused per CU in the shared mode
     int classify_threads = 1024;    // mld_set_shared_gpu bits 1..2: 256- / 512-thread k_classify blocks
     size_t lds_per_cu = 0;          // device property
@@ -861,6 +864,7 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->rsb_masks) (void)hipFree(ctx->rsb_masks);
     if (ctx->rsb_planes) (void)hipFree(ctx->rsb_planes);
     if (ctx->rsb_seeds) (void)hipFree(ctx->rsb_seeds);
+    if (ctx->rsb_sample_idx) (void)hipFree(ctx->rsb_sample_idx);
     if (ctx->fr_host) (void)hipHostFree(ctx->fr_host);
     if (ctx->fr_dev) (void)hipFree(ctx->fr_dev);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
@@ -923,6 +927,7 @@ int mld_set_shared_gpu(mld_ctx* ctx, int shared) {
     // k_feature_fused is capped by its LDS request: 14 KB per wavefront -> 11 per CU (3 per SIMD, which is all the
     // VGPRs there are at 168 per wave); 20 KB -> 8 per CU, 2 per SIMD, and a third of the register file stays free
     // for the projection wavefronts (48 VGPRs each) of a context running beside this one.
+    ctx->shared_arg = shared;
     ctx->classify_threads = (shared & 2) ? 256 : ((shared & 4) ? 512 : 1024);
     int blocks = (shared >> 8) & 0xFF;  // bits 8..15: wavefronts per CU (0 = the default, 8)
     if (blocks <= 0) blocks = 8;
@@ -930,6 +935,16 @@ int mld_set_shared_gpu(mld_ctx* ctx, int shared) {
     const size_t per_cu = ctx->lds_per_cu ? ctx->lds_per_cu : 160 * 1024, want = (per_cu / (size_t)blocks) & ~(size_t)255;
     ctx->lds_fused_pad = ((shared & 1) && ctx->lds_fused < want) ? want - ctx->lds_fused : 0;
     return MLD_OK;
+}
+
+int mld_set_list_capacity(mld_ctx* ctx, int wide_entries, int narrow_entries) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    if (narrow_entries < 8 || narrow_entries > wide_entries || wide_entries > kK1MaxLimit)
+        return fail(ctx, MLD_ERR_INVALID_ARG, "list capacities: 8 <= narrow <= wide <= 64");
+    ctx->calib.k1max = wide_entries;
+    ctx->calib.kMain = narrow_entries;
+    ctx->lds_fused = (size_t)(wide_entries + narrow_entries) * kWave * sizeof(uint32_t);
+    return mld_set_shared_gpu(ctx, ctx->shared_arg);
 }
 
 // ---------------------------------------------------------------------------- setInputCloud
@@ -1026,8 +1041,20 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
     if (!P.do_use_ransac_plane) return set_clouds_common(ctx, n_slots, pts_dev, n, stride_bytes, nullptr, nullptr);
     const int n_draws = P.ransac_plane_max_iterations + 1;
     if (n_draws < 1) return fail(ctx, MLD_ERR_INVALID_ARG, "ransac_plane_max_iterations must be >= 0");
-    if (P.ransac_plane_min_z > -1001.) {
-        // z pass-through (RansacPlane.cpp:57-64): ordered compaction of the whole cloud, per-slot path
+    // every slot's arguments are checked before anything is queued or any slot state changes
+    for (int i = 0; i < n_slots; i++)
+        if ((rc = check_cloud_args(ctx, pts_dev[i], n[i], stride_bytes))) return rc;
+    int64_t max_n = 0;
+    for (int i = 0; i < n_slots; i++) max_n = std::max(max_n, n[i]);
+    // z pass-through (RansacPlane.cpp:57-64) inside the batched kernel: one byte of LDS per 64 points + one int per 1024
+    const bool pass = P.ransac_plane_min_z > -1001.;
+    const size_t lds_fixed = (size_t)kSample * 4 * sizeof(float) + (size_t)kPartials * 9 * sizeof(float) +
+                             (2 * kRsRound + 8) * sizeof(int);
+    const size_t n_chunks = (size_t)((max_n + 1023) / 1024);
+    const size_t lds = lds_fixed + (pass ? (n_chunks + 1) * sizeof(int) + 16 * n_chunks + 16 : 0);
+    if (lds > 150 * 1024) {
+        // clouds beyond ~2.3 M points with the pass-through: the per-slot estimator (ordered compaction in device
+        // memory), which synchronises once per slot
         if ((rc = set_clouds_common(ctx, n_slots, pts_dev, n, stride_bytes, nullptr, nullptr))) return rc;
         for (int i = 0; i < n_slots; i++) {
             rc = mld_estimate_ground_plane(ctx, i, seeds[i], nullptr, nullptr);
@@ -1039,12 +1066,7 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
         }
         return MLD_OK;
     }
-    // every slot's arguments are checked before anything is queued or any slot state changes
-    for (int i = 0; i < n_slots; i++)
-        if ((rc = check_cloud_args(ctx, pts_dev[i], n[i], stride_bytes))) return rc;
-    int64_t max_n = 0;
-    for (int i = 0; i < n_slots; i++) max_n = std::max(max_n, n[i]);
-    const size_t words = (size_t)((max_n + 31) / 32) + 1;
+    const size_t words = (((size_t)((max_n + 31) / 32) + 2) & ~(size_t)1);  // even: the words double as 64-bit group masks
     if (!ctx->rsb_planes || words > ctx->rsb_mask_words) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->rsb_masks) HIP_TRY(ctx, hipFree(ctx->rsb_masks));
@@ -1054,11 +1076,14 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
         if (!ctx->rsb_planes) {
             HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_planes, ctx->slots.size() * sizeof(PlaneDev)));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_seeds, ctx->slots.size() * sizeof(uint32_t)));
-            const size_t lds = (size_t)kSample * 4 * sizeof(float) + (size_t)kPartials * 9 * sizeof(float) +
-                               (2 * kRsRound + 8) * sizeof(int);
-            HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_batch),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
+    }
+    if (pass && !ctx->rsb_sample_idx)
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_sample_idx, ctx->slots.size() * (size_t)kSample * sizeof(int32_t)));
+    if (lds > ctx->rsb_lds) {
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_batch),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->rsb_lds = lds;
     }
     hipStream_t st = projection_fork(ctx, rc);
     if (rc) return rc;
@@ -1078,12 +1103,11 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
     if ((rc = upload_descs(ctx, n_slots, st))) return rc;
     {
         ScopedTimer tm(ctx, 4, st);
-        const size_t lds = (size_t)kSample * 4 * sizeof(float) + (size_t)kPartials * 9 * sizeof(float) +
-                           (2 * kRsRound + 8) * sizeof(int);
         hipLaunchKernelGGL(k_rs_batch, dim3((unsigned)n_slots), dim3(kRsThreads), lds, st, ctx->d_slots, ctx->rsb_seeds,
                            n_draws, P.ransac_plane_max_iterations, P.ransac_plane_probability,
                            P.ransac_plane_distance_treshold, P.ransac_plane_refinement_treshold,
-                           P.ransac_plane_use_refinement, ctx->rsb_planes);
+                           P.ransac_plane_use_refinement, ctx->rsb_planes, pass ? 1 : 0, (float)P.ransac_plane_min_z,
+                           (float)P.ransac_plane_max_z, ctx->rsb_sample_idx);
         HIP_TRY(ctx, hipGetLastError());
     }
     if ((rc = launch_project(ctx, n_slots, max_n, false, 0, st))) return rc;
@@ -1097,16 +1121,29 @@ int mld_get_estimated_planes(mld_ctx* ctx, int n_slots, float* coeffs_out, int64
     if (n_slots < 1 || n_slots > (int)ctx->slots.size()) return fail(ctx, MLD_ERR_INVALID_ARG, "bad slot count");
     int rc = bind_device(ctx);
     if (rc) return rc;
-    if (!ctx->rsb_planes) return fail(ctx, MLD_ERR_NOT_INITIALIZED, "no batched plane estimation has run");
     std::vector<PlaneDev> h((size_t)n_slots);
-    HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->rsb_planes, h.size() * sizeof(PlaneDev), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->rsb_planes)
+        HIP_TRY(ctx, hipMemcpyAsync(h.data(), ctx->rsb_planes, h.size() * sizeof(PlaneDev), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n_slots; i++) {
-        const bool on_dev = ctx->slots[i].d.plane_dev != nullptr;
+        const Slot& s = ctx->slots[i];
+        const bool on_dev = s.d.plane_dev != nullptr && ctx->rsb_planes;
         if (coeffs_out)
-            for (int t = 0; t < 4; t++) coeffs_out[4 * i + t] = on_dev ? h[i].coeffs[t] : ctx->slots[i].d.coeffs[t];
-        if (n_inliers_out) n_inliers_out[i] = on_dev ? h[i].n_inliers : -1;
-        if (status_out) status_out[i] = on_dev ? h[i].status : (ctx->slots[i].d.has_plane ? 0 : 1);
+            for (int t = 0; t < 4; t++) coeffs_out[4 * i + t] = on_dev ? h[i].coeffs[t] : (s.d.has_plane ? s.d.coeffs[t] : 0.f);
+        if (status_out) status_out[i] = on_dev ? h[i].status : (s.d.has_plane ? 0 : 1);
+        if (n_inliers_out) {
+            if (on_dev) {
+                n_inliers_out[i] = h[i].n_inliers;
+            } else if (s.d.has_plane && s.d.inlier_mask) {
+                // a slot whose plane was estimated by the per-slot path (or handed in): count its mask
+                int64_t k = 0;
+                int rc2 = mld_get_ground_plane_inliers(ctx, i, nullptr, 0, &k);
+                if (rc2) return rc2;
+                n_inliers_out[i] = k;
+            } else {
+                n_inliers_out[i] = 0;
+            }
+        }
     }
     return MLD_OK;
 }
@@ -1519,6 +1556,10 @@ int mld_calculate_depth_frame(mld_ctx* ctx, int slot, const void* pts_host, int6
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
     }
     // The small inputs go first, on the side stream: their DMA and the mask build run while the cloud is in flight.
+    // (The side stream starts after whatever is already queued on the context's stream: an earlier asynchronous call
+    // on this slot may still read the mask buffer and the staging block that are rewritten here.)
+    HIP_TRY(ctx, hipEventRecord(ctx->side_done, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->side_done, 0));
     if (n_inl) std::memcpy(ctx->fr_host, inlier_idx_host, n_inl * sizeof(int32_t));
     if (F) std::memcpy(ctx->fr_host + off_uv, uv_host, (size_t)F * 2 * sizeof(double));
     if (off_depth) HIP_TRY(ctx, hipMemcpyAsync(ctx->fr_dev, ctx->fr_host, off_depth, hipMemcpyHostToDevice, ctx->side));

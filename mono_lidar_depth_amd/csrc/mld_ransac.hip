@@ -326,8 +326,11 @@ __global__ __launch_bounds__(kPartials) void k_rs_refine(const float* __restrict
 // hypotheses in rounds of 16 (one wavefront each) with PCL's sequential stopping rule replayed after every round,
 // refinement, inlier bitmask — and leaves the plane in device memory (PlaneDev) where the feature kernels read it.
 // No host round trip.  Arithmetic and association orders are those of the single-slot kernels above (bit-identical
-// results).  The z pass-through (:57-64) needs an ordered compaction of the whole cloud and is not part of this form:
-// the host falls back to the per-slot path when it is enabled.
+// results).
+// The z pass-through (:57-64) - an order-preserving selection over the whole cloud - needs no compacted index list here:
+// a first pass leaves one 64-bit candidate mask per 64 points in the slot's (still unused) inlier-mask words and the
+// candidate count of every group in LDS; the pos-th candidate of the stratified sample is then found by a binary search
+// over per-1024-point prefix sums, a walk over the sixteen group counts of that chunk and a bit select in its mask.
 // ------------------------------------------------------------------------------------------------
 constexpr int kRsThreads = 1024;
 constexpr int kRsRound = kRsThreads / kWave;  // hypotheses evaluated per round
@@ -342,22 +345,36 @@ __device__ inline long long sample_pos(long long M, int j, uint32_t seed) {
     return pos;
 }
 
+// k-th (0-based) set bit of m
+__device__ inline int select_bit(unsigned long long m, int k) {
+    for (int t = 0; t < k; t++) m &= m - 1ull;
+    return __ffsll((long long)m) - 1;
+}
+
+// pass != 0: pcl::PassThrough on z with the float limits [lo, hi] ahead of the sub-sampling; sample_idx (kSample
+// int32 per slot, device scratch) then holds the original indices of the sample.  LDS beyond the fixed part: one byte
+// per 64 points + one int per 1024 points.
 __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restrict__ slots, const uint32_t* __restrict__ seeds,
                                                         int n_draws, int max_it, double probability, double thr,
-                                                        double refine_thr, int use_refinement, PlaneDev* out) {
+                                                        double refine_thr, int use_refinement, PlaneDev* out, int pass,
+                                                        float lo, float hi, int32_t* __restrict__ sample_idx_all) {
     extern __shared__ __align__(16) unsigned char rs_smem[];
-    float* sp = reinterpret_cast<float*>(rs_smem);                 // [3 * kSample]
-    int* inl_pos = reinterpret_cast<int*>(sp + 3 * kSample);       // [kSample]
+    // the sample as three coordinate arrays (structure of arrays): a lane reads four consecutive points with three
+    // 16-byte LDS loads in the hypothesis loop, which is what this kernel spends its time in
+    float* sx = reinterpret_cast<float*>(rs_smem);                 // [kSample]
+    float* sy = sx + kSample;                                      // [kSample]
+    float* sz = sy + kSample;                                      // [kSample]
+    int* inl_pos = reinterpret_cast<int*>(sz + kSample);           // [kSample]
     float* acc = reinterpret_cast<float*>(inl_pos + kSample);      // [kPartials * 9]
     int* counts = reinterpret_cast<int*>(acc + kPartials * 9);     // [kRsRound]
     int* wsum = counts + kRsRound;                                 // [kRsRound]
-    int* misc = wsum + kRsRound;                                   // [0] running offset, [1] inlier total
+    int* misc = wsum + kRsRound;                                   // [0] running offset, [1] inlier total, [2] candidates
     const SlotDesc s = slots[blockIdx.x];
     PlaneDev* pd = out + blockIdx.x;
     const uint32_t seed = seeds[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid >> 6;
-    const long long M = s.n;
-    const int S = M > kSample ? kSample : (int)M;
+    long long M = s.n;
+    int S = M > kSample ? kSample : (int)M;
     auto fail = [&]() {
         if (tid == 0) {
             pd->has_plane = 0;
@@ -370,12 +387,108 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         fail();
         return;
     }
-    for (int j = tid; j < S; j += kRsThreads) {
-        const float* p = reinterpret_cast<const float*>(s.cloud + (size_t)sample_pos(M, j, seed) * (size_t)s.stride);
-        sp[3 * j] = p[0];
-        sp[3 * j + 1] = p[1];
-        sp[3 * j + 2] = p[2];
+    int32_t* sample_idx = sample_idx_all ? sample_idx_all + (size_t)blockIdx.x * kSample : nullptr;
+    if (pass) {
+        const long long n = s.n;
+        const int G = (int)((n + kWave - 1) / kWave), NC = (G + 15) / 16;  // 64-point groups, 1024-point chunks
+        int* cpre = misc + 8;                                              // [NC + 1] candidates before chunk c
+        unsigned char* gcnt = reinterpret_cast<unsigned char*>(cpre + NC + 1);  // [16 * NC] candidates per group
+        // the slot's inlier-mask words (n / 8 bytes, written only at the very end) hold the group masks meanwhile
+        unsigned long long* gm = reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(s.inlier_mask));
+        for (int g = w; g < 16 * NC; g += kRsRound) {  // a wavefront per group, no barrier in between
+            const long long i = (long long)g * kWave + lane;
+            bool f = false;
+            if (i < n) {
+                const float* p = reinterpret_cast<const float*>(s.cloud + (size_t)i * (size_t)s.stride);
+                const float x = p[0], y = p[1], z = p[2];
+                f = isfinite(x) && isfinite(y) && isfinite(z) && !(z < lo) && !(z > hi);  // k_rs_flags
+            }
+            const unsigned long long m = __ballot(f);
+            if (lane == 0) {
+                if (g < G) gm[g] = m;
+                gcnt[g] = (unsigned char)__popcll(m);
+            }
+        }
+        __syncthreads();
+        // exclusive prefix over the chunks (thread c sums its sixteen groups; one wavefront scans)
+        for (int c = tid; c < NC; c += kRsThreads) {
+            int t = 0;
+            for (int q = 0; q < 16; q++) t += gcnt[16 * c + q];
+            cpre[c + 1] = t;
+        }
+        if (tid == 0) cpre[0] = 0;
+        __syncthreads();
+        if (w == 0) {
+            int carry = 0;
+            for (int c0 = 0; c0 < NC; c0 += kWave) {
+                const int c = c0 + lane;
+                int v = (c < NC) ? cpre[c + 1] : 0, incl = v;
+#pragma unroll
+                for (int d = 1; d < kWave; d <<= 1) {
+                    const int t = __shfl_up(incl, d);
+                    if (lane >= d) incl += t;
+                }
+                if (c < NC) cpre[c + 1] = carry + incl;
+                carry += __shfl(incl, kWave - 1);
+            }
+            if (lane == 0) misc[2] = carry;
+        }
+        __syncthreads();
+        M = misc[2];
+        S = M > kSample ? kSample : (int)M;
+        if (M < 3) {  // fewer than three candidates: no model (k_rs_select: status 1)
+            __syncthreads();
+            for (int g = tid; g < G; g += kRsThreads) gm[g] = 0ull;  // hand the mask words back cleared
+            fail();
+            return;
+        }
+        for (int j = tid; j < S; j += kRsThreads) {
+            const int pos = (int)sample_pos(M, j, seed);
+            int a = 0, b = NC;  // cpre[a] <= pos < cpre[b]
+            while (b - a > 1) {
+                const int mid = (a + b) >> 1;
+                if (cpre[mid] <= pos) a = mid; else b = mid;
+            }
+            int r = pos - cpre[a], g = 16 * a;
+            while (r >= (int)gcnt[g]) {
+                r -= (int)gcnt[g];
+                g++;
+            }
+            const int idx = g * kWave + select_bit(gm[g], r);
+            sample_idx[j] = idx;
+            const float* p = reinterpret_cast<const float*>(s.cloud + (size_t)idx * (size_t)s.stride);
+            sx[j] = p[0];
+            sy[j] = p[1];
+            sz[j] = p[2];
+        }
+        __syncthreads();
+        for (int g = tid; g < G; g += kRsThreads) gm[g] = 0ull;  // the words become the inlier mask again
+    } else {
+        for (int j = tid; j < S; j += kRsThreads) {
+            const float* p = reinterpret_cast<const float*>(s.cloud + (size_t)sample_pos(M, j, seed) * (size_t)s.stride);
+            sx[j] = p[0];
+            sy[j] = p[1];
+            sz[j] = p[2];
+        }
     }
+    // point j of the sample / its distance to a model (plane_dist's arithmetic)
+    auto dist = [&](const float c[4], int j) { return fabsf(c[0] * sx[j] + c[1] * sy[j] + c[2] * sz[j] + c[3]); };
+    auto model_of = [&](int d) {  // draw_model on the LDS sample
+        uint32_t a = mix(seed, (uint32_t)d, 1u) % (uint32_t)S;
+        uint32_t b = mix(seed, (uint32_t)d, 2u) % (uint32_t)S;
+        uint32_t c = mix(seed, (uint32_t)d, 3u) % (uint32_t)S;
+        if (b == a) b = (b + 1) % (uint32_t)S;
+        while (c == a || c == b) c = (c + 1) % (uint32_t)S;
+        const float p0[3] = {sx[a], sy[a], sz[a]}, p1[3] = {sx[b], sy[b], sz[b]}, p2[3] = {sx[c], sy[c], sz[c]};
+        return plane_from(p0, p1, p2);
+    };
+    // "(double)distance < thr" for a float distance == "distance < thr_f" with thr_f the smallest float >= thr
+    auto up = [](double t) {
+        float f = (float)t;
+        if ((double)f < t) f = nextafterf(f, __builtin_huge_valf());
+        return f;
+    };
+    const float thr_f = up(thr);
     if (tid == 0) {
         misc[0] = 0;
         misc[1] = 0;
@@ -392,11 +505,22 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         int cnt = 0;
         bool degenerate = false;
         if (d < n_draws) {
-            const Model m = draw_model(sp, S, seed, d);
+            const Model m = model_of(d);
             degenerate = m.degenerate != 0;
-            if (m.valid)
-                for (int j = lane; j < S; j += kWave)
-                    if ((double)plane_dist(m.c, sp + 3 * j) < thr) cnt++;
+            if (m.valid) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const float c0 = m.c[0], c1 = m.c[1], c2 = m.c[2], c3 = m.c[3];
+                for (int j0 = 4 * lane; j0 < S; j0 += 4 * kWave) {  // four consecutive points per lane and iteration
+                    if (j0 + 3 < S) {
+                        const f4 x = *reinterpret_cast<const f4*>(sx + j0), y = *reinterpret_cast<const f4*>(sy + j0),
+                                 z = *reinterpret_cast<const f4*>(sz + j0);
+#pragma unroll
+                        for (int t = 0; t < 4; t++) cnt += (fabsf(c0 * x[t] + c1 * y[t] + c2 * z[t] + c3) < thr_f) ? 1 : 0;
+                    } else {
+                        for (int j = j0; j < S; j++) cnt += (dist(m.c, j) < thr_f) ? 1 : 0;
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
@@ -430,14 +554,14 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         fail();
         return;
     }
-    const Model bm = draw_model(sp, S, seed, best_draw);
+    const Model bm = model_of(best_draw);
     const float rm[4] = {bm.c[0], bm.c[1], bm.c[2], bm.c[3]};
     float coeffs[4] = {rm[0], rm[1], rm[2], rm[3]};
     const bool valid = fabs((double)rm[2]) >= 0.984807753012208;
     // ---- ordered list of the RANSAC inliers (positions in the sample), as k_rs_refine ----
     for (int c0 = 0; c0 < S; c0 += kRsThreads) {
         const int j = c0 + tid;
-        const bool in = (j < S) && valid && ((double)plane_dist(rm, sp + 3 * j) < thr);
+        const bool in = (j < S) && valid && (dist(rm, j) < thr_f);
         const unsigned long long m = __ballot(in);
         if (lane == 0) wsum[w] = __popcll(m);
         __syncthreads();
@@ -457,7 +581,8 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         if (tid < kPartials) {  // thread p owns inliers p, p + 256, ...: the association of the single-slot kernel
             float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
             for (int q = tid; q < ni; q += kPartials) {
-                const float* v = sp + 3 * inl_pos[q];
+                const int jq = inl_pos[q];
+                const float v[3] = {sx[jq], sy[jq], sz[jq]};
                 a[0] += v[0] * v[0];
                 a[1] += v[0] * v[1];
                 a[2] += v[0] * v[2];
@@ -490,11 +615,11 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         }
     }
     // ---- final inlier set (bitmask keyed by original index; the host cleared it before the launch) ----
-    const double sel_thr = use_refinement ? refine_thr : thr;
+    const float sel_thr = up(use_refinement ? refine_thr : thr);
     int cnt = 0;
     for (int j = tid; j < S; j += kRsThreads) {
-        if (valid && ((double)plane_dist(rm, sp + 3 * j) < sel_thr)) {
-            const uint32_t id = (uint32_t)sample_pos(M, j, seed);
+        if (valid && (dist(rm, j) < sel_thr)) {
+            const uint32_t id = pass ? (uint32_t)sample_idx[j] : (uint32_t)sample_pos(M, j, seed);
             const uint32_t bit = 1u << (id & 31);
             cnt += (atomicOr(const_cast<uint32_t*>(s.inlier_mask) + (id >> 5), bit) & bit) ? 0 : 1;  // duplicates count once
         }

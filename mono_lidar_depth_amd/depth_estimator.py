@@ -243,6 +243,11 @@ class DepthEstimator:
         finished (device-side; mld_order_after)."""
         self._check(self._lib.mld_order_after(self._ctx, other._ctx))
 
+    def setListCapacity(self, wide: int, narrow: int):
+        """Neighbour-list capacities of the lane-per-feature kernel (mld_set_list_capacity): 32 / 24 by default, 48 / 24
+        for dense (128-beam) clouds."""
+        self._check(self._lib.mld_set_list_capacity(self._ctx, int(wide), int(narrow)))
+
     def pairWith(self, other: "DepthEstimator"):
         """The batched projections of this context and `other` run back to back on one stream (owned by this context),
         each context's feature kernels on its own (mld_pair_contexts).  Close `other` first."""
@@ -356,17 +361,28 @@ class DepthEstimator:
                                                      b["coeffs"].ctypes.data_as(C.POINTER(C.c_float)), b["mask_ptrs"]))
         self._check(lib.mld_calculate_depths_device(ctx, n, b["uv_ptrs"], b["F"], b["depth_ptrs"], b["type_ptrs"]))
 
-    def runBatchBeside(self, b, nxt: "DepthEstimator"):
-        """runBatch for a context that alternates with `nxt` on one GPU: `nxt`'s next projection is released when this
-        batch's projection is done, i.e. it runs beside this batch's feature kernels (HBM streaming beside gather / f64
-        work: include/mld.h "Two contexts").  Call `setSharedGpu()` on both contexts once."""
+    def projectBatch(self, b):
+        """setInputCloud(cloud, plane) of a prepared batch: the projection launch only."""
         lib, ctx, n = self._lib, self._ctx, b["n"]
         self._after_torch(b["keep"][0][0])
         self._check(lib.mld_set_clouds_planes_device(ctx, n, b["cloud_ptrs"], b["cloud_n"], b["stride"],
                                                      b["coeffs"].ctypes.data_as(C.POINTER(C.c_float)), b["mask_ptrs"]))
+
+    def featuresBatchBeside(self, b, nxt: "DepthEstimator"):
+        """CalculateDepth of a prepared batch whose projection is already queued; the NEXT context's projection is
+        released first (unless the two are paired: their projections are in call order on the shared stream)."""
         if nxt is not self and not getattr(self, "_paired", False):
-            nxt.orderAfter(self)  # (a pair's projections are already in call order on their shared stream)
-        self._check(lib.mld_calculate_depths_device(ctx, n, b["uv_ptrs"], b["F"], b["depth_ptrs"], b["type_ptrs"]))
+            nxt.orderAfter(self)
+        self._check(self._lib.mld_calculate_depths_device(self._ctx, b["n"], b["uv_ptrs"], b["F"], b["depth_ptrs"],
+                                                          b["type_ptrs"]))
+
+    def runBatchBeside(self, b, nxt: "DepthEstimator"):
+        """`runBatch` for two (or more) contexts used in turn: context `nxt`, which will take the next batch, is released
+        as soon as THIS batch's projection has finished, so that its projection runs beside this batch's feature kernels
+        (HBM-bound work beside gather-bound work: include/mld.h "Two contexts").  Call `setSharedGpu()` on both contexts
+        once."""
+        self.projectBatch(b)
+        self.featuresBatchBeside(b, nxt)
 
     def estimateGroundPlane(self, slot: int = 0, seed: int = 0):
         """RansacPlane::CalculateInliersPlane on the GPU for the slot's cloud; installs the plane.
@@ -463,10 +479,9 @@ class DepthEstimator:
         VectorXd / VectorXi of the reference — as numpy arrays (host input) or torch CUDA tensors (device input;
         asynchronous inputs on torch's current stream are waited for, the results are complete on return).
         """
-        self._uv_layout = uv_layout
         if len(args) == 3:
             cloud, uv, gp = args
-            fast = self._frame_call(cloud, uv, gp, slot)
+            fast = self._frame_call(cloud, uv, gp, slot, uv_layout)
             if fast is not None:
                 return fast if return_types else fast[0]
             self.setInputCloud(cloud, gp, slot=slot)
@@ -477,7 +492,7 @@ class DepthEstimator:
         self._require_init("CalculateDepth")
         if _is_torch_cuda(uv):
             import torch
-            uvd = self._uv_device(uv)
+            uvd = self._uv_device(uv, uv_layout)
             F = int(uvd.numel() // 2)
             depth = torch.empty(F, dtype=torch.float64, device=uvd.device)
             types = torch.empty(F, dtype=torch.int32, device=uvd.device)
@@ -486,7 +501,7 @@ class DepthEstimator:
                                                              types.data_ptr()))
             self.synchronize()
             return (depth, types) if return_types else depth
-        uvh = self._uv_host(uv)
+        uvh = self._uv_host(uv, uv_layout)
         F = int(uvh.size // 2)
         depth = np.empty(F, dtype=np.float64)
         types = np.empty(F, dtype=np.int32)
@@ -501,7 +516,7 @@ class DepthEstimator:
         self._last_types = types
         return (depth, types) if return_types else depth
 
-    def _frame_call(self, cloud, uv, gp, slot):
+    def _frame_call(self, cloud, uv, gp, slot, uv_layout=None):
         """CalculateDepth(cloud, uv, groundPlane) entirely from host memory with a plane that needs no estimation: the
         single-call entry point mld_calculate_depth_frame (one frame per call, the ROS usage).  None: not applicable."""
         self._require_init("CalculateDepth")
@@ -514,7 +529,7 @@ class DepthEstimator:
             if isinstance(gp, RansacPlane) and gp.inliers is None:
                 return None
         ptr, n, stride, keep = self._cloud_view(cloud)
-        uvh = self._uv_host(uv)
+        uvh = self._uv_host(uv, uv_layout)
         F = int(uvh.size // 2)
         depth = np.empty(F, dtype=np.float64)
         types = np.empty(F, dtype=np.int32)
@@ -576,11 +591,11 @@ class DepthEstimator:
             self._check(self._lib.mld_get_ground_plane_cloud(self._ctx, slot, out.ctypes.data, n.value, C.byref(n)))
         return out.T
 
-    def _uv_host(self, uv) -> np.ndarray:
+    @staticmethod
+    def _uv_host(uv, layout: Optional[str] = None) -> np.ndarray:
         a = np.asarray(uv, dtype=np.float64)
         if a.ndim != 2:
             raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "uv must be 2xF or Fx2")
-        layout = getattr(self, "_uv_layout", None)
         if layout not in (None, "2xF", "Fx2"):
             raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "uv_layout must be '2xF' or 'Fx2'")
         if a.shape == (2, 2) and layout is None:
@@ -596,9 +611,22 @@ class DepthEstimator:
         return np.ascontiguousarray(a)
 
     @staticmethod
-    def _uv_device(uv):
+    def _uv_device(uv, layout: Optional[str] = None):
+        """Device features as contiguous float64 [F,2] (= column-major 2 x F).  Same layout rule as the host path: a
+        2 x 2 tensor needs `layout`; "2xF" (Eigen::Matrix2Xd) is transposed into a new tensor."""
         import torch
-        if uv.dtype != torch.float64 or uv.dim() != 2 or uv.shape[1] != 2 or not uv.is_contiguous():
+        if layout not in (None, "2xF", "Fx2"):
+            raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "uv_layout must be '2xF' or 'Fx2'")
+        if uv.dtype != torch.float64 or uv.dim() != 2:
+            raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "device uv must be float64 [F,2] (or [2,F] with uv_layout='2xF')")
+        if tuple(uv.shape) == (2, 2) and layout is None:
+            raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG,
+                                      "a 2x2 uv tensor is ambiguous: pass uv_layout='2xF' (Eigen::Matrix2Xd) or 'Fx2'")
+        if layout == "2xF":
+            if uv.shape[0] != 2:
+                raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "uv must be 2xF")
+            return uv.t().contiguous()
+        if uv.shape[1] != 2 or not uv.is_contiguous():
             raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "device uv must be contiguous float64 [F,2]")
         return uv
 

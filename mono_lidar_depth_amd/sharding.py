@@ -88,3 +88,17 @@ def sum_over_ranks(value: float, device=None) -> float:
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_over_ranks(value: float, device=None):
+    """The value of every rank, in rank order (per-rank figures of the benchmark's multi-GPU line)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64)
+    if device is not None:
+        t = t.to(device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]

@@ -94,3 +94,58 @@ class TrackletDepthModule:
 
     def tracklet(self, track_id: int):
         return list(self._tracklet_map[track_id])
+
+
+class TrackletBatch:
+    """The tracklet layer for S independent sequences at once (mld_set_clouds_planes_range_device +
+    mld_tracklets_depths_device): the estimator's frame slots are two banks of S slots, sequence s keeps its current
+    frame in slot bank * S + s and its previous frame, still resident, in the other bank.  Device tensors in, device
+    tensors out; asynchronous.  (Track bookkeeping per sequence is the caller's, as in TrackletDepthModule.)"""
+
+    def __init__(self, parameters, camera: CameraPinhole, transform_lidar_to_cam, n_seq: int, max_tracks: int,
+                 device: int = 0, list_capacity=None):
+        self.S = int(n_seq)
+        self.est = DepthEstimator(device=device, max_frames=2 * self.S, max_features=max_tracks)
+        self.est.InitConfig(parameters)
+        self.est.Initialize(camera, transform_lidar_to_cam)
+        if list_capacity:
+            self.est.setListCapacity(*list_capacity)
+        self.bank = 0
+        self.have_last = False
+        self._keep = None
+
+    def prepare(self, clouds, coeffs, masks, u_new, v_new, u_old, v_old, is_new, d_cur, d_last, t_cur=None, t_last=None):
+        """Pointer tables of one frame of every sequence (reusable: a steady-state caller prepares one per bank).
+        clouds / masks: S torch CUDA tensors ([N,4] float32 / int32 inlier bitmask), coeffs [S,4] float32 (host);
+        u_new ... is_new: S CUDA tensors each (float32 x4, uint8); outputs: S CUDA float32 tensors (d_cur, d_last) and
+        optional int32 (t_cur, t_last)."""
+        S = self.S
+        vp = lambda ts: (C.c_void_p * S)(*[int(t.data_ptr()) for t in ts])  # noqa: E731
+        co = np.ascontiguousarray(coeffs, dtype=np.float32).reshape(S, 4)
+        return {"clouds": vp(clouds), "n": (C.c_int64 * S)(*[int(c.shape[0]) for c in clouds]), "coeffs": co,
+                "masks": vp(masks), "u_new": vp(u_new), "v_new": vp(v_new), "u_old": vp(u_old), "v_old": vp(v_old),
+                "is_new": vp(is_new), "nt": (C.c_int64 * S)(*[int(t.shape[0]) for t in u_new]), "d_cur": vp(d_cur),
+                "d_last": vp(d_last), "t_cur": vp(t_cur) if t_cur is not None else None,
+                "t_last": vp(t_last) if t_last is not None else None,
+                "keep": (list(clouds), list(masks), list(u_new), list(v_new), list(u_old), list(v_old), list(is_new),
+                         list(d_cur), list(d_last), t_cur, t_last)}
+
+    def run(self, f):
+        """One frame of every sequence from prepared tables: projection of the current bank, then the tracklet call."""
+        S, est, lib = self.S, self.est, self.est._lib
+        est._check(lib.mld_set_clouds_planes_range_device(est._ctx, self.bank * S, S, f["clouds"], f["n"], 16,
+                                                          f["coeffs"].ctypes.data_as(C.POINTER(C.c_float)), f["masks"]))
+        est._check(lib.mld_tracklets_depths_device(est._ctx, S, self.bank, 1 if self.have_last else 0, f["u_new"], f["v_new"],
+                                                   f["u_old"], f["v_old"], f["is_new"], f["nt"], f["d_cur"], f["d_last"],
+                                                   f["t_cur"], f["t_last"]))
+        # the arrays must outlive the asynchronous launches; the previous frame's clouds stay referenced by their slots
+        self._keep = (self._keep[1] if self._keep else None, f)
+        self.bank = 1 - self.bank
+        self.have_last = True
+
+    def frame(self, clouds, *args, **kw):
+        self.est._after_torch(clouds[0])
+        self.run(self.prepare(clouds, *args, **kw))
+
+    def close(self):
+        self.est.close()

@@ -1,25 +1,30 @@
 #!/bin/bash
 # Profiles bench.py under rocprofv3 on the GPU box (invoke through gpurun from the repo root):
-#   gpurun -- 'bash profiles/run_profile.sh r2'
+#   gpurun -- 'bash profiles/run_profile.sh r3'
 # Writes raw output under gpurun_out/prof_<tag>/; profiles/summarize.py condenses it into profiles/<tag>_*.
-TAG=${1:-r2}
+TAG=${1:-r3}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 COMMON="--cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0"
-ARGS="--steps 200 --warmup 5 $COMMON"
+ARGS="--steps 200 --warmup 5 --repeats 1 $COMMON"
 # the bench default: two contexts alternating (a projection beside the other context's feature kernels)
 # (only launches of the timed schedule in this trace: no plane-estimated leg, no kernels-alone pass)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS --no-estimated --no-exclusive > $OUT/bench_trace.json 2> $OUT/trace.log
 # one context, one kernel at a time: what each kernel takes with the GPU to itself (1024 frames per launch)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_x -- python3 $REPO/bench.py --contexts 1 $ARGS --no-estimated > $OUT/bench_trace_x.json 2> $OUT/trace_x.log
 # the plane-estimated leg on its own (k_rs_batch)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_e -- python3 $REPO/bench.py --steps 2 --warmup 1 $COMMON --no-exclusive > $OUT/bench_trace_e.json 2> $OUT/trace_e.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_e -- python3 $REPO/bench.py --steps 2 --warmup 1 --repeats 1 $COMMON --no-exclusive > $OUT/bench_trace_e.json 2> $OUT/trace_e.log
 # counters: rocprofv3 serialises the kernels in these passes, so they are collected on the one-context schedule
-PMCARGS="--contexts 1 --steps 4 --warmup 1 $COMMON --no-kernel-timing --no-estimated"
+PMCARGS="--contexts 1 --steps 4 --warmup 1 --repeats 1 $COMMON --no-kernel-timing --no-estimated"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_write.json 2> $OUT/pmc_write.log
+# L1 / L2 request counts of the gather-bound feature kernel (gather roof)
+rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum --output-format csv -d $OUT/pmc_tcp -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_tcp.json 2> $OUT/pmc_tcp.log
+rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_tcc -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_tcc.json 2> $OUT/pmc_tcc.log
+# the random-gather line rates of this box (ceilings of that roof), same session
+if [ -x $REPO/profiles/tools/libs/randgather ]; then $REPO/profiles/tools/libs/randgather > $OUT/randgather.txt 2>&1; fi
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_sq.json 2> $OUT/pmc_sq.log
 # the other single-GPU BASELINE configs, one leg per run
 for c in 3 5; do

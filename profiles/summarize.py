@@ -7,7 +7,7 @@ import sys
 
 import pandas as pd
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 src = f"gpurun_out/prof_{tag}"
 import os
 
@@ -23,7 +23,7 @@ stats_x = newest(f"{src}/trace_x/*/*kernel_stats.csv")
 if stats_x:
     shutil.copy(stats_x, f"profiles/{tag}_kernel_stats_one_context.csv")
 lines = [f"# rocprofv3 summary — {tag}", "",
-         "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 5 "
+         "Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 200 --warmup 5 --repeats 1 "
          "--cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0` (see profiles/run_profile.sh): the "
          "bench default (with `--no-estimated --no-exclusive`, so that only launches of the timed schedule are averaged), "
          "two contexts of 1024 frame slots, consecutive steps alternating between them, so the projection "
@@ -84,7 +84,7 @@ lines += ["## PMC (per launch, mean over launches)", "",
           "(float4 cloud loads); the feature kernel's 4-B map reads / 16-B gathers are uncalibrated and left as is.", "",
           "| kernel | counter | value |", "|---|---|---|"]
 rows = {}
-for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_tcp", "pmc_tcc"):
     f_ = newest(f"{src}/{d}/*/*_counter_collection.csv")
     if not f_:
         continue
@@ -105,10 +105,45 @@ for k in ("k_project_scatter", "k_classify", "k_feature_fused"):
         traffic[k] = {"fetch_bytes_corrected": fc, "write_bytes": w, "hbm_bytes_per_launch": fc + w, "launch_s": avg}
         lines.append(f"* `{k}`: HBM traffic per launch = {fc / 1e6:,.1f} MB read (corrected) + {w / 1e6:,.1f} MB "
                      f"written = {(fc + w) / 1e6:,.1f} MB -> {(fc + w) / avg / 1e12:.2f} TB/s over the {avg * 1e6:.1f} us launch")
+# gather roof of the lane-per-feature kernel: the cache-line requests of its divergent loads (TCP = per-CU L1, TCC = L2)
+# against the line rates random gathers reach on this part (profiles/tools/randgather.hip, run in the same session)
+fk = "k_feature_fused"
+if fk in traffic and (fk, "TCP_TCC_READ_REQ_sum") in rows:
+    traffic[fk]["tcp_total_cache_accesses"] = rows.get((fk, "TCP_TOTAL_CACHE_ACCESSES_sum"), 0.0)
+    traffic[fk]["tcp_tcc_read_req"] = rows[(fk, "TCP_TCC_READ_REQ_sum")]
+    traffic[fk]["tcc_ea_rdreq"] = rows.get((fk, "TCC_EA0_RDREQ_sum"), 0.0)
+    traffic[fk]["tcc_hit"] = rows.get((fk, "TCC_HIT_sum"), 0.0)
+    traffic[fk]["tcc_miss"] = rows.get((fk, "TCC_MISS_sum"), 0.0)
+rg = f"{src}/randgather.txt"
+if os.path.exists(rg):
+    import re
+    shutil.copy(rg, f"profiles/{tag}_randgather.txt")
+    rates = {}
+    for ln in open(rg):
+        m = re.match(r"buffer\s+(\d+) KiB: 4B x4 ([\d.]+) G/s .*\| 4B x8 ([\d.]+) G/s \| 16B x4 ([\d.]+) G/s", ln)
+        if m:
+            rates[int(m.group(1))] = (float(m.group(2)), float(m.group(3)), float(m.group(4)))
+    if rates:
+        pick = lambda kb: max(rates[kb][0], rates[kb][1])  # noqa: E731  best 4-byte gather rate at that footprint
+        traffic["gather_ceilings"] = {"l1_Glines_s": pick(16), "l2_Glines_s": pick(2048), "mall_Glines_s": pick(65536),
+                                      "hbm_Glines_s": pick(4194304),
+                                      "source": f"profiles/{tag}_randgather.txt (random 64-B-line gathers, every CU issuing; "
+                                                "buffer 16 KiB / 2 MiB / 64 MiB / 4 GiB)"}
+        lines += ["", "## gather roof of `k_feature_fused`", "",
+                  f"random-gather line rates (profiles/{tag}_randgather.txt): L1 {pick(16):.1f}, L2 {pick(2048):.1f}, "
+                  f"Infinity Cache {pick(65536):.1f}, HBM {pick(4194304):.1f} G lines/s"]
+        if "tcp_tcc_read_req" in traffic.get(fk, {}):
+            t = traffic[fk]
+            l2r, ear = t["tcp_tcc_read_req"], t["tcc_ea_rdreq"]
+            floor = max(l2r - ear, 0) / (pick(2048) * 1e9) + ear / (pick(4194304) * 1e9)
+            lines.append(f"* `{fk}` per launch: {t['tcp_total_cache_accesses'] / 1e6:.1f} M L1 line accesses, {l2r / 1e6:.1f} M "
+                         f"requests to L2, {ear / 1e6:.1f} M fetched from memory -> service time at those rates "
+                         f"{floor * 1e6:.1f} us = {floor / t['launch_s']:.2f} of the {t['launch_s'] * 1e6:.1f} us launch "
+                         f"({l2r / t['launch_s'] / 1e9:.1f} G lines/s achieved)")
 try:
     traffic["frames_per_launch"] = b["config"].get("frame_slots_per_launch", b["config"]["frames_per_step"])
-    traffic["source"] = (f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, one context; "
-                         "launch_s = that kernel alone, from the --contexts 1 trace)")
+    traffic["source"] = (f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCP_* / TCC_*, separate passes, one "
+                         "context; launch_s = that kernel alone, from the --contexts 1 trace)")
     json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
 except Exception as e:  # noqa: BLE001
     print("traffic.json not written:", e)

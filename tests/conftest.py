@@ -27,7 +27,8 @@ def _native_built():
     if stale or not capi.LIB_PATH.exists() or not oracle.LIB_PATH.exists():
         import __graft_entry__
         __graft_entry__.build()
-        capi._lib = None  # load the rebuilt library
+        capi._lib = None  # load the rebuilt libraries
+        capi._lib_ab = None
     yield
 
 

@@ -11,7 +11,7 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 pytestmark = pytest.mark.gpu
 
-SMALL = ["--steps", "2", "--warmup", "1", "--frames-per-step", "32", "--unique-frames", "4", "--cpu-seconds", "0",
+SMALL = ["--steps", "2", "--warmup", "1", "--repeats", "2", "--frames-per-step", "32", "--unique-frames", "4", "--cpu-seconds", "0",
          "--latency-frames", "0", "--streaming-batches", "0", "--config-frames", "0"]
 
 
@@ -27,10 +27,19 @@ def _run(extra, env_extra=None):
 
 
 def test_bench_gpus_2_starts_two_ranks_and_each_checks_its_sequence():
-    out = _run(["--gpus", "2"] + SMALL, {"MLD_BENCH_BACKEND": "gloo"})
+    args = [a for a in SMALL]
+    i = args.index("--streaming-batches")
+    args[i + 1] = "2"  # every rank streams its own sequence as well (BASELINE config 4)
+    out = _run(["--gpus", "2"] + args + ["--streaming-frames", "4"], {"MLD_BENCH_BACKEND": "gloo"})
     assert out["n_gpus"] == 2 and out["config"]["sequences"] == 2
     assert out["verified"] is True
     assert out["value"] > 0 and out["scaling"] == "weak"
+    d = out["distributed"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["ranks_verified"] == 2
+    assert 0 < d["resident_associations_per_s_per_rank"]["min"] <= d["resident_associations_per_s_per_rank"]["max"]
+    st = out["streaming"]
+    assert st["ranks"] == 2 and st["frames_per_s"] > 0
+    assert 0 < st["frames_per_s_per_rank"]["min"] <= st["frames_per_s_per_rank"]["max"]
 
 
 def test_bench_single_rank_line_is_physical():
@@ -40,6 +49,13 @@ def test_bench_single_rank_line_is_physical():
     assert 0.0 < r["frac"] <= 1.0
     assert r["kernels"]["k_project_scatter"]["frac"] <= 1.0
     assert out["verification"]["mismatching_frames"] == []
+    # the dominant kernel is the one with the longest measured launch; both long kernels carry their own roofline
+    ks = r["kernels"]
+    assert r["kernel"] == max(("k_project_scatter", "k_feature_fused"), key=lambda k: ks[k]["avg_ms"])
+    assert ks["k_feature_fused"]["bound"] == "hbm" and 0.0 < ks["k_feature_fused"]["frac"] <= 1.0
+    # both contexts' outputs were checked, several timed loops ran
+    assert out["verification"]["output_sets"] == 2 and {o for o, _ in out["verification"]["frames_checked"]} == {0, 1}
+    assert out["timed_loops"]["repeats"] >= 2 and out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
 
 
 def test_bench_schedules_agree():
@@ -48,7 +64,7 @@ def test_bench_schedules_agree():
     appear only where two contexts share the GPU."""
     a = _run(SMALL)
     assert a["config"]["contexts"] == 2 and a["config"]["frame_slots_per_launch"] == 32
-    assert a["roofline"]["kernel"] == "k_project_scatter" and a["roofline"]["exclusive"]["frac"] > 0
+    assert a["roofline"]["kernel"] in ("k_project_scatter", "k_feature_fused") and a["roofline"]["exclusive"]["frac"] > 0
     b = _run(SMALL + ["--slots", "8"])
     assert b["verified"] is True and b["config"]["frame_slots_per_launch"] == 8
     c = _run(SMALL + ["--contexts", "1"])

@@ -165,7 +165,14 @@ def test_uv_layouts_of_the_python_mirror():
     two = np.array([[1.0, 2.0], [3.0, 4.0]])
     with pytest.raises(DepthEstimatorError, match="ambiguous"):
         e._uv_host(two)
-    e._uv_layout = "2xF"
-    assert np.array_equal(e._uv_host(two), [[1.0, 3.0], [2.0, 4.0]])  # columns (1,3) and (2,4) are the features
-    e._uv_layout = "Fx2"
-    assert np.array_equal(e._uv_host(two), two)
+    assert np.array_equal(e._uv_host(two, "2xF"), [[1.0, 3.0], [2.0, 4.0]])  # columns (1,3) and (2,4) are the features
+    assert np.array_equal(e._uv_host(two, "Fx2"), two)
+    # the device path follows the same rule (CPU tensors suffice for the shape logic)
+    import torch
+    t2 = torch.tensor(two, dtype=torch.float64)
+    with pytest.raises(DepthEstimatorError, match="ambiguous"):
+        e._uv_device(t2)
+    assert torch.equal(e._uv_device(t2, "2xF"), torch.tensor([[1.0, 3.0], [2.0, 4.0]], dtype=torch.float64))
+    assert torch.equal(e._uv_device(t2, "Fx2"), t2)
+    t5 = torch.tensor(a)
+    assert torch.equal(e._uv_device(t5), t5) and torch.equal(e._uv_device(t5.t().contiguous(), "2xF"), t5)

@@ -167,3 +167,57 @@ def test_batched_estimation_every_slot_equals_the_restatement():
     assert (st2 == 0).all()
     _check_truth(co2[0])
     _check_truth(co2[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("min_z,max_z", [(-1000.0, 1000.0), (-2.2, -0.9)])
+def test_batched_estimation_with_the_z_pass_through(min_z, max_z):
+    """The z pass-through (RansacPlane.cpp:57-64) INSIDE the batched kernel: candidate masks per 64 points instead of a
+    compacted index list.  With the reference test's own limits (+-1000 m: every finite point passes) and with limits
+    that cut the cloud, every slot of a 16-slot batch - clouds of different sizes, NaN "no return" points, one slot with
+    fewer than three candidates - has the coefficients, inlier set and count of the CPU restatement, and the depths
+    computed with those planes agree with the oracle."""
+    import torch
+    P = capi.params_c0().replace(**dict(REF_TEST_PARAMS, ransac_plane_min_z=min_z, ransac_plane_max_z=max_z,
+                                        ransac_plane_max_iterations=200))
+    B, F = 16, 500
+    est = make_estimator(P, max_frames=B, max_features=F)
+    dev = torch.device("cuda:0")
+    scanners = [synth.HDL64_KITTI, synth.HDL64, synth.VLP16]
+    clouds = [synth.make_cloud(scanners[b % 3], seed=60 + b % 5, frame=b) for b in range(B)]
+    clouds[3] = _reference_test_cloud()
+    clouds[5] = clouds[5][:777].copy()          # not a multiple of 64
+    clouds[9] = clouds[9].copy()
+    clouds[9][:, 2] = 50.0                      # nothing passes a cutting pass-through
+    seeds = [2000 + 13 * b for b in range(B)]
+    uvs = [synth.make_features(F, seed=70 + b) for b in range(B)]
+    t_clouds = [torch.from_numpy(c).to(dev) for c in clouds]
+    t_uvs = [torch.from_numpy(u).to(dev) for u in uvs]
+    d = [torch.empty(F, dtype=torch.float64, device=dev) for _ in range(B)]
+    t = [torch.empty(F, dtype=torch.int32, device=dev) for _ in range(B)]
+    torch.cuda.synchronize()
+    for rounds in range(2):  # twice: the mask words serve as scratch and must come back clean
+        est.setInputCloudsEstimatePlanes(t_clouds, seeds)
+        est.CalculateDepths(t_uvs, d, t)
+    est.synchronize()
+    coeffs, n_inl, status = est.getEstimatedPlanes(B)
+    n_failed = 0
+    for b in range(B):
+        ref = make_oracle(P)
+        ref.set_cloud(clouds[b])
+        try:
+            c0, inl0 = ref.estimate_ground_plane(seeds[b])
+        except Exception:  # noqa: BLE001  (the restatement raises where the reference throws ExceptionPclInvalid)
+            c0 = None
+        if c0 is None:
+            n_failed += 1
+            assert status[b] == 1, b
+            ref.set_ground_plane(None, None)
+        else:
+            assert status[b] == 0, b
+            assert np.array_equal(coeffs[b], c0), b
+            assert np.array_equal(est.getGroundPlaneInliers(b), inl0), b
+            assert n_inl[b] == inl0.size
+        d0, t0 = ref.calculate_depth(uvs[b])
+        assert_depth_parity(d[b].cpu().numpy(), t[b].cpu().numpy(), d0, t0)
+    assert (n_failed >= 1) if max_z < 0 else (n_failed == 0)  # slot 9 (and any slot with < 3 candidates) runs without a plane

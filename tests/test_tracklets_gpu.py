@@ -94,3 +94,64 @@ def test_tracklet_module_with_semantic_image():
         assert (t_cur == 16).sum() > 20
         known = set(int(i) for i in ids)
         ids_prev, ref_last = ids, ref_cur
+
+
+def test_tracklet_batch_of_sequences_equals_the_oracle_per_sequence():
+    """mld_tracklets_depths_device: eight sequences (different scanners, cloud sizes and track counts), three frames each,
+    both slots of every sequence - the current frame's features and the new tracks' previous features on the
+    previous frame's resident slot - against the per-sequence CPU restatement of TrackletDepthModule."""
+    import torch
+    from mono_lidar_depth_amd import TrackletBatch
+    P = capi.params_c0()
+    cam = kitti_camera()
+    dev = torch.device("cuda:0")
+    scanners = [synth.HDL64_KITTI, synth.VLP16, synth.DENSE128, synth.HDL64_KITTI, synth.VLP16, synth.HDL64_KITTI,
+                synth.VLP16, synth.HDL64_KITTI]
+    n_tracks = [2500, 1800, 6000, 1000, 3000, 2048, 64, 3333]
+    S = len(scanners)
+    tb = TrackletBatch(P, cam, synth.T_CAM_LIDAR, S, max(n_tracks), list_capacity=(48, 24))  # the dense-cloud setting
+    rng = np.random.default_rng(11)
+    ids_prev = [None] * S
+    ref_last = [None] * S
+    known = [set() for _ in range(S)]
+
+    def mask_of(inl, n):
+        m = np.zeros((n + 31) // 32, dtype=np.uint32)
+        np.bitwise_or.at(m, inl >> 5, (np.uint32(1) << (inl & 31).astype(np.uint32)))
+        return torch.from_numpy(m.view(np.int32)).to(dev)
+
+    for frame in range(3):
+        host = []
+        for s in range(S):
+            cloud = synth.make_cloud(scanners[s], seed=40 + s, frame=frame * 2)
+            coeffs, inl = synth.make_ground_plane(cloud)
+            ids, u0, v0, u1, v1 = _tracks(rng, ids_prev[s], n_tracks[s], 0.10, cam.width, cam.height)
+            is_new = np.array([int(i) not in known[s] for i in ids])
+            host.append((cloud, coeffs, inl, ids, u0, v0, u1, v1, is_new))
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        d_cur = [torch.empty(n, dtype=torch.float32, device=dev) for n in n_tracks]
+        d_last = [torch.full((n,), float("nan"), dtype=torch.float32, device=dev) for n in n_tracks]
+        t_cur = [torch.empty(n, dtype=torch.int32, device=dev) for n in n_tracks]
+        t_last = [torch.zeros(n, dtype=torch.int32, device=dev) for n in n_tracks]
+        tb.frame([to(h[0]) for h in host], np.stack([h[1] for h in host]), [mask_of(h[2], h[0].shape[0]) for h in host],
+                 [to(h[4]) for h in host], [to(h[5]) for h in host], [to(h[6]) for h in host], [to(h[7]) for h in host],
+                 [to(h[8].astype(np.uint8)) for h in host], d_cur, d_last, t_cur, t_last)
+        tb.est.synchronize()
+        for s in range(S):
+            cloud, coeffs, inl, ids, u0, v0, u1, v1, is_new = host[s]
+            ref_cur = make_oracle(P)
+            ref_cur.set_cloud(cloud)
+            ref_cur.set_ground_plane(coeffs, inl)
+            e_cur, e_last, et_cur, et_last = oracle.tracklets_depth(ref_cur, ref_last[s], u0, v0, u1, v1, is_new, n_threads=8)
+            dc, dl = d_cur[s].cpu().numpy(), d_last[s].cpu().numpy()
+            tc, tl = t_cur[s].cpu().numpy(), t_last[s].cpu().numpy()
+            assert np.array_equal(tc, et_cur), (frame, s)
+            assert np.allclose(dc, e_cur, rtol=0, atol=1e-4, equal_nan=True), (frame, s)
+            assert np.array_equal(tl[is_new], et_last[is_new]), (frame, s)
+            assert np.allclose(dl[is_new], e_last[is_new], rtol=0, atol=1e-4, equal_nan=True), (frame, s)
+            assert np.isnan(dl[~is_new]).all()
+            if frame == 0:
+                assert (dl[is_new] == -1).all()
+            known[s] = set(int(i) for i in ids)
+            ids_prev[s], ref_last[s] = ids, ref_cur
+    tb.close()
