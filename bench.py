@@ -56,9 +56,11 @@ def parse_args():
     ap.add_argument("--shared-mode", type=int, default=1,
                     help="mld_set_shared_gpu argument of the alternating contexts: 1 = on; + 256 * n = n feature-kernel "
                          "wavefronts per CU instead of 8")
-    ap.add_argument("--no-pair", action="store_true",
-                    help="two contexts: hand the projection over with mld_order_after (one event across streams) instead "
-                         "of running both contexts' projections on one shared stream (mld_pair_contexts)")
+    ap.add_argument("--pair", action="store_true",
+                    help="two contexts: run both contexts' projections on one shared stream (mld_pair_contexts) instead of "
+                         "handing the projection over with mld_order_after (one event across streams).  Measured: the "
+                         "back-to-back projections starve k_classify of wave slots and the step gets longer (0.79 / 0.90 "
+                         "against 0.77 ms); kept as an option of the library, not the bench default")
     ap.add_argument("--unique-frames", type=int, default=16, help="distinct synthetic clouds generated per rank")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
@@ -272,7 +274,7 @@ class Resident:
     """B device-resident frames (U distinct clouds, B distinct feature sets) and a context with S frame slots."""
 
     def __init__(self, P, cam, T, scanner, B, U, F, seq, device, integer_uv=False, slots=0, contexts=1, shared_mode=1,
-                 pair=True):
+                 pair=False):
         import torch
         from mono_lidar_depth_amd import DepthEstimator, synth
         dev = torch.device("cuda", device)
@@ -815,7 +817,7 @@ def main():
     U = max(1, min(args.unique_frames, B))
     seq = sharding.assign_sequences(world, world)[rank][0]  # one sequence per rank (config 4 layout)
     res = Resident(P, cam, T, synth.HDL64, B, U, F, seq, gpu_index, slots=args.slots, contexts=args.contexts,
-                   shared_mode=args.shared_mode, pair=not args.no_pair)
+                   shared_mode=args.shared_mode, pair=args.pair)
     S, N = res.S, res.N
 
     def barrier():

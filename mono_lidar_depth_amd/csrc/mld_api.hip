@@ -147,7 +147,6 @@ struct mld_ctx {
     size_t lds_fused_pad = 0;       // mld_set_shared_gpu
     int shared_arg = 0;             // its last argument (re-applied when the list capacities change)
     int fused_blocks_per_cu = 8;    // mld_set_shared_gpu: wavefronts of k_feature_fused per CU in the shared mode
-    int classify_threads = 1024;    // mld_set_shared_gpu bits 1..2: 256- / 512-thread k_classify blocks
     size_t lds_per_cu = 0;          // device property
     bool timing = false;
     std::vector<TimedLaunch> timed;
@@ -527,7 +526,7 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     Calib calib = override_calib ? *override_calib : ctx->calib;
     // ONE frame per call (the ROS usage, the tracklet path): too few wavefronts for the lane-per-feature kernel to be
     // anything but one wavefront's lifetime (41 us for 2000 features); the wave-cooperative kernel, one feature per
-    // wavefront, finishes the frame in the time of its slowest feature.  k_classify still settles the dead features.
+    // wavefront, finishes the frame in the time of its slowest feature, and settles the dead features itself.
     const bool few = single && max_F <= 16384 && !ctx->force_thread_path;
     if (few) calib.threadPath = 0;
     const int per_slot = (int)((max_F + kWave - 1) / kWave);
@@ -535,24 +534,13 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     const SlotDesc one = single ? ctx->slots[slot].d : SlotDesc{};
     const int use_single = single ? 1 : 0, ns = single ? 1 : n_slots;
     if (few) {
-        HIP_TRY(ctx, hipMemsetAsync(one.ovf_count, 0, sizeof(int32_t), ctx->stream));
-        ScopedTimer ts(ctx, 5);
-        hipLaunchKernelGGL(mld::k_classify_few, dim3((unsigned)((max_F + mld::kFewThreads - 1) / mld::kFewThreads)),
-                           dim3(mld::kFewThreads), 0, ctx->stream, one, calib);
+        // (the wave kernel settles the features without neighbours itself: k_feature_wave, direct mode)
     } else {
         ScopedTimer ts(ctx, 5);
-        if (ctx->classify_staged && ctx->classify_threads == 256) {
-            hipLaunchKernelGGL((mld::k_classify<true, 256, 8>), dim3((unsigned)ns), dim3(256), ctx->lds_classify, ctx->stream,
-                               ctx->d_slots, one, use_single, calib, ctx->bm_ncol, ctx->bm_ncolp);
-        } else if (ctx->classify_staged && ctx->classify_threads == 512) {
-            hipLaunchKernelGGL((mld::k_classify<true, 512, 4>), dim3((unsigned)ns), dim3(512), ctx->lds_classify, ctx->stream,
-                               ctx->d_slots, one, use_single, calib, ctx->bm_ncol, ctx->bm_ncolp);
-        } else {
-            auto kc = ctx->classify_staged ? mld::k_classify<true, kClsThreads, kClsKeep>
-                                           : mld::k_classify<false, kClsThreads, kClsKeep>;
-            hipLaunchKernelGGL(kc, dim3((unsigned)ns), dim3(kClsThreads), ctx->lds_classify, ctx->stream, ctx->d_slots, one,
-                               use_single, calib, ctx->bm_ncol, ctx->bm_ncolp);
-        }
+        auto kc = ctx->classify_staged ? mld::k_classify<true, kClsThreads, kClsKeep>
+                                       : mld::k_classify<false, kClsThreads, kClsKeep>;
+        hipLaunchKernelGGL(kc, dim3((unsigned)ns), dim3(kClsThreads), ctx->lds_classify, ctx->stream, ctx->d_slots, one,
+                           use_single, calib, ctx->bm_ncol, ctx->bm_ncolp);
     }
     if (calib.threadPath) {
         ScopedTimer tm(ctx, 1);
@@ -569,7 +557,7 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         const int want = (int)((max_F + chunk - 1) / chunk);
         const int pw = std::max(1, std::min(want, std::max(4, (few ? 16384 : 4096) / ns)));
         hipLaunchKernelGGL(k_feature_wave, dim3((unsigned)pw * (unsigned)ns), dim3(kWave), ctx->lds_bytes, ctx->stream,
-                           ctx->d_slots, one, use_single, calib, ns, pw, tag_all, chunk);
+                           ctx->d_slots, one, use_single, calib, ns, pw, tag_all, chunk, few ? 1 : 0);
     }
     HIP_TRY(ctx, hipGetLastError());
     return MLD_OK;
@@ -758,12 +746,7 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if (ctx->lds_classify > 48 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_classify<true, kClsThreads, kClsKeep>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_classify);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_classify<true, 256, 8>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_classify);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_classify<true, 512, 4>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_classify);
+
         if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute(k_classify)");
     }
     if (ctx->lds_fused > 48 * 1024) {
@@ -928,7 +911,6 @@ int mld_set_shared_gpu(mld_ctx* ctx, int shared) {
     // VGPRs there are at 168 per wave); 20 KB -> 8 per CU, 2 per SIMD, and a third of the register file stays free
     // for the projection wavefronts (48 VGPRs each) of a context running beside this one.
     ctx->shared_arg = shared;
-    ctx->classify_threads = (shared & 2) ? 256 : ((shared & 4) ? 512 : 1024);
     int blocks = (shared >> 8) & 0xFF;  // bits 8..15: wavefronts per CU (0 = the default, 8)
     if (blocks <= 0) blocks = 8;
     ctx->fused_blocks_per_cu = blocks;
@@ -1571,12 +1553,13 @@ int mld_calculate_depth_frame(mld_ctx* ctx, int slot, const void* pts_host, int6
             HIP_TRY(ctx, hipGetLastError());
         }
     }
+    // (the slot's occupancy bitmap is cleared there as well: off the cloud copy's critical path)
+    if ((rc = begin_cloud(ctx, s, s.cloud_buf, n, stride_bytes, true, ctx->side))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->side_done, ctx->side));
     // The cloud, straight from the caller's memory (measured: the runtime's own staging of a pageable source moves
     // 2.1 MB in 51 us, as fast as from pinned memory; copying through a pinned buffer of ours in pieces was slower).
     if (bytes) HIP_TRY(ctx, hipMemcpyAsync(s.cloud_buf, pts_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
-    if ((rc = begin_cloud(ctx, s, s.cloud_buf, n, stride_bytes))) return rc;
     if (coeffs) {
         set_plane_coeffs(s, coeffs);
         s.d.inlier_mask = s.mask_buf;

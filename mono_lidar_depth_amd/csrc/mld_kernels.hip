@@ -2006,6 +2006,9 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
     main_tail(c, s, lst, lane, ks, live, minZ, maxZ, myu, myv, mytype, mydepth, overflow ST_PASS);
 }
 
+__device__ __forceinline__ bool window_bounds(const Calib& c, double u, double v, double halfX, double halfY, int& x0,
+                                              int& y0, int& nx, int& ny);
+
 // Wave-cooperative kernel for the features the thread kernels could not hold (lists longer than their capacities).
 // Queue entries: (feature, -1) = main path + road fallback, (feature, t >= 0) = road fallback only, t being the
 // main path's result.
@@ -2013,23 +2016,66 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
 // spread a long queue (dense clouds: every feature overflows) over many more wavefronts.
 // (171 VGPRs, two wavefronts per SIMD; 168 / 128 registers for three / four were measured: same time - the kernel is
 // bound by instruction issue, ~5000 VALU instructions per feature, not by occupancy)
+// direct != 0 (ONE frame per call): no queue - entry e IS feature e, and the block settles the features without
+// enough neighbours itself (what k_classify does for batches: window count in the occupancy bitmap, which the projection
+// has just left in L2), so a single-frame call is projection + this kernel.
 __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restrict__ slots, SlotDesc single, int use_single,
-                                                        Calib c, int n_slots, int per_slot, uint32_t tag_all, int chunk) {
+                                                        Calib c, int n_slots, int per_slot, uint32_t tag_all, int chunk,
+                                                        int direct) {
     extern __shared__ __align__(16) unsigned char smem[];
     int slot, j;
     decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
     SlotDesc s = use_single ? single : slots[slot];
     apply_plane_dev(s);
     if (tag_all) s.tag = tag_all;
-    if (!s.ovf_count) return;
-    const int count = *GPTR(int32_t, s.ovf_count);
+    int count;
+    if (direct) {
+        long long Fn = s.F;
+        if (s.F_dev) {
+            const long long fd = *GPTR(long long, s.F_dev);
+            Fn = fd < Fn ? fd : Fn;
+        }
+        count = (int)Fn;
+    } else {
+        if (!s.ovf_count) return;
+        count = *GPTR(int32_t, s.ovf_count);
+    }
     const int lane = threadIdx.x;
     for (int e0 = j * chunk; e0 < count; e0 += per_slot * chunk) {
-        const bool active = lane < chunk && e0 + lane < count;
+        bool active = lane < chunk && e0 + lane < count;
         long long f = 0;
         int code = 0;
         double myu = 0, myv = 0;
-        if (active) {
+        if (active && direct) {
+            f = e0 + lane;
+            code = -1;
+            const auto* q = GPTR(double, s.uv) + 2 * f;
+            myu = q[0];
+            myv = q[1];
+            // DepthEstimator.cpp:680: fewer than radiusSearch_count_min neighbours in the search window
+            int x0, y0, nx, ny;
+            if (window_bounds(c, myu, myv, c.halfX1, c.halfY1, x0, y0, nx, ny) && nx <= 32) {
+                const auto* bm = GPTR(uint32_t, s.bitmap) + (size_t)(x0 >> 5) * (size_t)c.bmStride;
+                const uint32_t sh = (uint32_t)(x0 & 31);
+                const uint32_t colmask = (nx >= 32) ? ~0u : ((1u << nx) - 1u);
+                int k1 = 0;
+                for (int r = 0; r < ny; r++) {
+                    const uint32_t lo = bm[y0 + r], hi = bm[c.bmStride + y0 + r];
+                    k1 += __popc(__builtin_amdgcn_alignbit(hi, lo, sh) & colmask);
+                }
+                if ((unsigned)k1 < c.countMin) {
+                    GPTRW(double, s.depth)[f] = -1.0;
+                    if (s.type) GPTRW(int32_t, s.type)[f] = MLD_RadiusSearchInsufficientPoints;
+                    active = false;
+                }
+            } else if (nx <= 32) {  // no window at all (non-finite feature): zero neighbours
+                if (0u < c.countMin) {
+                    GPTRW(double, s.depth)[f] = -1.0;
+                    if (s.type) GPTRW(int32_t, s.type)[f] = MLD_RadiusSearchInsufficientPoints;
+                    active = false;
+                }
+            }
+        } else if (active) {
             f = (long long)GPTR(int32_t, s.ovf_queue)[2 * (size_t)(e0 + lane)];
             code = GPTR(int32_t, s.ovf_queue)[2 * (size_t)(e0 + lane) + 1];
             const auto* q = GPTR(double, s.uv) + 2 * f;
@@ -2113,7 +2159,8 @@ enum : int { CLS_DEAD = -1, CLS_OVF = -2, CLS_NONE = -3 };
 
 // STAGED: the slot's bitmap is copied to LDS (row-major there: word [y * ncolp + column], ncolp odd) and read from
 // it; otherwise (bitmap larger than the LDS budget: very large images) it is read in place.
-template <bool STAGED, int kClsThreads, int kClsKeep>
+template <bool STAGED, int kClsThreads, int kClsKeep>  // (block shape as template parameters: 256 / 512-thread variants
+                                                       //  were measured for the shared-GPU schedule and lost)
 __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __restrict__ slots, SlotDesc single,
                                                           int use_single, Calib c, int ncol, int ncolp) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -2289,50 +2336,6 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
         const int cls = classify(uv[2 * i], uv[2 * i + 1]);
         if (cls >= 0) live[atomicAdd(&hist[cls], 1)] = (int32_t)i;
     }
-}
-
-// ONE frame per call (the wave-only mode of launch_features): what k_classify does for such a call - features with too
-// few neighbours are settled, the others go to the wave kernel's queue - without the staging and the sort, by as many
-// small blocks as the features need instead of one 1024-thread block (25 -> ~5 us of a 145 us call).  The bitmap rows
-// come straight from L2, where the projection has just left them.  *s.ovf_count must be zero on entry.
-constexpr int kFewThreads = 256;
-__global__ __launch_bounds__(kFewThreads) void k_classify_few(SlotDesc s, Calib c) {
-    apply_plane_dev(s);
-    long long Fn = s.F;
-    if (s.F_dev) {
-        const long long fd = *GPTR(long long, s.F_dev);
-        Fn = fd < Fn ? fd : Fn;
-    }
-    const long long i = (long long)blockIdx.x * kFewThreads + threadIdx.x;
-    const int lane = (int)threadIdx.x & (kWave - 1);
-    bool queue = false;
-    if (i < Fn) {
-        const auto* uv = GPTR(double, s.uv);
-        const double u = uv[2 * i], v = uv[2 * i + 1];
-        int x0, y0, nx, ny, k1 = 0;
-        if (window_bounds(c, u, v, c.halfX1, c.halfY1, x0, y0, nx, ny)) {
-            if (nx > 32) {
-                queue = true;  // (a 64-bit row mask would be needed; the wave kernel counts for itself)
-            } else {
-                const auto* bm = GPTR(uint32_t, s.bitmap) + (size_t)(x0 >> 5) * (size_t)c.bmStride;
-                const uint32_t sh = (uint32_t)(x0 & 31);
-                const uint32_t colmask = (nx >= 32) ? ~0u : ((1u << nx) - 1u);
-                for (int r = 0; r < ny; r++) {
-                    const uint32_t lo = bm[y0 + r], hi = bm[c.bmStride + y0 + r];
-                    k1 += __popc(__builtin_amdgcn_alignbit(hi, lo, sh) & colmask);
-                }
-            }
-        }
-        if (!queue) {
-            if ((unsigned)k1 < c.countMin) {  // DepthEstimator.cpp:680
-                GPTRW(double, s.depth)[i] = -1.0;
-                if (s.type) GPTRW(int32_t, s.type)[i] = MLD_RadiusSearchInsufficientPoints;
-            } else {
-                queue = true;
-            }
-        }
-    }
-    enqueue_features(s.ovf_queue, s.ovf_count, queue, lane, i, -1);
 }
 
 #ifndef MLD_KEY_BATCH_F
