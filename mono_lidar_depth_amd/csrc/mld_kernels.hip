@@ -1347,7 +1347,10 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
 constexpr int kK1MaxLimit = 64;  // upper bound of Calib::k1max, the per-feature neighbour list capacity
                                  // (LDS: k1max entries x 64 lanes x 4 B per wave; relative bins need k1max < 254)
 constexpr int kK2Max = 16;  // longest list the per-thread O(n^2) triangle search accepts
-constexpr int kTriSmall = 8;
+#ifndef MLD_TRI_SMALL
+#define MLD_TRI_SMALL 8
+#endif
+constexpr int kTriSmall = MLD_TRI_SMALL;
 #ifndef MLD_KZC
 #define MLD_KZC 12
 #endif
@@ -1375,6 +1378,9 @@ struct RawP {
     float x, y, z;
 };
 __device__ __forceinline__ RawP load_raw(const SlotDesc& s, uint32_t i) {
+#ifdef MLD_DIAG_NO_POINTS  // diagnostic build only (profiles/tools): no cloud gathers - wrong results, same instruction stream
+    return RawP{5.0f + (float)(i & 1023u) * 0.01f, (float)(i & 63u) * 0.05f - 1.6f, -1.7f + (float)(i & 7u) * 0.01f};
+#endif
     const unsigned char* p = s.cloud + (size_t)i * (size_t)s.stride;
     RawP r;
     if ((((size_t)s.cloud) & 15) == 0) {
@@ -2442,7 +2448,12 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDes
 #pragma unroll
         for (int q = 0; q < kKeyBatchF; q++) cell[q] = (e0 + q < kk) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
 #pragma unroll
+#ifdef MLD_DIAG_NO_KEYS  // diagnostic build only: no key gathers
+        for (int q = 0; q < kKeyBatchF; q++) key[q] = make_key(s.tag, (cell[q] * 2654435761u) >> 15, 1u);
+        (void)mp;
+#else
         for (int q = 0; q < kKeyBatchF; q++) key[q] = (e0 + q < kk) ? mp[cell[q] & 0x7FFFFFFFu] : 0u;
+#endif
 #pragma unroll
         for (int q = 0; q < kKeyBatchF; q++)
             if (e0 + q < kk) LST(e0 + q) = key_index(key[q]) | ((key[q] & 3u) << kEntStateShift) | (cell[q] & kEntNarrow);
