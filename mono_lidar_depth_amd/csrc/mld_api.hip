@@ -87,6 +87,7 @@ struct mld_ctx {
     bool classify_staged = true;  // the bitmap fits the LDS budget of k_classify
     int bm_ncol = 0, bm_ncolp = 0;  // bitmap word columns (incl. the slack column) / padded LDS row length
     bool force_thread_path = false;  // test build only: single-slot calls use the lane-per-feature kernel too
+    size_t proj_lds = 0;             // test build only (MLD_PROJ_LDS): unused dynamic LDS per projection block, caps its occupancy
     std::string err;
     // ground-plane estimation scratch (device)
     int32_t* rs_flags = nullptr;
@@ -326,6 +327,8 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     c.useRoad = P.do_use_ransac_plane;
     c.roadMode = P.plane_estimator_use_triangle_maximation ? 1 : 0;
     c.roadDistThr = P.ransac_plane_point_distance_treshold;
+    c.roadDistThrF = (float)c.roadDistThr;
+    c.padf2_ = 0.f;
     c.zxMinRel = P.plane_estimator_z_x_min_relation;
     c.usePCA = P.do_use_PCA;
     c.pcaAbsMin = P.pca_treshold_3_abs_min;
@@ -348,6 +351,8 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     if (const char* e = std::getenv("MLD_FORCE_WAVE_PATH")) c.threadPath = (e[0] == '1') ? 0 : 1;
     if (const char* e = std::getenv("MLD_NO_XCD")) c.xcdAware = (e[0] == '1') ? 0 : 1;
     if (const char* e = std::getenv("MLD_FORCE_THREAD_PATH")) ctx->force_thread_path = e[0] == '1';
+    //   MLD_PROJ_LDS=bytes     occupancy experiments: the batched projection asks for that much (unused) LDS per block
+    if (const char* e = std::getenv("MLD_PROJ_LDS")) ctx->proj_lds = (size_t)std::atoll(e);
     if (const char* e = std::getenv("MLD_K1MAX")) c.k1max = std::min(std::max(std::atoi(e), 8), kK1MaxLimit);
     if (const char* e = std::getenv("MLD_KMAIN")) c.kMain = std::min(std::max(std::atoi(e), 8), c.k1max);
 #endif
@@ -494,7 +499,7 @@ int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int sl
                            ctx->slots[slot].d, 1, ctx->calib, 1, per_slot, 0u);
     } else {
         // (batch: the slots [slot, slot + n_slots))
-        hipLaunchKernelGGL(k_project_scatter, dim3((unsigned)per_slot * n_slots), dim3(kProjThreads), 0, st,
+        hipLaunchKernelGGL(k_project_scatter, dim3((unsigned)per_slot * n_slots), dim3(kProjThreads), ctx->proj_lds, st,
                            ctx->d_slots + slot, SlotDesc{}, 0, ctx->calib, n_slots, per_slot, common_tag(ctx, n_slots, slot));
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -597,8 +602,9 @@ int precheck_calc(mld_ctx* ctx, Slot& s, int64_t F) {
 
 // Commits the plane coefficients of a slot: coeffs + the M-estimator prior (DepthEstimator.cpp:286-292).  Callers
 // validate their arguments and build the inlier mask BEFORE this, so that a failed call leaves the slot as it was.
-void set_plane_coeffs(Slot& s, const float coeffs[4]) {
+void set_plane_coeffs(mld_ctx* ctx, Slot& s, const float coeffs[4]) {
     std::memcpy(s.d.coeffs, coeffs, sizeof(float) * 4);
+    far_margins(coeffs, ctx->calib.far_elin, ctx->calib.far_econst, ctx->calib.roadDistThrF, s.d.far_mg0, s.d.far_mg1);
     // DepthEstimator.cpp:289-291: prior = Hyperplane(Vector3d(a,b,c).normalized(), d)
     double a = (double)coeffs[0], b = (double)coeffs[1], cc = (double)coeffs[2];
     double z = a * a + (b * b + cc * cc);
@@ -978,7 +984,7 @@ static int set_clouds_common(mld_ctx* ctx, int n_slots, const void* const* pts_d
         Slot& s = ctx->slots[first + i];
         if ((rc = begin_cloud(ctx, s, pts_dev[i], n[i], stride_bytes, false, st))) return rc;
         if (coeffs) {
-            set_plane_coeffs(s, coeffs + 4 * i);
+            set_plane_coeffs(ctx, s, coeffs + 4 * i);
             s.d.inlier_mask = mask_dev[i];
             s.d.mask_in_key = 1;
         }
@@ -1089,7 +1095,8 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
                            n_draws, P.ransac_plane_max_iterations, P.ransac_plane_probability,
                            P.ransac_plane_distance_treshold, P.ransac_plane_refinement_treshold,
                            P.ransac_plane_use_refinement, ctx->rsb_planes, pass ? 1 : 0, (float)P.ransac_plane_min_z,
-                           (float)P.ransac_plane_max_z, ctx->rsb_sample_idx);
+                           (float)P.ransac_plane_max_z, ctx->rsb_sample_idx, ctx->calib.far_elin, ctx->calib.far_econst,
+                           ctx->calib.roadDistThrF);
         HIP_TRY(ctx, hipGetLastError());
     }
     if ((rc = launch_project(ctx, n_slots, max_n, false, 0, st))) return rc;
@@ -1145,7 +1152,7 @@ int mld_set_ground_plane_device(mld_ctx* ctx, int slot, const float coeffs[4], c
     if (n_inliers < 0 || (!inlier_idx_dev && n_inliers > 0)) return fail(ctx, MLD_ERR_INVALID_ARG, "bad inlier list");
     // mask first, commit afterwards: a failure leaves the slot's previous plane state untouched
     if ((rc = build_mask_from_indices(ctx, s, inlier_idx_dev, n_inliers))) return rc;
-    set_plane_coeffs(s, coeffs);
+    set_plane_coeffs(ctx, s, coeffs);
     s.d.inlier_mask = s.mask_buf;
     s.d.mask_in_key = 0;
     return MLD_OK;
@@ -1168,7 +1175,7 @@ int mld_set_ground_plane(mld_ctx* ctx, int slot, const float coeffs[4], const in
         HIP_TRY(ctx, hipMemcpyAsync(s.inl_buf, inlier_idx_host, (size_t)n_inliers * sizeof(int32_t),
                                     hipMemcpyHostToDevice, ctx->stream));
     if ((rc = build_mask_from_indices(ctx, s, s.inl_buf, n_inliers))) return rc;
-    set_plane_coeffs(s, coeffs);
+    set_plane_coeffs(ctx, s, coeffs);
     s.d.inlier_mask = s.mask_buf;
     s.d.mask_in_key = 0;
     return MLD_OK;
@@ -1251,7 +1258,7 @@ int mld_estimate_ground_plane(mld_ctx* ctx, int slot, uint32_t seed, float coeff
         s.plane_decided = false;
         return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");
     }
-    set_plane_coeffs(s, res.coeffs);
+    set_plane_coeffs(ctx, s, res.coeffs);
     s.d.inlier_mask = s.mask_buf;
     s.d.mask_in_key = 0;
     if (coeffs_out)
@@ -1316,7 +1323,7 @@ static int semantic_plane_core(mld_ctx* ctx, Slot& s, const unsigned char* img_d
         s.plane_decided = false;
         return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");
     }
-    set_plane_coeffs(s, res.coeffs);
+    set_plane_coeffs(ctx, s, res.coeffs);
     s.d.inlier_mask = s.mask_buf;
     s.d.mask_in_key = 0;
     if (coeffs_out)
@@ -1389,7 +1396,7 @@ int mld_set_ground_plane_mask_device(mld_ctx* ctx, int slot, const float coeffs[
         return MLD_OK;
     }
     if (!mask_dev) return fail(ctx, MLD_ERR_INVALID_ARG, "null mask");
-    set_plane_coeffs(s, coeffs);
+    set_plane_coeffs(ctx, s, coeffs);
     s.d.inlier_mask = mask_dev;
     s.d.mask_in_key = 0;
     return MLD_OK;
@@ -1561,7 +1568,7 @@ int mld_calculate_depth_frame(mld_ctx* ctx, int slot, const void* pts_host, int6
     if (bytes) HIP_TRY(ctx, hipMemcpyAsync(s.cloud_buf, pts_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
     if (coeffs) {
-        set_plane_coeffs(s, coeffs);
+        set_plane_coeffs(ctx, s, coeffs);
         s.d.inlier_mask = s.mask_buf;
         s.d.mask_in_key = 1;
     } else {

@@ -41,6 +41,8 @@ struct Calib {
     // pcm[2] m1 + pcm[3], v tests pcm[4] m1 + pcm[5]
     float pcm[6];
     float far_econst;
+    float roadDistThrF;  // (float)roadDistThr
+    float padf2_;
     double halfX1, halfY1;  // main search window half sizes  (scale 1.0, 1.0)
     double halfX2, halfY2;  // road search window half sizes  (scale 2.0, 1.5)
     double binW;
@@ -77,7 +79,20 @@ struct PlaneDev {
     int has_plane;   // 0: the estimation failed (GroundPlane::ExceptionPclInvalid): the road fallback is off for the frame
     int status;      // 0 ok, 1 too few points / no model
     int n_inliers, iterations, best_draw, best_count, S, pad_;
+    float far_mg0, far_mg1;  // margins of the projection's single-precision far test for this plane (far_margins)
 };
+
+// Margin of k_project_scatter's single-precision "far from the ground plane" test as a linear function of
+// m1 = |x|+|y|+|z|: mg0 * m1 + mg1.  The f64 round trip of DepthEstimator.cpp:810 returns the raw float coordinates up
+// to e = far_elin * m1 + far_econst, so the distance evaluated on the RAW floats differs from the reference's by at
+// most cs (2^-24 m1 + 2 e) + 8 * 2^-24 (cs m1 + |d|), cs = |a|+|b|+|c|; the margin is several times that (rounded up),
+// plus the rounding of the threshold.  Computed once per plane (host, or k_rs_batch), not per wavefront.
+__host__ __device__ inline void far_margins(const float co[4], float far_elin, float far_econst, float thr, float& mg0,
+                                            float& mg1) {
+    const float cs = (fabsf(co[0]) + fabsf(co[1]) + fabsf(co[2])) * 1.001f;
+    mg0 = (2e-6f * cs + 4.f * cs * far_elin) * 1.001f;
+    mg1 = (2e-6f * fabsf(co[3]) + 4.f * cs * far_econst + 2e-7f * fabsf(thr)) * 1.001f + 1e-30f;
+}
 
 // Per-frame-slot descriptor (device-resident array, or passed by value for single-slot calls).
 struct SlotDesc {
@@ -104,6 +119,7 @@ struct SlotDesc {
     uint32_t tag;  // current map tag, 1..255
     int has_plane;
     int mask_in_key;  // 1: the inlier / far flags of every map key are valid (the plane was known when the cloud was projected)
+    float far_mg0, far_mg1;  // margins of the projection's single-precision far test for `coeffs` (far_margins)
 };
 
 // One sequence of the batched tracklet layer (mld_tracklets_depths_device): the arrays of

@@ -243,17 +243,28 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
     // feature kernel; a handful of points per frame at most).
     const bool flags_on = s.mask_in_key != 0;
     float pa = s.coeffs[0], pb = s.coeffs[1], pcz = s.coeffs[2], pd = s.coeffs[3];
+    float fmg0 = s.far_mg0, fmg1 = s.far_mg1;  // (far_margins: prepared once per plane, not per wavefront)
     if (flags_on && s.plane_dev) {  // the plane of a batched estimation lives in device memory
         const auto* q = GPTR(PlaneDev, s.plane_dev);
         pa = q->coeffs[0];
         pb = q->coeffs[1];
         pcz = q->coeffs[2];
         pd = q->coeffs[3];
+        fmg0 = q->far_mg0;
+        fmg1 = q->far_mg1;
     }
-    const float thrf = (float)c.roadDistThr;
-    const float pcs = (fabsf(pa) + fabsf(pb) + fabsf(pcz)) * 1.001f;
-    const float fmg0 = (2e-6f * pcs + 4.f * pcs * c.far_elin) * 1.001f;
-    const float fmg1 = (2e-6f * fabsf(pd) + 4.f * pcs * c.far_econst + 2e-7f * fabsf(thrf)) * 1.001f + 1e-30f;
+    {
+        // block-uniform values: into scalar registers (the register file decides how many projection wavefronts fit
+        // beside the other context's feature kernel)
+        auto sreg = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+        pa = sreg(pa);
+        pb = sreg(pb);
+        pcz = sreg(pcz);
+        pd = sreg(pd);
+        fmg0 = sreg(fmg0);
+        fmg1 = sreg(fmg1);
+    }
+    const float thrf = c.roadDistThrF;
     // 32-bit index and offset arithmetic throughout: a cloud has at most 2^23 - 1 points of 16 or 32 bytes
     const int n = (int)s.n;
     const int blk0 = j * (kProjThreads * kProjPerThread);

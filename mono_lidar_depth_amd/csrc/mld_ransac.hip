@@ -357,7 +357,8 @@ __device__ inline int select_bit(unsigned long long m, int k) {
 __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restrict__ slots, const uint32_t* __restrict__ seeds,
                                                         int n_draws, int max_it, double probability, double thr,
                                                         double refine_thr, int use_refinement, PlaneDev* out, int pass,
-                                                        float lo, float hi, int32_t* __restrict__ sample_idx_all) {
+                                                        float lo, float hi, int32_t* __restrict__ sample_idx_all,
+                                                        float far_elin, float far_econst, float far_thr) {
     extern __shared__ __align__(16) unsigned char rs_smem[];
     // the sample as three coordinate arrays (structure of arrays): a lane reads four consecutive points with three
     // 16-byte LDS loads in the hypothesis loop, which is what this kernel spends its time in
@@ -650,6 +651,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         pd->prior_n[1] = b;
         pd->prior_n[2] = cc;
         pd->prior_off = (double)coeffs[3];
+        far_margins(coeffs, far_elin, far_econst, far_thr, pd->far_mg0, pd->far_mg1);
         pd->n_inliers = misc[1];
         pd->iterations = iterations;
         pd->best_draw = best_draw;
