@@ -398,6 +398,9 @@ __global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc
 //   phase 3 (lanes = neighbours, only features that fell through): wide window, ground-plane inliers, fit sums
 //   phase 4 (lanes = features): road plane, intersection, thresholds
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool window_bounds(const Calib& c, double u, double v, double halfX, double halfY, int& x0,
+                                              int& y0, int& nx, int& ny);
+
 struct Lists {
     double* x;
     double* y;
@@ -410,8 +413,9 @@ constexpr int kRecFields = 11;
 
 // Window scan (NeighborFinderPixel.cpp:60-95) + 3-D gather (NeighborFinderBase.cpp:15-27).  Returns the
 // neighbour count (wave-uniform); entries are in the reference's row-major scan order.
+// inliers_only: only the points whose key carries the state "plane inlier" (valid when SlotDesc::mask_in_key).
 __device__ int gather_window(const Calib& c, const SlotDesc& s, double u, double v, double halfX, double halfY,
-                             const Lists& L, int lane) {
+                             const Lists& L, int lane, bool inliers_only = false) {
     if (!(isfinite(u) && isfinite(v))) return 0;  // reference: undefined behaviour (int cast of NaN)
     double a;
     a = u - halfX;
@@ -441,7 +445,7 @@ __device__ int gather_window(const Calib& c, const SlotDesc& s, double u, double
             int row = (int)(((float)cidx + 0.5f) * rnx);
             int col = cidx - row * nx;
             uint32_t key = GPTR(uint32_t, s.map)[(size_t)(x0 + col) + (size_t)(y0 + row) * (size_t)c.W];
-            has = (key >> kTagShift) == s.tag;
+            has = (key >> kTagShift) == s.tag && (!inliers_only || (key & 3u) == kPtInlier);
             orig = (int)key_index(key);
         }
         unsigned long long m = __ballot(has);
@@ -459,6 +463,38 @@ __device__ int gather_window(const Calib& c, const SlotDesc& s, double u, double
     }
     k = uniform(k);
     return k < c.cap ? k : c.cap;
+}
+
+// The same window through the keys alone (valid when SlotDesc::mask_in_key): the number of neighbours, of plane inliers
+// among them, and whether any neighbour is far from the plane / undecided (k_project_scatter's ground-plane state).
+__device__ void window_states(const Calib& c, const SlotDesc& s, double u, double v, double halfX, double halfY, int lane,
+                              int& k_all, int& k_inl, bool& any_far, bool& any_unsure) {
+    k_all = 0;
+    k_inl = 0;
+    any_far = false;
+    any_unsure = false;
+    int x0, y0, nx, ny;
+    if (!window_bounds(c, u, v, halfX, halfY, x0, y0, nx, ny)) return;
+    x0 = uniform(x0);
+    y0 = uniform(y0);
+    nx = uniform(nx);
+    ny = uniform(ny);
+    const int ncell = nx * ny;
+    const float rnx = 1.0f / (float)nx;
+    for (int base = 0; base < ncell; base += kWave) {
+        const int cidx = base + lane;
+        uint32_t st = 0xFFu;
+        if (cidx < ncell) {
+            const int row = (int)(((float)cidx + 0.5f) * rnx);
+            const int col = cidx - row * nx;
+            const uint32_t key = GPTR(uint32_t, s.map)[(size_t)(x0 + col) + (size_t)(y0 + row) * (size_t)c.W];
+            if ((key >> kTagShift) == s.tag) st = key & 3u;
+        }
+        k_all += (int)__popcll(__ballot(st != 0xFFu));
+        k_inl += (int)__popcll(__ballot(st == kPtInlier));
+        any_far = any_far || (__ballot(st == kPtFar) != 0ull);
+        any_unsure = any_unsure || (__ballot(st == kPtUnsure) != 0ull);
+    }
 }
 
 // PointHistogram::FilterPointsMinDistBlob (HistogramPointDepth.cpp:15-123, Histogram.cpp:14-49).
@@ -1229,16 +1265,28 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
         const double u = readlane_f64(myu, fi), v = readlane_f64(myv, fi);
         const int resultOld = __builtin_amdgcn_readlane(mytype, fi);
         int state = ST_FINAL, type = resultOld;
-        int k = gather_window(c, s, u, v, c.halfX2, c.halfY2, L, lane);  // :585 scale 2.0, 1.5
+        // With the points' ground-plane state in the keys (the plane was known at projection time) the window is first
+        // read through the keys alone: a far neighbour or fewer than three inliers settle the feature without a single
+        // point fetch (:591), otherwise only the inliers are gathered - in the same order as the general loop below
+        // compacts them, so the estimator sees the same list.
+        bool by_state = false, anyFar = false;
+        int k = 0, kk = 0;
+        if (s.mask_in_key) {
+            bool unsure = false;
+            int k_inl = 0;
+            window_states(c, s, u, v, c.halfX2, c.halfY2, lane, k, k_inl, anyFar, unsure);
+            by_state = !unsure;
+            if (by_state && (unsigned)k >= c.countMin && !anyFar && k_inl >= 3)
+                kk = gather_window(c, s, u, v, c.halfX2, c.halfY2, L, lane, true);
+        }
+        if (!by_state) k = gather_window(c, s, u, v, c.halfX2, c.halfY2, L, lane);  // :585 scale 2.0, 1.5
         ST_USE_U32(k);
         ST_MARK(6);
         if ((unsigned)k < c.countMin) {
             type = MLD_RadiusSearchInsufficientPoints;
         } else {
             // CalculateDepthSegmentationPlane (DepthEstimator.cpp:782-900)
-            bool anyFar = false;
-            int kk = 0;
-            for (int b = 0; b < k; b += kWave) {
+            for (int b = 0; !by_state && b < k; b += kWave) {
                 int i = b + lane;
                 bool far = false, inl = false;
                 double x = 0, y = 0, z = 0;
@@ -2022,9 +2070,6 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
     main_hist(c, s, lst, lane, k, live, mytype, ks, minZ, maxZ ST_PASS);
     main_tail(c, s, lst, lane, ks, live, minZ, maxZ, myu, myv, mytype, mydepth, overflow ST_PASS);
 }
-
-__device__ __forceinline__ bool window_bounds(const Calib& c, double u, double v, double halfX, double halfY, int& x0,
-                                              int& y0, int& nx, int& ny);
 
 // Wave-cooperative kernel for the features the thread kernels could not hold (lists longer than their capacities).
 // Queue entries: (feature, -1) = main path + road fallback, (feature, t >= 0) = road fallback only, t being the
