@@ -337,7 +337,6 @@ class Resident:
             self.batches = [prep(e, 0, c) for c, e in enumerate(self.ests)]
         else:
             self.batches = [prep(self.ests[(i // S) % NC], i, 0) for i in range(0, B, S)]
-        self.primed = False
 
     def poison(self):
         """Results that are not rewritten by the timed region cannot pass the check."""
@@ -345,32 +344,13 @@ class Resident:
             d.fill_(float("nan"))
             t.fill_(-77)
 
-    def prime(self):
-        """Steady-state start of a timed loop (default schedule only): the projection of one UNTIMED step is submitted
-        and finished here; its feature kernels are submitted by the first timed run_step, beside that step's
-        projection - as in every later step.  The clock therefore starts with the pipeline full, and the timed region
-        holds the feature kernels of steps+1 steps and the projections of `steps` (never less work than it counts)."""
-        if not (self.whole and len(self.batches) > 1):
-            return
-        e, b = self.batches[self.k % len(self.batches)]
-        e.projectBatch(b)
-        e.synchronize()
-        self.primed = True
-
     def run_step(self):
         # contexts in turn; the next context's projection is released by the end of this one's, so it streams its
         # clouds beside this context's feature kernels
         nb = len(self.batches)
         if self.whole:
             e, b = self.batches[self.k % nb]
-            nxt = self.batches[(self.k + 1) % nb][0]
-            if self.primed:  # the primed step's projection is done: its feature kernels, then a whole step
-                self.primed = False
-                e.featuresBatchBeside(b, nxt)
-                self.k += 1
-                e, b = self.batches[self.k % nb]
-                nxt = self.batches[(self.k + 1) % nb][0]
-            e.runBatchBeside(b, nxt)
+            e.runBatchBeside(b, self.batches[(self.k + 1) % nb][0])
             self.k += 1
             return
         for i, (e, b) in enumerate(self.batches):
@@ -523,8 +503,6 @@ def timed_resident(res, steps, warmup, timing, timing_every, barrier=lambda: Non
     for _ in range(max(1, repeats)):
         barrier()
         torch.cuda.synchronize()
-        if not estimated:
-            res.prime()  # pipeline full when the clock starts (default schedule)
         t0 = time.perf_counter()
         for it in range(steps):
             if timing:
@@ -828,8 +806,7 @@ def main():
     loops, kt = timed_resident(res, args.steps, args.warmup, timing, args.timing_every, barrier, repeats=args.repeats,
                                reduce_max=lambda x: sharding.max_over_ranks(x, device=coll_dev))
     elapsed = float(np.median(loops))  # every loop: exactly --steps steps, max over ranks
-    loop_start = ("pipeline full: one untimed step's projection done, its feature kernels inside the timed region"
-                  if (res.whole and len(res.ests) > 1) else "idle GPU")
+    loop_start = "idle GPU (synchronised): exactly --steps steps per loop, first projection and last feature kernels unpartnered"
     elapsed_local = float(np.median(res.local_loops)) if getattr(res, "local_loops", None) else elapsed
     units = sharding.sum_over_ranks(float(B * F * args.steps), device=coll_dev)
 

@@ -77,6 +77,7 @@ struct mld_ctx {
     // One allocation per kind for all slots instead of one per slot: a 1024-slot context would otherwise hold 4096
     // small mappings, and the gathers of the feature kernels would walk as many page-table fragments.
     uint32_t* map_slab = nullptr;    // pixel maps of all slots
+    size_t map_stride = 0;           // words per slot in map_slab
     int32_t* queue_slab = nullptr;   // per slot: overflow queue (2F), live queue (F)
     uint32_t* bitmaps = nullptr;  // occupancy bitmaps of all slots, contiguous
     size_t bitmap_words = 0;      // per slot
@@ -453,13 +454,14 @@ int check_cloud_args(mld_ctx* ctx, const void* dev_ptr, int64_t n, int stride) {
 
 // New cloud for a slot: bump the map tag (zero-fill on wrap), forget the previous plane / debug data.
 int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int stride, bool clear_bitmap = true,
-                hipStream_t st = nullptr) {
+                hipStream_t st = nullptr, bool map_cleared = false) {
     if (!st) st = ctx->stream;
     if (int rc = check_cloud_args(ctx, dev_ptr, n, stride)) return rc;
     if (clear_bitmap) HIP_TRY(ctx, hipMemsetAsync(s.d.bitmap, 0, ctx->bitmap_words * sizeof(uint32_t), st));
     if (s.d.tag >= kMaxTag) {
-        HIP_TRY(ctx, hipMemsetAsync(s.d.map, 0,
-                                    ((size_t)ctx->cam.width * ctx->cam.height + kMapPadCells) * sizeof(uint32_t), st));
+        if (!map_cleared)
+            HIP_TRY(ctx, hipMemsetAsync(s.d.map, 0,
+                                        ((size_t)ctx->cam.width * ctx->cam.height + kMapPadCells) * sizeof(uint32_t), st));
         s.d.tag = 1;
     } else {
         s.d.tag += 1;
@@ -477,6 +479,23 @@ int begin_cloud(mld_ctx* ctx, Slot& s, const void* dev_ptr, int64_t n, int strid
     s.plane_decided = false;
     s.full_valid = false;
     return MLD_OK;
+}
+
+// Tag wrap of a whole batch (every slot of the range is at the last tag: the steady state of a batch that is always
+// projected together): ONE fill over the slots' contiguous maps instead of one per slot (1024 fills of 1.86 MB cost
+// 6 ms every 127 batches - 6 % of a step; one fill of 1.9 GB 0.5 ms).  Returns true when it cleared them.
+bool clear_maps_on_common_wrap(mld_ctx* ctx, int first, int n_slots, hipStream_t st, int& rc) {
+    rc = MLD_OK;
+    for (int i = 0; i < n_slots; i++)
+        if (ctx->slots[first + i].d.tag < kMaxTag) return false;
+    hipError_t e = hipMemsetAsync(ctx->map_slab + (size_t)first * ctx->map_stride, 0,
+                                  ctx->map_stride * (size_t)n_slots * sizeof(uint32_t), st);
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMemsetAsync(maps): ") + hipGetErrorString(e);
+        rc = MLD_ERR_HIP;
+        return false;
+    }
+    return true;
 }
 
 // The map tag shared by slots [0, n_slots), or 0 when they differ (then the per-slot tags of the uploaded
@@ -784,6 +803,7 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
         ctx->slots[si].d.ovf_count = ctx->queue_counts + (size_t)max_frames + si;
     }
     const size_t map_stride = (cells + 63) & ~(size_t)63;  // words; slots start on 256-byte boundaries
+    ctx->map_stride = map_stride;
     if ((e = hipMalloc((void**)&ctx->map_slab, map_stride * (size_t)max_frames * sizeof(uint32_t))) != hipSuccess)
         return hip_bail(e, "hipMalloc(maps)");
     if ((e = hipMemsetAsync(ctx->map_slab, 0, map_stride * (size_t)max_frames * sizeof(uint32_t), ctx->stream)) != hipSuccess)
@@ -980,9 +1000,11 @@ static int set_clouds_common(mld_ctx* ctx, int n_slots, const void* const* pts_d
     // the slots' occupancy bitmaps are contiguous: one fill for the whole batch
     HIP_TRY(ctx, hipMemsetAsync(ctx->bitmaps + (size_t)first * ctx->bitmap_words, 0,
                                 ctx->bitmap_words * (size_t)n_slots * sizeof(uint32_t), st));
+    const bool maps_cleared = clear_maps_on_common_wrap(ctx, first, n_slots, st, rc);
+    if (rc) return rc;
     for (int i = 0; i < n_slots; i++) {
         Slot& s = ctx->slots[first + i];
-        if ((rc = begin_cloud(ctx, s, pts_dev[i], n[i], stride_bytes, false, st))) return rc;
+        if ((rc = begin_cloud(ctx, s, pts_dev[i], n[i], stride_bytes, false, st, maps_cleared))) return rc;
         if (coeffs) {
             set_plane_coeffs(ctx, s, coeffs + 4 * i);
             s.d.inlier_mask = mask_dev[i];
@@ -1079,9 +1101,11 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
     HIP_TRY(ctx, hipMemsetAsync(ctx->bitmaps, 0, ctx->bitmap_words * (size_t)n_slots * sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->rsb_masks, 0, ctx->rsb_mask_words * (size_t)n_slots * sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->rsb_seeds, seeds, (size_t)n_slots * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    const bool maps_cleared = clear_maps_on_common_wrap(ctx, 0, n_slots, st, rc);
+    if (rc) return rc;
     for (int i = 0; i < n_slots; i++) {
         Slot& s = ctx->slots[i];
-        if ((rc = begin_cloud(ctx, s, pts_dev[i], n[i], stride_bytes, false, st))) return rc;
+        if ((rc = begin_cloud(ctx, s, pts_dev[i], n[i], stride_bytes, false, st, maps_cleared))) return rc;
         s.d.inlier_mask = ctx->rsb_masks + (size_t)i * ctx->rsb_mask_words;
         s.d.mask_in_key = 1;
         s.d.plane_dev = ctx->rsb_planes + i;
