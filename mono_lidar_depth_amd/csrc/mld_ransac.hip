@@ -334,6 +334,7 @@ __global__ __launch_bounds__(kPartials) void k_rs_refine(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 constexpr int kRsThreads = 1024;
 constexpr int kRsRound = kRsThreads / kWave;  // hypotheses evaluated per round
+constexpr int kRsPerThread = (kSample + kRsThreads - 1) / kRsThreads;  // sample points per thread
 
 __device__ inline long long sample_pos(long long M, int j, uint32_t seed) {
     long long pos = j;
@@ -351,13 +352,38 @@ __device__ inline int select_bit(unsigned long long m, int k) {
     return __ffsll((long long)m) - 1;
 }
 
-// pass != 0: pcl::PassThrough on z with the float limits [lo, hi] ahead of the sub-sampling; sample_idx (kSample
-// int32 per slot, device scratch) then holds the original indices of the sample.  LDS beyond the fixed part: one byte
-// per 64 points + one int per 1024 points.
+#ifdef MLD_DIAG_RS_PHASES
+// diagnostic build only: time per phase of k_rs_batch (100 MHz ticks of thread 0, collected in LDS, summed over the
+// blocks at the end)
+__device__ unsigned long long g_rs_phase[16];
+constexpr int kRsMisc = 8 + 32;
+#define RS_PHASE(i)                                                                     \
+    do {                                                                                \
+        if (threadIdx.x == 0) {                                                         \
+            const unsigned long long t_now = wall_clock64();                            \
+            reinterpret_cast<unsigned long long*>(misc + 8)[i] += t_now - t_prev;       \
+            t_prev = t_now;                                                             \
+        }                                                                               \
+    } while (0)
+#define RS_COUNT(i, v) reinterpret_cast<unsigned long long*>(misc + 8)[i] += (unsigned long long)(v)
+#define RS_FLUSH()                                                                                              \
+    do {                                                                                                        \
+        if (threadIdx.x == 0)                                                                                   \
+            for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_rs_phase[i_], reinterpret_cast<unsigned long long*>(misc + 8)[i_]); \
+    } while (0)
+#else
+constexpr int kRsMisc = 8;
+#define RS_PHASE(i) do {} while (0)
+#define RS_COUNT(i, v) do {} while (0)
+#define RS_FLUSH() do {} while (0)
+#endif
+
+// pass != 0: pcl::PassThrough on z with the float limits [lo, hi] ahead of the sub-sampling.  LDS beyond the fixed part:
+// one byte per 64 points + one int per 1024 points.
 __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restrict__ slots, const uint32_t* __restrict__ seeds,
                                                         int n_draws, int max_it, double probability, double thr,
                                                         double refine_thr, int use_refinement, PlaneDev* out, int pass,
-                                                        float lo, float hi, int32_t* __restrict__ sample_idx_all,
+                                                        float lo, float hi,
                                                         float far_elin, float far_econst, float far_thr) {
     extern __shared__ __align__(16) unsigned char rs_smem[];
     // the sample as three coordinate arrays (structure of arrays): a lane reads four consecutive points with three
@@ -374,6 +400,11 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
     PlaneDev* pd = out + blockIdx.x;
     const uint32_t seed = seeds[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid >> 6;
+#ifdef MLD_DIAG_RS_PHASES
+    unsigned long long t_prev = wall_clock64();
+    if (tid == 0)
+        for (int i_ = 0; i_ < 16; i_++) reinterpret_cast<unsigned long long*>(misc + 8)[i_] = 0ull;
+#endif
     long long M = s.n;
     int S = M > kSample ? kSample : (int)M;
     auto fail = [&]() {
@@ -388,11 +419,35 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         fail();
         return;
     }
-    int32_t* sample_idx = sample_idx_all ? sample_idx_all + (size_t)blockIdx.x * kSample : nullptr;
+    // original indices of this thread's sample points (j = tid, tid + 1024, ...), kept for the inlier mask at the end
+    uint32_t ids[kRsPerThread];
+#pragma unroll
+    for (int q = 0; q < kRsPerThread; q++) ids[q] = 0u;
+    // the sample itself: all of a thread's loads in flight at once (they are ~300 B apart: every one its own line)
+    auto gather_sample = [&]() {
+        float px[kRsPerThread], py[kRsPerThread], pz[kRsPerThread];
+#pragma unroll
+        for (int q = 0; q < kRsPerThread; q++) {
+            const float* p = reinterpret_cast<const float*>(s.cloud + (size_t)ids[q] * (size_t)s.stride);
+            const bool in = tid + q * kRsThreads < S;
+            px[q] = in ? p[0] : 0.0f;
+            py[q] = in ? p[1] : 0.0f;
+            pz[q] = in ? p[2] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < kRsPerThread; q++) {
+            const int j = tid + q * kRsThreads;
+            if (j < S) {
+                sx[j] = px[q];
+                sy[j] = py[q];
+                sz[j] = pz[q];
+            }
+        }
+    };
     if (pass) {
         const long long n = s.n;
         const int G = (int)((n + kWave - 1) / kWave), NC = (G + 15) / 16;  // 64-point groups, 1024-point chunks
-        int* cpre = misc + 8;                                              // [NC + 1] candidates before chunk c
+        int* cpre = misc + kRsMisc;                                              // [NC + 1] candidates before chunk c
         unsigned char* gcnt = reinterpret_cast<unsigned char*>(cpre + NC + 1);  // [16 * NC] candidates per group
         // the slot's inlier-mask words (n / 8 bytes, written only at the very end) hold the group masks meanwhile
         unsigned long long* gm = reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(s.inlier_mask));
@@ -443,7 +498,10 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
             fail();
             return;
         }
-        for (int j = tid; j < S; j += kRsThreads) {
+#pragma unroll
+        for (int q = 0; q < kRsPerThread; q++) {
+            const int j = tid + q * kRsThreads;
+            if (j >= S) continue;
             const int pos = (int)sample_pos(M, j, seed);
             int a = 0, b = NC;  // cpre[a] <= pos < cpre[b]
             while (b - a > 1) {
@@ -455,22 +513,18 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
                 r -= (int)gcnt[g];
                 g++;
             }
-            const int idx = g * kWave + select_bit(gm[g], r);
-            sample_idx[j] = idx;
-            const float* p = reinterpret_cast<const float*>(s.cloud + (size_t)idx * (size_t)s.stride);
-            sx[j] = p[0];
-            sy[j] = p[1];
-            sz[j] = p[2];
+            ids[q] = (uint32_t)(g * kWave + select_bit(gm[g], r));
         }
+        gather_sample();
         __syncthreads();
         for (int g = tid; g < G; g += kRsThreads) gm[g] = 0ull;  // the words become the inlier mask again
     } else {
-        for (int j = tid; j < S; j += kRsThreads) {
-            const float* p = reinterpret_cast<const float*>(s.cloud + (size_t)sample_pos(M, j, seed) * (size_t)s.stride);
-            sx[j] = p[0];
-            sy[j] = p[1];
-            sz[j] = p[2];
+#pragma unroll
+        for (int q = 0; q < kRsPerThread; q++) {
+            const int j = tid + q * kRsThreads;
+            ids[q] = j < S ? (uint32_t)sample_pos(M, j, seed) : 0u;
         }
+        gather_sample();
     }
     // point j of the sample / its distance to a model (plane_dist's arithmetic)
     auto dist = [&](const float c[4], int j) { return fabsf(c[0] * sx[j] + c[1] * sy[j] + c[2] * sz[j] + c[3]); };
@@ -495,6 +549,8 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         misc[1] = 0;
     }
     __syncthreads();
+    RS_PHASE(0);  // sample gathered
+    RS_PHASE(14);  // (diagnostic) cost of a marker
     // ---- hypotheses, rounds of kRsRound; the replay below is executed by every thread on the same data ----
     int iterations = 0, best = -2147483647, best_draw = -1;
     double k = 1.0;
@@ -503,30 +559,47 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
     bool done = false;
     for (int d0 = 0; d0 < n_draws && !done; d0 += kRsRound) {
         const int d = d0 + w;
-        int cnt = 0;
+        int cnt = 0, cnt_wave = 0;  // per lane (the ragged end of the sample) / per wavefront
         bool degenerate = false;
         if (d < n_draws) {
             const Model m = model_of(d);
             degenerate = m.degenerate != 0;
+            RS_PHASE(9);  // (diagnostic) model of the draw
+            if (threadIdx.x == 0) RS_COUNT(13, m.valid ? 1 : 0);
             if (m.valid) {
                 typedef float f4 __attribute__((ext_vector_type(4)));
+                typedef float f2 __attribute__((ext_vector_type(2)));
                 const float c0 = m.c[0], c1 = m.c[1], c2 = m.c[2], c3 = m.c[3];
-                for (int j0 = 4 * lane; j0 < S; j0 += 4 * kWave) {  // four consecutive points per lane and iteration
-                    if (j0 + 3 < S) {
-                        const f4 x = *reinterpret_cast<const f4*>(sx + j0), y = *reinterpret_cast<const f4*>(sy + j0),
-                                 z = *reinterpret_cast<const f4*>(sz + j0);
-#pragma unroll
-                        for (int t = 0; t < 4; t++) cnt += (fabsf(c0 * x[t] + c1 * y[t] + c2 * z[t] + c3) < thr_f) ? 1 : 0;
-                    } else {
-                        for (int j = j0; j < S; j++) cnt += (dist(m.c, j) < thr_f) ? 1 : 0;
-                    }
+                // two points per instruction (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations, no contraction),
+                // the inliers counted from the comparison masks on the scalar unit
+                const f2 C0 = {c0, c0}, C1 = {c1, c1}, C2 = {c2, c2}, C3 = {c3, c3};
+                auto four = [&](int j0) {  // four consecutive points per lane
+                    const f4 x = *reinterpret_cast<const f4*>(sx + j0), y = *reinterpret_cast<const f4*>(sy + j0),
+                             z = *reinterpret_cast<const f4*>(sz + j0);
+                    const f2 da = ((C0 * x.xy + C1 * y.xy) + C2 * z.xy) + C3;
+                    const f2 db = ((C0 * x.zw + C1 * y.zw) + C2 * z.zw) + C3;
+                    cnt_wave += __popcll(__ballot(fabsf(da.x) < thr_f)) + __popcll(__ballot(fabsf(da.y) < thr_f)) +
+                                __popcll(__ballot(fabsf(db.x) < thr_f)) + __popcll(__ballot(fabsf(db.y) < thr_f));
+                };
+                const int n_full = (S >> 2) / kWave;  // iterations in which every lane holds four points
+                int it = 0;
+                for (; it + 2 <= n_full; it += 2) {  // (unrolled by hand: the ballots keep the compiler from doing it)
+                    four(4 * lane + it * (4 * kWave));
+                    four(4 * lane + (it + 1) * (4 * kWave));
                 }
+                if (it < n_full) four(4 * lane + it * (4 * kWave));
+                const int j0 = 4 * lane + n_full * (4 * kWave);
+                if (j0 + 3 < S) four(j0);
+                else
+                    for (int j = j0; j < S; j++) cnt += (dist(m.c, j) < thr_f) ? 1 : 0;  // the ragged end of the sample
             }
         }
+        RS_PHASE(10);  // (diagnostic) distances of the sample
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-        if (lane == 0) counts[w] = degenerate ? -1 : cnt;
+        if (lane == 0) counts[w] = degenerate ? -1 : cnt + cnt_wave;
         __syncthreads();
+        RS_PHASE(11);  // (diagnostic) wait for the round's other wavefronts
         for (int q = 0; q < kRsRound; q++) {  // ransac.hpp computeModel, as k_rs_select
             if (d0 + q >= n_draws || !((double)iterations < k)) {
                 done = true;
@@ -551,6 +624,8 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         }
         __syncthreads();
     }
+    RS_PHASE(1);  // hypothesis rounds
+    if (threadIdx.x == 0) RS_COUNT(8, iterations);
     if (best_draw < 0) {
         fail();
         return;
@@ -577,6 +652,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         }
         __syncthreads();
     }
+    RS_PHASE(2);  // inlier list
     const int ni = misc[0];
     if (use_refinement && ni > 3) {
         if (tid < kPartials) {  // thread p owns inliers p, p + 256, ...: the association of the single-slot kernel
@@ -597,6 +673,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
             for (int t = 0; t < 9; t++) acc[tid * 9 + t] = a[t];
         }
         __syncthreads();
+        RS_PHASE(3);  // partial sums
         // the 256 partials of each of the nine sums are combined in index order (the restatement's association) - by
         // nine lanes side by side, each with its 256 LDS reads in flight at once, instead of 2304 dependent steps of
         // one thread (which used to be most of this kernel's time)
@@ -610,6 +687,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         __syncthreads();
         if (tid < 9) acc[tid] = mine;
         __syncthreads();
+        RS_PHASE(4);  // combination
         if (tid == 0) {
             float s9[9];
             for (int t = 0; t < 9; t++) s9[t] = acc[t];
@@ -624,16 +702,38 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
             coeffs[3] = -1.0f * (e0 * s9[6] + e1 * s9[7] + e2 * s9[8]);
         }
     }
+    RS_PHASE(5);  // eigenvector
     // ---- final inlier set (bitmask keyed by original index; the host cleared it before the launch) ----
     const float sel_thr = up(use_refinement ? refine_thr : thr);
     int cnt = 0;
-    for (int j = tid; j < S; j += kRsThreads) {
-        if (valid && (dist(rm, j) < sel_thr)) {
-            const uint32_t id = pass ? (uint32_t)sample_idx[j] : (uint32_t)sample_pos(M, j, seed);
-            const uint32_t bit = 1u << (id & 31);
-            cnt += (atomicOr(const_cast<uint32_t*>(s.inlier_mask) + (id >> 5), bit) & bit) ? 0 : 1;  // duplicates count once
-        }
+    // Clouds up to 32 x kSample points: the slot's whole mask is put together where the inlier list was (LDS atomics)
+    // and leaves as plain coalesced stores - 4 M global atomics with return per 1024 frames were a fifth of this kernel.
+    const int mask_words = (int)((s.n + 31) >> 5);
+    const bool lds_mask = mask_words <= kSample;
+    uint32_t* lm = reinterpret_cast<uint32_t*>(inl_pos);
+    uint32_t* gmask = const_cast<uint32_t*>(s.inlier_mask);
+    if (lds_mask) {
+        for (int i = tid; i < mask_words; i += kRsThreads) lm[i] = 0u;
+        __syncthreads();
     }
+    {
+        // (global path: the thread's atomics travel together.)  The return values tell duplicates apart: they count once
+        uint32_t prev[kRsPerThread];
+#pragma unroll
+        for (int q = 0; q < kRsPerThread; q++) {
+            const int j = tid + q * kRsThreads;
+            const bool in = j < S && valid && (dist(rm, j) < sel_thr);
+            const uint32_t bit = 1u << (ids[q] & 31);
+            prev[q] = !in ? bit : lds_mask ? atomicOr(lm + (ids[q] >> 5), bit) : atomicOr(gmask + (ids[q] >> 5), bit);
+        }
+#pragma unroll
+        for (int q = 0; q < kRsPerThread; q++) cnt += (prev[q] & (1u << (ids[q] & 31))) ? 0 : 1;
+    }
+    if (lds_mask) {
+        __syncthreads();
+        for (int i = tid; i < mask_words; i += kRsThreads) gmask[i] = lm[i];
+    }
+    RS_PHASE(6);  // mask
     atomicAdd(&misc[1], cnt);
     __syncthreads();
     if (tid == 0) {
@@ -660,6 +760,8 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         pd->status = 0;
         pd->has_plane = 1;
     }
+    RS_PHASE(7);  // plane written
+    RS_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -791,3 +893,13 @@ __global__ void k_mask_from_flags(const int32_t* __restrict__ flags, long long n
 
 }  // namespace ransac
 }  // namespace mld
+
+#ifdef MLD_DIAG_RS_PHASES
+// diagnostic build only (profiles/tools/rs_phases.sh): reads and clears the phase clocks of k_rs_batch
+extern "C" int mld_debug_rs_phases(unsigned long long* out16) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mld::ransac::g_rs_phase), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long zero[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(mld::ransac::g_rs_phase), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
