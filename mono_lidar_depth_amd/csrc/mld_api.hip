@@ -1079,12 +1079,12 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
     for (int i = 0; i < n_slots; i++) max_n = std::max(max_n, n[i]);
     // z pass-through (RansacPlane.cpp:57-64) inside the batched kernel: one byte of LDS per 64 points + one int per 1024
     const bool pass = P.ransac_plane_min_z > -1001.;
-    const size_t lds_fixed = (size_t)kSample * 4 * sizeof(float) + (size_t)kPartials * 9 * sizeof(float) +
-                             (2 * kRsRound + kRsMisc) * sizeof(int);
+    const size_t lds_fixed = (size_t)kSample * 5 * sizeof(float) + (size_t)kPartials * 9 * sizeof(float) +
+                             (2 * kRsRound + kRsMisc + kRsEpochInts) * sizeof(int);
     const size_t n_chunks = (size_t)((max_n + 1023) / 1024);
     const size_t lds = lds_fixed + (pass ? (n_chunks + 1) * sizeof(int) + 16 * n_chunks + 16 : 0);
-    if (lds > 150 * 1024) {
-        // clouds beyond ~2.3 M points with the pass-through: the per-slot estimator (ordered compaction in device
+    if (lds > 158 * 1024) {
+        // clouds beyond ~1.5 M points with the pass-through: the per-slot estimator (ordered compaction in device
         // memory), which synchronises once per slot
         if ((rc = set_clouds_common(ctx, n_slots, pts_dev, n, stride_bytes, nullptr, nullptr))) return rc;
         for (int i = 0; i < n_slots; i++) {

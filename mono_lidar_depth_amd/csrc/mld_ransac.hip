@@ -335,6 +335,9 @@ __global__ __launch_bounds__(kPartials) void k_rs_refine(const float* __restrict
 constexpr int kRsThreads = 1024;
 constexpr int kRsRound = kRsThreads / kWave;  // hypotheses evaluated per round
 constexpr int kRsPerThread = (kSample + kRsThreads - 1) / kRsThreads;  // sample points per thread
+constexpr int kRsEpoch = kRsThreads;  // draws whose models are set up together (after a slot's first 64)
+constexpr int kRsLater = 4;       // draws per wavefront and round after a slot's first round
+constexpr int kRsEpochInts = kRsEpoch * 6;  // LDS of an epoch: model (4 floats), count, list entry
 
 __device__ inline long long sample_pos(long long M, int j, uint32_t seed) {
     long long pos = j;
@@ -352,10 +355,58 @@ __device__ inline int select_bit(unsigned long long m, int k) {
     return __ffsll((long long)m) - 1;
 }
 
+// Inliers of NM planes among the S sample points (three coordinate arrays in LDS), by one wavefront: a lane reads four
+// consecutive points with three 16-byte LDS loads - once for all NM planes (the loop is bound by LDS bandwidth with one
+// plane per pass).  Two points per instruction (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations as plane_dist,
+// no contraction), the inliers counted from the comparison masks on the scalar unit.  out[m] is wavefront-uniform.
+template <int NM>
+__device__ inline void rs_count_inliers(const float* sx, const float* sy, const float* sz, int S, int lane, float thr_f,
+                                        const float (&c)[NM][4], int (&out)[NM]) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    int cnt[NM], cnt_wave[NM];  // per lane (the ragged end of the sample) / per wavefront
+#pragma unroll
+    for (int m = 0; m < NM; m++) cnt[m] = cnt_wave[m] = 0;
+    auto four = [&](int j0) {  // four consecutive points per lane
+        const f4 x = *reinterpret_cast<const f4*>(sx + j0), y = *reinterpret_cast<const f4*>(sy + j0),
+                 z = *reinterpret_cast<const f4*>(sz + j0);
+#pragma unroll
+        for (int m = 0; m < NM; m++) {
+            const f2 C0 = {c[m][0], c[m][0]}, C1 = {c[m][1], c[m][1]}, C2 = {c[m][2], c[m][2]}, C3 = {c[m][3], c[m][3]};
+            const f2 da = ((C0 * x.xy + C1 * y.xy) + C2 * z.xy) + C3;
+            const f2 db = ((C0 * x.zw + C1 * y.zw) + C2 * z.zw) + C3;
+            cnt_wave[m] += __popcll(__ballot(fabsf(da.x) < thr_f)) + __popcll(__ballot(fabsf(da.y) < thr_f)) +
+                           __popcll(__ballot(fabsf(db.x) < thr_f)) + __popcll(__ballot(fabsf(db.y) < thr_f));
+        }
+    };
+    const int n_full = (S >> 2) / kWave;  // iterations in which every lane holds four points
+    int it = 0;
+    if (NM == 1)
+        for (; it + 2 <= n_full; it += 2) {  // (unrolled by hand: the ballots keep the compiler from doing it)
+            four(4 * lane + it * (4 * kWave));
+            four(4 * lane + (it + 1) * (4 * kWave));
+        }
+    for (; it < n_full; it++) four(4 * lane + it * (4 * kWave));
+    const int j0 = 4 * lane + n_full * (4 * kWave);
+    if (j0 + 3 < S) four(j0);
+    else
+        for (int j = j0; j < S; j++)  // the ragged end of the sample
+#pragma unroll
+            for (int m = 0; m < NM; m++)
+                cnt[m] += (fabsf(c[m][0] * sx[j] + c[m][1] * sy[j] + c[m][2] * sz[j] + c[m][3]) < thr_f) ? 1 : 0;
+#pragma unroll
+    for (int m = 0; m < NM; m++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt[m] += __shfl_xor(cnt[m], o);
+        out[m] = cnt[m] + cnt_wave[m];
+    }
+}
+
 #ifdef MLD_DIAG_RS_PHASES
 // diagnostic build only: time per phase of k_rs_batch (100 MHz ticks of thread 0, collected in LDS, summed over the
 // blocks at the end)
 __device__ unsigned long long g_rs_phase[16];
+__device__ unsigned int g_rs_slot[4096 * 4];  // per slot: ticks in all, ticks of the rounds, iterations, epochs
 constexpr int kRsMisc = 8 + 32;
 #define RS_PHASE(i)                                                                     \
     do {                                                                                \
@@ -366,8 +417,19 @@ constexpr int kRsMisc = 8 + 32;
         }                                                                               \
     } while (0)
 #define RS_COUNT(i, v) reinterpret_cast<unsigned long long*>(misc + 8)[i] += (unsigned long long)(v)
+#define RS_PIN(x) asm volatile("" ::"v"(x))  /* the value is computed before the next marker */
 #define RS_FLUSH()                                                                                              \
     do {                                                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                                            \
+            unsigned long long* a_ = reinterpret_cast<unsigned long long*>(misc + 8);                           \
+            unsigned long long all_ = 0;                                                                        \
+            for (int i_ = 0; i_ < 15; i_++) all_ += i_ == 8 ? 0 : a_[i_];                                       \
+            g_rs_slot[4 * blockIdx.x + 0] = (unsigned int)all_;                                                 \
+            g_rs_slot[4 * blockIdx.x + 1] = (unsigned int)wall_clock64(); /* end, absolute */                    \
+            g_rs_slot[4 * blockIdx.x + 2] = (unsigned int)a_[8];                                                \
+            g_rs_slot[4 * blockIdx.x + 3] = (__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xFFFFF) | /* HW_ID */ \
+                                            ((__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) << 20); /* XCC_ID */ \
+        }                                                                                                       \
         if (threadIdx.x == 0)                                                                                   \
             for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_rs_phase[i_], reinterpret_cast<unsigned long long*>(misc + 8)[i_]); \
     } while (0)
@@ -375,6 +437,7 @@ constexpr int kRsMisc = 8 + 32;
 constexpr int kRsMisc = 8;
 #define RS_PHASE(i) do {} while (0)
 #define RS_COUNT(i, v) do {} while (0)
+#define RS_PIN(x) do {} while (0)
 #define RS_FLUSH() do {} while (0)
 #endif
 
@@ -392,19 +455,32 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
     float* sy = sx + kSample;                                      // [kSample]
     float* sz = sy + kSample;                                      // [kSample]
     int* inl_pos = reinterpret_cast<int*>(sz + kSample);           // [kSample]
-    float* acc = reinterpret_cast<float*>(inl_pos + kSample);      // [kPartials * 9]
-    int* counts = reinterpret_cast<int*>(acc + kPartials * 9);     // [kRsRound]
-    int* wsum = counts + kRsRound;                                 // [kRsRound]
-    int* misc = wsum + kRsRound;                                   // [0] running offset, [1] inlier total, [2] candidates
+    uint32_t* sidx = reinterpret_cast<uint32_t*>(inl_pos + kSample);  // [kSample] original index of sample point j
+    float* acc = reinterpret_cast<float*>(sidx + kSample);         // [kPartials * 9]
+    // [0] inliers of the best draw, [1] inlier total, [2] pass-through candidates
+    int* misc = reinterpret_cast<int*>(acc + kPartials * 9) + 2 * kRsRound;
+    // kernel arguments are otherwise fetched where they are first used, in the middle of a slot's serial phases
+    asm volatile("" ::"s"(n_draws), "s"(max_it), "s"(probability), "s"(thr), "s"(refine_thr), "s"(use_refinement), "s"(pass));
+    asm volatile("" ::"s"(lo), "s"(hi), "s"(far_elin), "s"(far_econst), "s"(far_thr));
+#ifdef MLD_DIAG_RS_PHASES
+    unsigned long long t_prev = wall_clock64();
+    if (threadIdx.x == 0)
+        for (int i_ = 0; i_ < 16; i_++) reinterpret_cast<unsigned long long*>(misc + 8)[i_] = 0ull;
+#endif
+    // "(double)distance < thr" for a float distance == "distance < thr_f" with thr_f the smallest float >= thr
+    auto up = [](double t) {
+        float f = (float)t;
+        if ((double)f < t) f = nextafterf(f, __builtin_huge_valf());
+        return f;
+    };
+    const float thr_f = up(thr), sel_thr = up(use_refinement ? refine_thr : thr);
+    const double log_probability = log(1.0 - probability);
+    asm volatile("" ::"v"(log_probability));  // here, beside the first cloud reads, not where it is first used
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid >> 6;
     const SlotDesc s = slots[blockIdx.x];
     PlaneDev* pd = out + blockIdx.x;
     const uint32_t seed = seeds[blockIdx.x];
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid >> 6;
-#ifdef MLD_DIAG_RS_PHASES
-    unsigned long long t_prev = wall_clock64();
-    if (tid == 0)
-        for (int i_ = 0; i_ < 16; i_++) reinterpret_cast<unsigned long long*>(misc + 8)[i_] = 0ull;
-#endif
+    asm volatile("" ::"s"(s.cloud), "s"(s.inlier_mask), "s"(s.n), "s"(s.stride), "s"(seed), "s"(pd));
     long long M = s.n;
     int S = M > kSample ? kSample : (int)M;
     auto fail = [&]() {
@@ -419,7 +495,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         fail();
         return;
     }
-    // original indices of this thread's sample points (j = tid, tid + 1024, ...), kept for the inlier mask at the end
+    // original indices of this thread's sample points (j = tid, tid + 1024, ...); they stay in LDS for the inlier mask
     uint32_t ids[kRsPerThread];
 #pragma unroll
     for (int q = 0; q < kRsPerThread; q++) ids[q] = 0u;
@@ -441,13 +517,14 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
                 sx[j] = px[q];
                 sy[j] = py[q];
                 sz[j] = pz[q];
+                sidx[j] = ids[q];
             }
         }
     };
     if (pass) {
         const long long n = s.n;
         const int G = (int)((n + kWave - 1) / kWave), NC = (G + 15) / 16;  // 64-point groups, 1024-point chunks
-        int* cpre = misc + kRsMisc;                                              // [NC + 1] candidates before chunk c
+        int* cpre = misc + kRsMisc + kRsEpochInts;                                              // [NC + 1] candidates before chunk c
         unsigned char* gcnt = reinterpret_cast<unsigned char*>(cpre + NC + 1);  // [16 * NC] candidates per group
         // the slot's inlier-mask words (n / 8 bytes, written only at the very end) hold the group masks meanwhile
         unsigned long long* gm = reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(s.inlier_mask));
@@ -537,13 +614,6 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         const float p0[3] = {sx[a], sy[a], sz[a]}, p1[3] = {sx[b], sy[b], sz[b]}, p2[3] = {sx[c], sy[c], sz[c]};
         return plane_from(p0, p1, p2);
     };
-    // "(double)distance < thr" for a float distance == "distance < thr_f" with thr_f the smallest float >= thr
-    auto up = [](double t) {
-        float f = (float)t;
-        if ((double)f < t) f = nextafterf(f, __builtin_huge_valf());
-        return f;
-    };
-    const float thr_f = up(thr);
     if (tid == 0) {
         misc[0] = 0;
         misc[1] = 0;
@@ -551,78 +621,138 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
     __syncthreads();
     RS_PHASE(0);  // sample gathered
     RS_PHASE(14);  // (diagnostic) cost of a marker
-    // ---- hypotheses, rounds of kRsRound; the replay below is executed by every thread on the same data ----
+    // ---- hypotheses.  The models of an epoch of draws are set up lane-parallel; only the draws whose model is valid
+    // (about half) need their inliers counted, so a round hands the next VALID draws to the wavefronts: most slots are
+    // decided in one round.  The stopping rule is replayed over the draws in order (skipped and invalid ones included)
+    // by every thread on the same data. ----
     int iterations = 0, best = -2147483647, best_draw = -1;
     double k = 1.0;
-    const double log_probability = log(1.0 - probability);
     const double one_over = 1.0 / (double)S;
     bool done = false;
-    for (int d0 = 0; d0 < n_draws && !done; d0 += kRsRound) {
-        const int d = d0 + w;
-        int cnt = 0, cnt_wave = 0;  // per lane (the ragged end of the sample) / per wavefront
-        bool degenerate = false;
-        if (d < n_draws) {
-            const Model m = model_of(d);
-            degenerate = m.degenerate != 0;
-            RS_PHASE(9);  // (diagnostic) model of the draw
-            if (threadIdx.x == 0) RS_COUNT(13, m.valid ? 1 : 0);
-            if (m.valid) {
-                typedef float f4 __attribute__((ext_vector_type(4)));
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                const float c0 = m.c[0], c1 = m.c[1], c2 = m.c[2], c3 = m.c[3];
-                // two points per instruction (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations, no contraction),
-                // the inliers counted from the comparison masks on the scalar unit
-                const f2 C0 = {c0, c0}, C1 = {c1, c1}, C2 = {c2, c2}, C3 = {c3, c3};
-                auto four = [&](int j0) {  // four consecutive points per lane
-                    const f4 x = *reinterpret_cast<const f4*>(sx + j0), y = *reinterpret_cast<const f4*>(sy + j0),
-                             z = *reinterpret_cast<const f4*>(sz + j0);
-                    const f2 da = ((C0 * x.xy + C1 * y.xy) + C2 * z.xy) + C3;
-                    const f2 db = ((C0 * x.zw + C1 * y.zw) + C2 * z.zw) + C3;
-                    cnt_wave += __popcll(__ballot(fabsf(da.x) < thr_f)) + __popcll(__ballot(fabsf(da.y) < thr_f)) +
-                                __popcll(__ballot(fabsf(db.x) < thr_f)) + __popcll(__ballot(fabsf(db.y) < thr_f));
-                };
-                const int n_full = (S >> 2) / kWave;  // iterations in which every lane holds four points
-                int it = 0;
-                for (; it + 2 <= n_full; it += 2) {  // (unrolled by hand: the ballots keep the compiler from doing it)
-                    four(4 * lane + it * (4 * kWave));
-                    four(4 * lane + (it + 1) * (4 * kWave));
-                }
-                if (it < n_full) four(4 * lane + it * (4 * kWave));
-                const int j0 = 4 * lane + n_full * (4 * kWave);
-                if (j0 + 3 < S) four(j0);
-                else
-                    for (int j = j0; j < S; j++) cnt += (dist(m.c, j) < thr_f) ? 1 : 0;  // the ragged end of the sample
-            }
-        }
-        RS_PHASE(10);  // (diagnostic) distances of the sample
+    RS_PIN(log_probability);
+    RS_PIN(one_over);
+    RS_PHASE(12);  // (diagnostic) constants of the stopping rule
+    float* mc = reinterpret_cast<float*>(misc + kRsMisc);  // [kRsEpoch][4] model of the draw
+    int* mcount = reinterpret_cast<int*>(mc + 4 * kRsEpoch);  // [kRsEpoch] its inliers; 0: model not valid; -1: skipped draw
+    int* vlist = mcount + kRsEpoch;                           // [kRsEpoch] the epoch's valid draws, in order
+    int* wcnt = misc - 2 * kRsRound;  // [kRsRound] valid draws a wavefront found in its share of the epoch
+    for (int e0 = 0, cap = 0; e0 < n_draws && !done; e0 += cap) {
+        // The first epoch is one wavefront's worth of draws (most slots stop within it).  A slot that goes on has a small
+        // inlier share or a cloud whose draws are mostly skipped (NaN points): every wavefront sets up 64 models then.
+        cap = e0 == 0 ? kWave : kRsEpoch;
+        const int ne = n_draws - e0 < cap ? n_draws - e0 : cap;
+        const int dl = w * kWave + lane;  // this thread's draw of the epoch
+        bool v = false;
+        if (dl < ne) {
+            const Model m = model_of(e0 + dl);
+            v = m.valid != 0;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-        if (lane == 0) counts[w] = degenerate ? -1 : cnt + cnt_wave;
+            for (int t = 0; t < 4; t++) mc[4 * dl + t] = m.c[t];
+            mcount[dl] = m.degenerate ? -1 : 0;
+            RS_PIN(m.c[3]);
+        }
+        RS_PHASE(13);  // (diagnostic) model_of
+        const unsigned long long vm = __ballot(v);
+        if (lane == 0) wcnt[w] = __popcll(vm);
         __syncthreads();
-        RS_PHASE(11);  // (diagnostic) wait for the round's other wavefronts
-        for (int q = 0; q < kRsRound; q++) {  // ransac.hpp computeModel, as k_rs_select
-            if (d0 + q >= n_draws || !((double)iterations < k)) {
-                done = true;
-                break;
+        int nv = 0, off = 0;
+#pragma unroll
+        for (int q = 0; q < kRsRound; q++) {
+            const int c = wcnt[q];
+            off += q < w ? c : 0;
+            nv += c;
+        }
+        if (v) vlist[off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(vm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)vm, 0u))] = dl;
+        __syncthreads();
+        RS_PHASE(9);  // (diagnostic) models of the epoch
+        if (threadIdx.x == 0) RS_COUNT(15, 1);
+        int next = 0;  // draws of the epoch replayed so far
+        for (int v0 = 0, round_n = 0; !done && next < ne; v0 += round_n) {
+            // the first round decides most slots with one draw per wavefront; a slot that goes on needs many more
+            // (a small inlier share): kRsLater draws per wavefront from then on, the sample read once for all of them
+            const int per = v0 == 0 ? 1 : kRsLater, first = v0 + w * per;
+            round_n = kRsRound * per;
+            if (first < nv) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                if (per == 1) {
+                    const int q = vlist[first];
+                    const f4 mq = *reinterpret_cast<const f4*>(mc + 4 * q);
+                    const float c1[1][4] = {{mq.x, mq.y, mq.z, mq.w}};
+                    int n1[1];
+                    rs_count_inliers<1>(sx, sy, sz, S, lane, thr_f, c1, n1);
+                    if (lane == 0) mcount[q] = n1[0];
+                } else {
+                    const int mine = nv - first < kRsLater ? nv - first : kRsLater;
+                    int qs[kRsLater], nl[kRsLater];
+                    float cl[kRsLater][4];
+#pragma unroll
+                    for (int t = 0; t < kRsLater; t++) {  // (the last draw again where the list ends)
+                        qs[t] = vlist[first + (t < mine ? t : mine - 1)];
+                        const f4 mq = *reinterpret_cast<const f4*>(mc + 4 * qs[t]);
+                        cl[t][0] = mq.x;
+                        cl[t][1] = mq.y;
+                        cl[t][2] = mq.z;
+                        cl[t][3] = mq.w;
+                    }
+                    rs_count_inliers<kRsLater>(sx, sy, sz, S, lane, thr_f, cl, nl);
+#pragma unroll
+                    for (int t = 0; t < kRsLater; t++)
+                        if (lane == 0 && t < mine) mcount[qs[t]] = nl[t];
+                }
             }
-            const int c = counts[q];
-            if (c < 0) continue;  // skipped draw
-            if (c > best) {
-                best = c;
-                best_draw = d0 + q;
-                const double wr = (double)best * one_over;
-                double p_no = 1.0 - wr * wr * wr;
-                p_no = fmax(2.220446049250313e-16, p_no);
-                p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
-                k = log_probability / log(p_no);
-            }
-            ++iterations;
-            if (iterations > max_it) {
-                done = true;
-                break;
+            RS_PHASE(10);  // (diagnostic) distances of the sample
+            __syncthreads();
+            RS_PHASE(11);  // (diagnostic) wait for the round's other wavefronts
+            // every draw ahead of the next valid one that has not been counted yet can be replayed now
+            const int upto = v0 + round_n < nv ? vlist[v0 + round_n] : ne;
+            // ransac.hpp computeModel, as k_rs_select.  One draw after the other is an LDS round trip per draw (60 ns; a
+            // slot whose draws are mostly skipped replays hundreds): the counts of 64 draws are fetched at once and the
+            // runs of draws that neither improve on the best model nor reach a stopping rule are booked in one step.
+            auto one_draw = [&](int c, int draw) {  // the reference's loop body; false: stop
+                if (!((double)iterations < k)) return false;
+                if (c < 0) return true;  // skipped draw
+                if (c > best) {
+                    best = c;
+                    best_draw = draw;
+                    const double wr = (double)best * one_over;
+                    double p_no = 1.0 - wr * wr * wr;
+                    p_no = fmax(2.220446049250313e-16, p_no);
+                    p_no = fmin(1.0 - 2.220446049250313e-16, p_no);
+                    k = log_probability / log(p_no);
+                }
+                ++iterations;
+                return !(iterations > max_it);
+            };
+            while (next < upto && !done) {
+                const int nb = upto - next < kWave ? upto - next : kWave;
+                const int c = lane < nb ? mcount[next + lane] : -1;
+                const unsigned long long counted = __ballot(c >= 0);
+                int pos = 0;
+                while (pos < nb && !done) {
+                    const unsigned long long rest = ~0ull << pos;
+                    const unsigned long long better = __ballot(c > best) & counted & rest;
+                    const int ipos = better ? __ffsll((long long)better) - 1 : nb;  // the next draw that improves
+                    const unsigned long long run = counted & rest & (ipos < kWave ? ~(~0ull << ipos) : ~0ull);
+                    const int m = __popcll(run);  // counted draws ahead of it
+                    // first iteration counts at which the rules stop the loop: !(i < k) before a draw, i > max_it after one
+                    const int stop_k = k >= 2147483647.0 ? 2147483647 : (int)ceil(k);
+                    if (iterations + m < stop_k && iterations + m <= max_it) {
+                        iterations += m;  // none of them stops the loop
+                        pos = ipos;
+                        if (ipos < nb) {
+                            if (!one_draw(__shfl(c, ipos), e0 + next + ipos)) done = true;
+                            pos = ipos + 1;
+                        }
+                    } else {  // a stopping rule fires within the run (or right after it): draw by draw
+                        const int end = ipos < nb ? ipos + 1 : nb;
+                        for (; pos < end && !done; pos++)
+                            if (!one_draw(__shfl(c, pos), e0 + next + pos)) done = true;
+                    }
+                }
+                next += nb;
             }
         }
-        __syncthreads();
+        __syncthreads();  // the next epoch rewrites the models and counts
     }
     RS_PHASE(1);  // hypothesis rounds
     if (threadIdx.x == 0) RS_COUNT(8, iterations);
@@ -634,22 +764,45 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
     const float rm[4] = {bm.c[0], bm.c[1], bm.c[2], bm.c[3]};
     float coeffs[4] = {rm[0], rm[1], rm[2], rm[3]};
     const bool valid = fabs((double)rm[2]) >= 0.984807753012208;
-    // ---- ordered list of the RANSAC inliers (positions in the sample), as k_rs_refine ----
-    for (int c0 = 0; c0 < S; c0 += kRsThreads) {
-        const int j = c0 + tid;
-        const bool in = (j < S) && valid && (dist(rm, j) < thr_f);
-        const unsigned long long m = __ballot(in);
-        if (lane == 0) wsum[w] = __popcll(m);
-        __syncthreads();
-        int off = misc[0];
-        for (int q = 0; q < w; q++) off += wsum[q];
-        if (in) inl_pos[off + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = j;
-        __syncthreads();
-        if (tid == 0) {
-            int t = 0;
-            for (int q = 0; q < kRsRound; q++) t += wsum[q];
-            misc[0] += t;
+    // ---- ordered list of the RANSAC inliers (positions in the sample), as k_rs_refine: the flags of a thread's (up to
+    // six) points at once, one scan over the 6 x 16 (chunk, wavefront) counts ----
+    {
+        int* wcnt = reinterpret_cast<int*>(acc);       // [kRsPerThread * kRsRound] (the partial sums are not in use yet)
+        int* wpre = wcnt + kRsPerThread * kRsRound;    // exclusive prefix of wcnt
+        int rank[kRsPerThread];
+        unsigned in_bits = 0u;
+#pragma unroll
+        for (int q = 0; q < kRsPerThread; q++) {
+            const int j = tid + q * kRsThreads;
+            const bool in = (j < S) && valid && (dist(rm, j) < thr_f);
+            const unsigned long long m = __ballot(in);
+            rank[q] = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            in_bits |= in ? (1u << q) : 0u;
+            if (lane == 0) wcnt[q * kRsRound + w] = __popcll(m);
         }
+        __syncthreads();
+        if (w == 0) {
+            static_assert(kRsPerThread * kRsRound <= 2 * kWave, "two counts per lane");
+            const int n_cnt = kRsPerThread * kRsRound;
+            const int v0 = lane < n_cnt ? wcnt[lane] : 0, v1 = kWave + lane < n_cnt ? wcnt[kWave + lane] : 0;
+            int i0 = v0, i1 = v1;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const int t0 = __shfl_up(i0, d), t1 = __shfl_up(i1, d);
+                if (lane >= d) {
+                    i0 += t0;
+                    i1 += t1;
+                }
+            }
+            const int total0 = __shfl(i0, kWave - 1);
+            if (lane < n_cnt) wpre[lane] = i0 - v0;
+            if (kWave + lane < n_cnt) wpre[kWave + lane] = total0 + i1 - v1;
+            if (lane == kWave - 1) misc[0] = total0 + i1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kRsPerThread; q++)
+            if (in_bits & (1u << q)) inl_pos[wpre[q * kRsRound + w] + rank[q]] = tid + q * kRsThreads;
         __syncthreads();
     }
     RS_PHASE(2);  // inlier list
@@ -704,7 +857,6 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
     }
     RS_PHASE(5);  // eigenvector
     // ---- final inlier set (bitmask keyed by original index; the host cleared it before the launch) ----
-    const float sel_thr = up(use_refinement ? refine_thr : thr);
     int cnt = 0;
     // Clouds up to 32 x kSample points: the slot's whole mask is put together where the inlier list was (LDS atomics)
     // and leaves as plain coalesced stores - 4 M global atomics with return per 1024 frames were a fifth of this kernel.
@@ -718,16 +870,17 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
     }
     {
         // (global path: the thread's atomics travel together.)  The return values tell duplicates apart: they count once
-        uint32_t prev[kRsPerThread];
+        uint32_t prev[kRsPerThread], bits[kRsPerThread];
 #pragma unroll
         for (int q = 0; q < kRsPerThread; q++) {
             const int j = tid + q * kRsThreads;
             const bool in = j < S && valid && (dist(rm, j) < sel_thr);
-            const uint32_t bit = 1u << (ids[q] & 31);
-            prev[q] = !in ? bit : lds_mask ? atomicOr(lm + (ids[q] >> 5), bit) : atomicOr(gmask + (ids[q] >> 5), bit);
+            const uint32_t id = in ? sidx[j] : 0u;
+            bits[q] = 1u << (id & 31);
+            prev[q] = !in ? bits[q] : lds_mask ? atomicOr(lm + (id >> 5), bits[q]) : atomicOr(gmask + (id >> 5), bits[q]);
         }
 #pragma unroll
-        for (int q = 0; q < kRsPerThread; q++) cnt += (prev[q] & (1u << (ids[q] & 31))) ? 0 : 1;
+        for (int q = 0; q < kRsPerThread; q++) cnt += (prev[q] & bits[q]) ? 0 : 1;
     }
     if (lds_mask) {
         __syncthreads();
@@ -901,5 +1054,9 @@ extern "C" int mld_debug_rs_phases(unsigned long long* out16) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mld::ransac::g_rs_phase), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
     unsigned long long zero[16] = {};
     return hipMemcpyToSymbol(HIP_SYMBOL(mld::ransac::g_rs_phase), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+extern "C" int mld_debug_rs_slots(unsigned int* out) {  // 4096 x (ticks, ticks of the rounds, iterations, epochs)
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mld::ransac::g_rs_slot), 4096 * 4 * sizeof(unsigned int)) == hipSuccess ? 0 : -1;
 }
 #endif

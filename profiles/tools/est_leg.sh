@@ -1,15 +1,18 @@
 #!/bin/bash
-# the plane-estimated leg of bench.py (k_rs_batch ahead of the projection): two contexts in turn, two contexts with
-# half a step each, one context; MLD_RS_PRIORITY=1: k_rs_batch on a stream of the highest priority
+# the plane-estimated leg of bench.py (k_rs_batch ahead of the projection): two contexts with half a step each, one
+# context, two contexts in turn; arguments: libraries to compare ("-" = the in-tree one)
 run() {
 python bench.py --steps 100 --warmup 3 --repeats 1 --cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0 $1 2>gpurun_out/est.err | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); e=d['plane_estimated']
-print('$1 prio=$MLD_RS_PRIORITY', 'step', round(d['ms_per_step'],4), 'estimated', round(e['ms_per_step'],4), {k:round(v*1e3,1) for k,v in e['kernels_ms_per_launch'].items()}, 'frames/launch', e['frame_slots_per_launch'], e['verified'])"
+print('$2 $1', 'step', round(d['ms_per_step'],4), 'estimated', round(e['ms_per_step'],4), {k:round(v*1e3,1) for k,v in e['kernels_ms_per_launch'].items()}, 'frames/launch', e['frame_slots_per_launch'], e['verified'])"
 }
+LIBS=${@:--}
 for r in 1 2; do
-for extra in "--est-schedule turn" "--est-schedule split" "--contexts 1"; do
-  MLD_RS_PRIORITY=0 run "$extra"
-  MLD_RS_PRIORITY=1 run "$extra"
+for extra in "--est-schedule split" "--contexts 1" "--est-schedule turn"; do
+  for lib in $LIBS; do
+    if [ "$lib" = "-" ]; then unset MLD_HIP_LIBRARY; else export MLD_HIP_LIBRARY=$PWD/profiles/tools/libs/$lib.so; fi
+    run "$extra" "$lib"
+  done
 done
 done

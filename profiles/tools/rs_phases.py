@@ -21,6 +21,7 @@ est.InitConfig(P)
 est.Initialize(cam, T)
 lib = est._lib
 lib.mld_debug_rs_phases.argtypes = [C.POINTER(C.c_ulonglong)]
+lib.mld_debug_rs_slots.argtypes = [C.POINTER(C.c_uint)]
 out = (C.c_ulonglong * 16)()
 names = ["sample", "rounds", "inlier list", "partial sums", "combination", "eigenvector", "mask", "plane"]
 for it in range(3):
@@ -29,6 +30,25 @@ for it in range(3):
     assert lib.mld_debug_rs_phases(out) == 0
     v = np.array(list(out), dtype=np.float64)
     print("us per block:", {n: round(v[i] / 100.0 / B, 2) for i, n in enumerate(names)},
-          "| rounds in detail:", {n: round(v[i] / 100.0 / B, 2) for i, n in ((9, "model"), (10, "distances"), (11, "barrier"), (1, "replay"), (14, "empty marker"))},
-          "total", round((v[:8].sum() + v[9:12].sum()) / 100.0 / B, 2), "iterations/block", round(v[8] / B, 1),
-          "valid draws of wavefront 0 per block", round(v[13] / B, 2))
+          "| rounds in detail:", {n: round(v[i] / 100.0 / B, 2) for i, n in ((9, "model"), (10, "distances"), (11, "barrier"), (1, "replay"), (14, "empty marker"), (12, "constants"), (13, "model_of"), (15, "model_of first (TWICE build)"))},
+          "total", round((v[:8].sum() + v[9:14].sum()) / 100.0 / B, 2), "iterations/block", round(v[8] / B, 1),
+          "")
+    st = (C.c_uint * (4096 * 4))()
+    assert lib.mld_debug_rs_slots(st) == 0
+    t = np.array(list(st), dtype=np.float64).reshape(4096, 4)[:B]
+    dur, end, hw = t[:, 0], t[:, 1], t[:, 3].astype(np.int64)
+    start = (end - dur) % 2**32
+    t0 = start.min()
+    cu = (hw >> 8) & 0xF | ((hw >> 12) & 0x3) << 4 | ((hw >> 13) & 0x7) << 6 | (hw >> 20) << 10  # cu, sh, se, xcc
+    print("us per slot: mean", round(dur.mean() / 100, 1), "percentiles 50/90/99/max",
+          [round(float(x) / 100, 1) for x in np.percentile(dur, [50, 90, 99, 100])],
+          "| kernel span (first start to last end)", round((end.max() - t0) / 100, 1), "us; distinct CUs", len(set(cu.tolist())))
+    gaps, per_cu = [], []
+    for c in set(cu.tolist()):
+        i = np.where(cu == c)[0]
+        i = i[np.argsort(start[i])]
+        per_cu.append(len(i))
+        gaps += [(start[i[j + 1]] - end[i[j]]) / 100 for j in range(len(i) - 1)]
+    print("slots per CU min/mean/max", min(per_cu), round(float(np.mean(per_cu)), 2), max(per_cu), "| gap between a block's end and the next block's start on its CU: mean",
+          round(float(np.mean(gaps)), 1), "percentiles 50/90/max", [round(float(x), 1) for x in np.percentile(gaps, [50, 90, 100])],
+          "| first starts (us after t0) 50/90/max", [round(float(x) / 100, 1) for x in np.percentile(start - t0, [25, 50, 100])])
