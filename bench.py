@@ -46,10 +46,6 @@ def parse_args():
     ap.add_argument("--slots", type=int, default=0,
                     help="frame slots of the context (0 = frames-per-step); a step runs frames-per-step/slots launch sets")
     ap.add_argument("--no-estimated", action="store_true", help="skip the plane-estimated leg")
-    ap.add_argument("--est-schedule", choices=("turn", "split"), default="turn",
-                    help="plane-estimated leg with two contexts: 'turn' = whole steps in turn, the next context released "
-                         "by the end of this one's plane estimation (its estimation runs beside this projection, its "
-                         "projection beside these feature kernels); 'split' = every context takes half of the step's frames")
     ap.add_argument("--no-exclusive", action="store_true",
                     help="skip the pass that times each kernel alone (profiling: keeps the kernel statistics of a trace "
                          "to the launches of the timed schedule)")
@@ -278,7 +274,7 @@ class Resident:
     """B device-resident frames (U distinct clouds, B distinct feature sets) and a context with S frame slots."""
 
     def __init__(self, P, cam, T, scanner, B, U, F, seq, device, integer_uv=False, slots=0, contexts=1, shared_mode=1,
-                 pair=False, est_schedule="split"):
+                 pair=False):
         import torch
         from mono_lidar_depth_amd import DepthEstimator, synth
         dev = torch.device("cuda", device)
@@ -319,9 +315,7 @@ class Resident:
         assert B % S == 0 and (self.whole or (B // S) % NC == 0), "--frames-per-step must be a multiple of --slots x --contexts"
         self.k = 0
         self.est_batches = None
-        self.est_turn = self.whole and NC > 1 and est_schedule == "turn"
-        # frame slots per launch of the plane-estimated leg
-        self.est_S = S if (not self.whole or NC == 1 or self.est_turn) else B // NC
+        self.est_S = S if (not self.whole or NC == 1) else B // NC  # frame slots per launch of the plane-estimated leg
         self.ests = []
         for _ in range(NC):
             e = DepthEstimator(device=device, max_frames=S, max_features=F)  # queues allocated up front
@@ -381,23 +375,10 @@ class Resident:
         the GroundPlane handed to setInputCloud is not segmented yet) instead of supplied."""
         import ctypes as C
         todo = self.batches
-        if self.est_turn:
-            # whole steps in turn: k_rs_batch does not fit beside the feature kernels (LDS) but it does beside a
-            # projection, so the next context is released by the end of this one's estimation
-            nb = len(self.batches)
-            e, b = self.batches[self.k % nb]
-            nxt = self.batches[(self.k + 1) % nb][0]
-            n = b["n"]
-            if "seeds" not in b:
-                b["seeds"] = (C.c_uint32 * n)(*range(1, n + 1))
-            e._check(e._lib.mld_set_clouds_estimate_planes_device(e._ctx, n, b["cloud_ptrs"], b["cloud_n"], b["stride"],
-                                                                  b["seeds"]))
-            nxt.orderAfterPlanes(e)
-            e._check(e._lib.mld_calculate_depths_device(e._ctx, n, b["uv_ptrs"], b["F"], b["depth_ptrs"], b["type_ptrs"]))
-            self.k += 1
-            return
         if self.whole and len(self.ests) > 1:
-            # every context takes its share of the step's frames, side by side
+            # (k_rs_batch - a 1024-thread block and 150 KB of LDS per frame - fits neither beside the feature kernels nor
+            # beside a projection, so alternating whole steps gains nothing here: every context takes its share of the
+            # step's frames, side by side)
             if self.est_batches is None:
                 NC, Sh = len(self.ests), self.B // len(self.ests)
                 rows = lambda t, i: [t[b] for b in range(i, i + Sh)]  # noqa: E731
@@ -854,7 +835,7 @@ def main():
     U = max(1, min(args.unique_frames, B))
     seq = sharding.assign_sequences(world, world)[rank][0]  # one sequence per rank (config 4 layout)
     res = Resident(P, cam, T, synth.HDL64, B, U, F, seq, gpu_index, slots=args.slots, contexts=args.contexts,
-                   shared_mode=args.shared_mode, pair=args.pair, est_schedule=args.est_schedule)
+                   shared_mode=args.shared_mode, pair=args.pair)
     S, N = res.S, res.N
 
     def barrier():
@@ -1017,31 +998,27 @@ def main():
     configs = {}
     if world == 1 and P.do_use_ransac_plane and not args.no_estimated:
         # the reference's default call: the plane of every frame estimated on the GPU (seeded RANSAC, batched, no host
-        # round trip) instead of supplied; checked against the restatement's estimate for two frames
+        # round trip) instead of supplied; checked against the restatement's estimate for three frames
         from oracle import oracle
-        # (k_rs_batch holds a third of a CU's LDS per block and does not fit beside the feature kernels; --est-schedule)
-        if not res.est_turn:
-            for e in res.ests:
-                e.setSharedGpu(False)
+        for e in res.ests:
+            e.setSharedGpu(False)
         loops_e, kt_e = timed_resident(res, max(2, args.steps // 2), 2, timing, 2, estimated=True)
         el_e = loops_e[0]
         for e in res.ests:
             e.setSharedGpu(res.shared_mode if len(res.ests) > 1 else 0)
         ok_e = True
-        for fr in (0, B - 1):
+        for fr in sorted({0, min(14, B - 1), B - 1}):  # (frame 14 of the synthetic sequence: most draws are skipped)
             ref = oracle.OracleDepthEstimator(P, cam_struct, T)
             ref.set_cloud(res.clouds_h[fr % U])
             ref.estimate_ground_plane((fr % res.est_S) + 1)
             d0, t0 = ref.calculate_depth(res.uvs_h[fr], 8)
-            o_e = (res.k - 1) % len(res.batches) if res.est_turn else 0  # the output set of the last step's context
-            dg, tg = res.out_depth[o_e][fr].cpu().numpy(), res.out_type[o_e][fr].cpu().numpy()
+            dg, tg = res.all_depth[fr].cpu().numpy(), res.all_type[fr].cpu().numpy()
             ok_e = ok_e and bool(np.array_equal(tg, t0) and np.allclose(dg, d0, rtol=0, atol=1e-4, equal_nan=True))
         n_e = max(2, args.steps // 2)
         estimated = {"plane": "estimated", "value": B * F * n_e / el_e, "ms_per_step": 1e3 * el_e / n_e,
                      "kernels_ms_per_launch": {k: v["avg_ms"] for k, v in kt_e.items()},
                      "ransac_us_per_frame": 1e3 * kt_e.get("k_rs_batch", {}).get("avg_ms", 0.0) / res.est_S,
-                     "frame_slots_per_launch": res.est_S, "verified": ok_e,
-                     "schedule": ("turn" if res.est_turn else "split") if len(res.ests) > 1 else "one context"}
+                     "frame_slots_per_launch": res.est_S, "verified": ok_e}
     if world == 1:
         if args.cpu_seconds > 0:
             cpu = cpu_baseline(P, cam_struct, T, res.clouds_h, res.planes_h, res.uvs_h, args.cpu_seconds)

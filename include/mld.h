@@ -183,15 +183,6 @@ int mld_synchronize(mld_ctx* ctx);
  */
 int mld_order_after(mld_ctx* ctx, mld_ctx* other);
 /*
- * mld_order_after_planes: the same, but `ctx` waits only for the end of the plane estimation (k_rs_batch) of other's
- *   last mld_set_clouds_estimate_planes_device, not for the projection queued behind it.  For the alternating schedule
- *   with ESTIMATED planes: k_rs_batch is a block per frame with ~50 KB of LDS (it does not fit beside the feature
- *   kernels, but leaves 3/4 of every CU's wavefront slots to a projection), so per pair of batches
- *     estimate(A) | project(A) beside estimate(B) | features(A) beside project(B) | features(B)
- *   Without an estimation on record it is mld_order_after.
- */
-int mld_order_after_planes(mld_ctx* ctx, mld_ctx* other);
-/*
  * mld_pair_contexts(a, b): the batched setInputCloud entry points (mld_set_clouds_*_device) of BOTH contexts run their
  *   projection on one stream created here (owned by `a`), back to back in call order, while each context's feature
  *   kernels stay on its own stream (two events per batch join them).  With the schedule above this replaces

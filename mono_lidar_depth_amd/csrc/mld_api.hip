@@ -140,11 +140,6 @@ struct mld_ctx {
     hipStream_t side = nullptr;  // the plane's inlier mask is built here while the cloud is still in flight
     hipEvent_t side_done = nullptr;
     hipEvent_t order_ev = nullptr;  // mld_order_after
-    hipEvent_t planes_ev = nullptr;  // end of the last k_rs_batch (mld_order_after_planes)
-    hipStream_t rs_stream = nullptr;  // MLD_RS_PRIORITY: k_rs_batch on a stream of the highest priority
-    hipEvent_t rs_fork = nullptr;
-    int rs_priority = 0;
-    bool planes_ev_set = false;
     // mld_pair_contexts: the batched projections of two contexts share ONE stream (back to back, no cross-stream
     // hand-over between them); each context's feature kernels stay on its own stream, joined by two events per batch
     hipStream_t proj_stream = nullptr;  // nullptr: projections run on `stream`
@@ -358,7 +353,6 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     if (const char* e = std::getenv("MLD_FORCE_THREAD_PATH")) ctx->force_thread_path = e[0] == '1';
     //   MLD_PROJ_LDS=bytes     occupancy experiments: the batched projection asks for that much (unused) LDS per block
     if (const char* e = std::getenv("MLD_PROJ_LDS")) ctx->proj_lds = (size_t)std::atoll(e);
-    if (const char* e = std::getenv("MLD_RS_PRIORITY")) ctx->rs_priority = std::atoi(e);
     if (const char* e = std::getenv("MLD_K1MAX")) c.k1max = std::min(std::max(std::atoi(e), 8), kK1MaxLimit);
     if (const char* e = std::getenv("MLD_KMAIN")) c.kMain = std::min(std::max(std::atoi(e), 8), c.k1max);
 #endif
@@ -883,9 +877,6 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->side_done) (void)hipEventDestroy(ctx->side_done);
     if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
-    if (ctx->planes_ev) (void)hipEventDestroy(ctx->planes_ev);
-    if (ctx->rs_fork) (void)hipEventDestroy(ctx->rs_fork);
-    if (ctx->rs_stream) (void)hipStreamDestroy(ctx->rs_stream);
     if (ctx->proj_stream) (void)hipStreamSynchronize(ctx->proj_stream);
     if (ctx->proj_fork) (void)hipEventDestroy(ctx->proj_fork);
     if (ctx->proj_join) (void)hipEventDestroy(ctx->proj_join);
@@ -935,20 +926,6 @@ int mld_order_after(mld_ctx* ctx, mld_ctx* other) {
     if (!ctx->order_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventRecord(ctx->order_ev, other->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->order_ev, 0));
-    return MLD_OK;
-}
-
-// ctx's next work waits for the end of other's last batched plane estimation (k_rs_batch) only - not for the projection
-// queued behind it: k_rs_batch (a block per frame, 4 wavefronts per CU) leaves most of the chip to a projection, so the
-// next context's estimation runs beside this one's projection.  Without an estimation on record: mld_order_after.
-int mld_order_after_planes(mld_ctx* ctx, mld_ctx* other) {
-    if (!ctx || !other) return MLD_ERR_INVALID_ARG;
-    if (ctx == other) return MLD_OK;
-    if (!other->planes_ev_set) return mld_order_after(ctx, other);
-    if (ctx->device != other->device) return fail(ctx, MLD_ERR_INVALID_ARG, "contexts live on different devices");
-    int rc = bind_device(ctx);
-    if (rc) return rc;
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, other->planes_ev, 0));
     return MLD_OK;
 }
 
@@ -1084,7 +1061,7 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
     const size_t n_chunks = (size_t)((max_n + 1023) / 1024);
     const size_t lds = lds_fixed + (pass ? (n_chunks + 1) * sizeof(int) + 16 * n_chunks + 16 : 0);
     if (lds > 158 * 1024) {
-        // clouds beyond ~1.5 M points with the pass-through: the per-slot estimator (ordered compaction in device
+        // clouds beyond ~0.4 M points with the pass-through: the per-slot estimator (ordered compaction in device
         // memory), which synchronises once per slot
         if ((rc = set_clouds_common(ctx, n_slots, pts_dev, n, stride_bytes, nullptr, nullptr))) return rc;
         for (int i = 0; i < n_slots; i++) {
@@ -1132,22 +1109,9 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
         s.plane_decided = true;
     }
     if ((rc = upload_descs(ctx, n_slots, st))) return rc;
-    if (!ctx->planes_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->planes_ev, hipEventDisableTiming));
-    hipStream_t rs = st;
-    if (ctx->rs_priority) {
-        if (!ctx->rs_stream) {
-            int least = 0, greatest = 0;
-            HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->rs_stream, hipStreamNonBlocking, greatest));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->rs_fork, hipEventDisableTiming));
-        }
-        rs = ctx->rs_stream;
-        HIP_TRY(ctx, hipEventRecord(ctx->rs_fork, st));
-        HIP_TRY(ctx, hipStreamWaitEvent(rs, ctx->rs_fork, 0));
-    }
     {
-        ScopedTimer tm(ctx, 4, rs);
-        hipLaunchKernelGGL(k_rs_batch, dim3((unsigned)n_slots), dim3(kRsThreads), lds, rs, ctx->d_slots, ctx->rsb_seeds,
+        ScopedTimer tm(ctx, 4, st);
+        hipLaunchKernelGGL(k_rs_batch, dim3((unsigned)n_slots), dim3(kRsThreads), lds, st, ctx->d_slots, ctx->rsb_seeds,
                            n_draws, P.ransac_plane_max_iterations, P.ransac_plane_probability,
                            P.ransac_plane_distance_treshold, P.ransac_plane_refinement_treshold,
                            P.ransac_plane_use_refinement, ctx->rsb_planes, pass ? 1 : 0, (float)P.ransac_plane_min_z,
@@ -1155,9 +1119,6 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
                            ctx->calib.roadDistThrF);
         HIP_TRY(ctx, hipGetLastError());
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->planes_ev, rs));
-    if (rs != st) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->planes_ev, 0));
-    ctx->planes_ev_set = true;
     if ((rc = launch_project(ctx, n_slots, max_n, false, 0, st))) return rc;
     return projection_join(ctx);
 }

@@ -243,11 +243,6 @@ class DepthEstimator:
         finished (device-side; mld_order_after)."""
         self._check(self._lib.mld_order_after(self._ctx, other._ctx))
 
-    def orderAfterPlanes(self, other: "DepthEstimator"):
-        """This context's next work waits only for the end of `other`'s last batched plane estimation, not for the
-        projection behind it (mld_order_after_planes)."""
-        self._check(self._lib.mld_order_after_planes(self._ctx, other._ctx))
-
     def setListCapacity(self, wide: int, narrow: int):
         """Neighbour-list capacities of the lane-per-feature kernel (mld_set_list_capacity): 32 / 24 by default, 48 / 24
         for dense (128-beam) clouds."""

@@ -1,6 +1,6 @@
 #!/bin/bash
-# the plane-estimated leg of bench.py (k_rs_batch ahead of the projection): two contexts with half a step each, one
-# context, two contexts in turn; arguments: libraries to compare ("-" = the in-tree one)
+# the plane-estimated leg of bench.py (k_rs_batch ahead of the projection): two contexts with half a step each and one
+# context; arguments: libraries to compare ("-" = the in-tree one)
 run() {
 python bench.py --steps 100 --warmup 3 --repeats 1 --cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0 $1 2>gpurun_out/est.err | python -c "
 import json,sys
@@ -9,7 +9,7 @@ print('$2 $1', 'step', round(d['ms_per_step'],4), 'estimated', round(e['ms_per_s
 }
 LIBS=${@:--}
 for r in 1 2; do
-for extra in "--est-schedule split" "--contexts 1" "--est-schedule turn"; do
+for extra in "" "--contexts 1"; do
   for lib in $LIBS; do
     if [ "$lib" = "-" ]; then unset MLD_HIP_LIBRARY; else export MLD_HIP_LIBRARY=$PWD/profiles/tools/libs/$lib.so; fi
     run "$extra" "$lib"

@@ -225,10 +225,10 @@ def test_batched_estimation_with_the_z_pass_through(min_z, max_z):
 
 @pytest.mark.gpu
 def test_estimated_planes_two_contexts_in_turn():
-    """Two contexts in turn with ESTIMATED planes (mld_order_after_planes): the next context is released by the end of
-    this one's k_rs_batch, so its estimation runs beside this projection and its projection beside these feature
-    kernels.  Six launch sets, each equal to the restatement whichever context computed it; the same slots are
-    re-estimated and re-projected while the other context's kernels are in flight."""
+    """Two contexts in turn with ESTIMATED planes (mld_order_after): the next context's estimation and projection are
+    released by the end of this one's projection and run beside these feature kernels.  Six launch sets, each equal to
+    the restatement whichever context computed it; the same slots are re-estimated and re-projected while the other
+    context's kernels are in flight."""
     import torch
     P = capi.params_c0()
     S, F, rounds = 5, 900, 3
@@ -236,8 +236,6 @@ def test_estimated_planes_two_contexts_in_turn():
     ests = [make_estimator(P, max_frames=S, max_features=F) for _ in range(2)]
     for e in ests:
         e.setSharedGpu(True)
-    # without an estimation on record the call is mld_order_after
-    ests[1].orderAfterPlanes(ests[0])
     sets = []
     for r in range(rounds * 2):
         clouds = [synth.make_cloud(synth.HDL64_KITTI if (r + b) % 2 else synth.HDL64, seed=500 + r, frame=b) for b in range(S)]
@@ -251,7 +249,7 @@ def test_estimated_planes_two_contexts_in_turn():
     for r, (clouds, uvs, seeds, tc, tu, d, t) in enumerate(sets):
         e, nxt = ests[r % 2], ests[(r + 1) % 2]
         e.setInputCloudsEstimatePlanes(tc, seeds)
-        nxt.orderAfterPlanes(e)
+        nxt.orderAfter(e)
         e.CalculateDepths(tu, d, t)
     for e in ests:
         e.synchronize()
@@ -262,8 +260,5 @@ def test_estimated_planes_two_contexts_in_turn():
             ref.estimate_ground_plane(seeds[b])
             d0, t0 = ref.calculate_depth(uvs[b])
             assert_depth_parity(d[b].cpu().numpy(), t[b].cpu().numpy(), d0, t0)
-    lib = ests[0]._lib
-    assert lib.mld_order_after_planes(ests[0]._ctx, None) == capi.MLD_ERR_INVALID_ARG
-    assert lib.mld_order_after_planes(ests[0]._ctx, ests[0]._ctx) == capi.MLD_OK
     for e in ests:
         e.close()
