@@ -423,7 +423,7 @@ constexpr int kRsMisc = 8 + 32;
         if (threadIdx.x == 0 && blockIdx.x < 4096) {                                                            \
             unsigned long long* a_ = reinterpret_cast<unsigned long long*>(misc + 8);                           \
             unsigned long long all_ = 0;                                                                        \
-            for (int i_ = 0; i_ < 15; i_++) all_ += i_ == 8 ? 0 : a_[i_];                                       \
+            for (int i_ = 0; i_ < 16; i_++) all_ += i_ == 8 ? 0 : a_[i_];                                       \
             g_rs_slot[4 * blockIdx.x + 0] = (unsigned int)all_;                                                 \
             g_rs_slot[4 * blockIdx.x + 1] = (unsigned int)wall_clock64(); /* end, absolute */                    \
             g_rs_slot[4 * blockIdx.x + 2] = (unsigned int)a_[8];                                                \
@@ -459,14 +459,15 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
     float* acc = reinterpret_cast<float*>(sidx + kSample);         // [kPartials * 9]
     // [0] inliers of the best draw, [1] inlier total, [2] pass-through candidates
     int* misc = reinterpret_cast<int*>(acc + kPartials * 9) + 2 * kRsRound;
-    // kernel arguments are otherwise fetched where they are first used, in the middle of a slot's serial phases
-    asm volatile("" ::"s"(n_draws), "s"(max_it), "s"(probability), "s"(thr), "s"(refine_thr), "s"(use_refinement), "s"(pass));
-    asm volatile("" ::"s"(lo), "s"(hi), "s"(far_elin), "s"(far_econst), "s"(far_thr));
 #ifdef MLD_DIAG_RS_PHASES
     unsigned long long t_prev = wall_clock64();
     if (threadIdx.x == 0)
         for (int i_ = 0; i_ < 16; i_++) reinterpret_cast<unsigned long long*>(misc + 8)[i_] = 0ull;
 #endif
+    // kernel arguments are otherwise fetched where they are first used, in the middle of a slot's serial phases
+    asm volatile("" ::"s"(n_draws), "s"(max_it), "s"(probability), "s"(thr), "s"(refine_thr), "s"(use_refinement), "s"(pass));
+    asm volatile("" ::"s"(lo), "s"(hi), "s"(far_elin), "s"(far_econst), "s"(far_thr));
+    RS_PHASE(15);  // (diagnostic) kernel arguments
     // "(double)distance < thr" for a float distance == "distance < thr_f" with thr_f the smallest float >= thr
     auto up = [](double t) {
         float f = (float)t;

@@ -30,8 +30,8 @@ for it in range(3):
     assert lib.mld_debug_rs_phases(out) == 0
     v = np.array(list(out), dtype=np.float64)
     print("us per block:", {n: round(v[i] / 100.0 / B, 2) for i, n in enumerate(names)},
-          "| rounds in detail:", {n: round(v[i] / 100.0 / B, 2) for i, n in ((9, "valid list"), (10, "distances"), (11, "barrier"), (1, "replay"), (14, "empty marker"), (12, "constants"), (13, "model_of"))},
-          "total", round((v[:8].sum() + v[9:14].sum()) / 100.0 / B, 2), "iterations/block", round(v[8] / B, 1),
+          "| rounds in detail:", {n: round(v[i] / 100.0 / B, 2) for i, n in ((9, "valid list"), (10, "distances"), (11, "barrier"), (1, "replay"), (14, "empty marker"), (12, "constants"), (13, "model_of"), (15, "kernel arguments"))},
+          "total", round((v[:8].sum() + v[9:16].sum()) / 100.0 / B, 2), "iterations/block", round(v[8] / B, 1),
           "")
     st = (C.c_uint * (4096 * 4))()
     assert lib.mld_debug_rs_slots(st) == 0
