@@ -262,3 +262,73 @@ def test_estimated_planes_two_contexts_in_turn():
             assert_depth_parity(d[b].cpu().numpy(), t[b].cpu().numpy(), d0, t0)
     for e in ests:
         e.close()
+
+
+def _boundary_clouds():
+    """Clouds that walk k_rs_batch's branches: samples shorter than a wavefront / not a multiple of four / exactly the
+    sample size, draws that are mostly skipped (NaN points) or never valid (a wall), duplicates, collinear points."""
+    rng = np.random.default_rng(77)
+
+    def plane(n, noise=0.02, z0=-1.7):
+        cl = np.zeros((n, 4), np.float32)
+        cl[:, 0] = rng.uniform(2, 40, n)
+        cl[:, 1] = rng.uniform(-15, 15, n)
+        cl[:, 2] = z0 + 0.01 * cl[:, 0] + rng.normal(0, noise, n)
+        return cl
+
+    clouds = [plane(n) for n in (3, 5, 63, 64, 65, 130, 257, 5999, 6000, 6001)]
+    nan_heavy = plane(20000)
+    nan_heavy[rng.random(20000) < 0.6] = np.nan  # most draws hit a NaN point and are skipped
+    wall = np.zeros((9000, 4), np.float32)  # a vertical wall: no draw gives a model within 10 degrees of horizontal
+    wall[:, 0] = 10.0 + rng.normal(0, 0.01, 9000)
+    wall[:, 1] = rng.uniform(-10, 10, 9000)
+    wall[:, 2] = rng.uniform(-2, 3, 9000)
+    dup = np.repeat(plane(40), 50, axis=0)  # every point fifty times: many degenerate triples
+    line = np.zeros((500, 4), np.float32)   # collinear points
+    line[:, 0] = np.linspace(1, 50, 500)
+    line[:, 2] = -1.7
+    weak = plane(12000, noise=0.02)         # a third of the points on the plane, the rest clutter: long runs of draws
+    clutter = rng.random(12000) < 0.67
+    weak[clutter, 2] = rng.uniform(-1.5, 4.0, clutter.sum())
+    return clouds + [nan_heavy, wall, dup, line, weak, synth.make_cloud(synth.HDL64, seed=1, frame=14)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_it,prob,z_limits", [
+    (0, 0.99, None), (1, 0.99, None), (15, 0.99, None), (16, 0.99, None), (63, 0.99, None), (64, 0.99, None),
+    (65, 0.99, None), (1023, 0.999999, None), (1087, 0.999999, None), (1088, 0.999999, None), (10000, 0.99, None),
+    (10000, 0.5, None), (3000, 0.999999999, None),
+    # the same with the z pass-through ahead of the sub-sampling (RansacPlane.cpp:57-64)
+    (64, 0.99, (-1.9, 0.5)), (1088, 0.999999, (-1.9, 0.5)), (10000, 0.99, (-1000.0, 1000.0))])
+def test_batched_estimation_boundaries(max_it, prob, z_limits):
+    """Every branch of the batched estimator against the restatement, bit for bit: draw budgets at the edges of its
+    epochs (64 draws, then 1024) and rounds (16 valid draws, then two per wavefront), stopping probabilities that end a
+    slot in the first round or keep it going for thousands of draws, samples of every raggedness, clouds whose draws
+    are skipped or never valid.  Slots the restatement cannot estimate must carry status 1."""
+    import torch
+    P = capi.params_c0().replace(ransac_plane_max_iterations=max_it, ransac_plane_probability=prob)
+    if z_limits:
+        P = P.replace(ransac_plane_min_z=z_limits[0], ransac_plane_max_z=z_limits[1])
+    clouds = _boundary_clouds()
+    B = len(clouds)
+    dev = torch.device("cuda:0")
+    est = make_estimator(P, max_frames=B, max_features=64)
+    seeds = [911 + 13 * b + max_it for b in range(B)]
+    est.setInputCloudsEstimatePlanes([torch.from_numpy(c).to(dev) for c in clouds], seeds)
+    coeffs, n_inl, status = est.getEstimatedPlanes(B)
+    n_ok = 0
+    for b in range(B):
+        ref = make_oracle(P)
+        ref.set_cloud(clouds[b])
+        try:
+            c0, inl0 = ref.estimate_ground_plane(seeds[b])
+        except RuntimeError:
+            assert status[b] == 1, (b, status[b])
+            continue
+        n_ok += 1
+        assert status[b] == 0, b
+        assert np.array_equal(coeffs[b], c0), (b, coeffs[b], c0)
+        assert n_inl[b] == inl0.size, b
+        assert np.array_equal(est.getGroundPlaneInliers(b), inl0), b
+    assert n_ok >= B - 6
+    est.close()
