@@ -405,7 +405,7 @@ __device__ inline void rs_count_inliers(const float* sx, const float* sy, const 
 #ifdef MLD_DIAG_RS_PHASES
 // diagnostic build only: time per phase of k_rs_batch (100 MHz ticks of thread 0, collected in LDS, summed over the
 // blocks at the end)
-__device__ unsigned long long g_rs_phase[16];
+__device__ unsigned long long g_rs_phase[4096 * 16];  // per block (no atomics: they would sit between a block's end and the next block's start)
 __device__ unsigned int g_rs_slot[4096 * 4];  // per slot: ticks in all, ticks of the rounds, iterations, epochs
 constexpr int kRsMisc = 8 + 32;
 #define RS_PHASE(i)                                                                     \
@@ -431,7 +431,7 @@ constexpr int kRsMisc = 8 + 32;
                                             ((__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) << 20); /* XCC_ID */ \
         }                                                                                                       \
         if (threadIdx.x == 0)                                                                                   \
-            for (int i_ = 0; i_ < 16; i_++) atomicAdd(&g_rs_phase[i_], reinterpret_cast<unsigned long long*>(misc + 8)[i_]); \
+            for (int i_ = 0; i_ < 16; i_++) g_rs_phase[16 * (blockIdx.x & 4095) + i_] = reinterpret_cast<unsigned long long*>(misc + 8)[i_]; \
     } while (0)
 #else
 constexpr int kRsMisc = 8;
@@ -1050,11 +1050,15 @@ __global__ void k_mask_from_flags(const int32_t* __restrict__ flags, long long n
 
 #ifdef MLD_DIAG_RS_PHASES
 // diagnostic build only (profiles/tools/rs_phases.sh): reads and clears the phase clocks of k_rs_batch
-extern "C" int mld_debug_rs_phases(unsigned long long* out16) {
+extern "C" int mld_debug_rs_phases(unsigned long long* out16) {  // sums over the blocks; clears
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(mld::ransac::g_rs_phase), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    unsigned long long zero[16] = {};
-    return hipMemcpyToSymbol(HIP_SYMBOL(mld::ransac::g_rs_phase), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+    static unsigned long long h[4096 * 16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(mld::ransac::g_rs_phase), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 16; i++) out16[i] = 0;
+    for (int b = 0; b < 4096; b++)
+        for (int i = 0; i < 16; i++) out16[i] += h[16 * b + i];
+    for (auto& v : h) v = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(mld::ransac::g_rs_phase), h, sizeof(h)) == hipSuccess ? 0 : -1;
 }
 extern "C" int mld_debug_rs_slots(unsigned int* out) {  // 4096 x (ticks, ticks of the rounds, iterations, epochs)
     if (hipDeviceSynchronize() != hipSuccess) return -1;

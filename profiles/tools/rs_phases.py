@@ -51,4 +51,16 @@ for it in range(3):
         gaps += [(start[i[j + 1]] - end[i[j]]) / 100 for j in range(len(i) - 1)]
     print("slots per CU min/mean/max", min(per_cu), round(float(np.mean(per_cu)), 2), max(per_cu), "| gap between a block's end and the next block's start on its CU: mean",
           round(float(np.mean(gaps)), 1), "percentiles 50/90/max", [round(float(x), 1) for x in np.percentile(gaps, [50, 90, 100])],
-          "| first starts (us after t0) 50/90/max", [round(float(x) / 100, 1) for x in np.percentile(start - t0, [25, 50, 100])])
+          "| block starts (us after the first): the 64th / 128th / 192nd / 256th / 512th", [round(float(x) / 100, 1) for x in np.sort(start - t0)[[63, 127, 191, 255, 511]]])
+    xcc = hw >> 20
+    print("per XCD: blocks", [int((xcc == x).sum()) for x in range(8)], "| last end (us after the first start)",
+          [round(float(end[xcc == x].max() - t0) / 100, 1) for x in range(8)], "| sum of block durations / 32 CUs",
+          [round(float(dur[xcc == x].sum()) / 3200, 1) for x in range(8)])
+    last_cus = sorted(set(cu.tolist()), key=lambda c: -end[cu == c].max())[:3]
+    for c in last_cus:
+        i = np.where(cu == c)[0]
+        i = i[np.argsort(start[i])]
+        print("  CU", c, "blocks (id, start, end):", [(int(j), round(float(start[j] - t0) / 100, 1), round(float(end[j] - t0) / 100, 1)) for j in i])
+    first = np.argsort(start)[:256]
+    print("the first 256 blocks: mean start per XCD (us)", [round(float((start[first][(hw[first] >> 20) == x] - t0).mean()) / 100, 1) for x in range(8)],
+          "| block ids among them: min/max", int(first.min()), int(first.max()))
