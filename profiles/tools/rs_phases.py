@@ -24,8 +24,10 @@ lib.mld_debug_rs_phases.argtypes = [C.POINTER(C.c_ulonglong)]
 lib.mld_debug_rs_slots.argtypes = [C.POINTER(C.c_uint)]
 out = (C.c_ulonglong * 16)()
 names = ["sample", "rounds", "inlier list", "partial sums", "combination", "eigenvector", "mask", "plane"]
+# every slot its own copy of its cloud, as in bench.py (16 buffers shared by 1024 slots would be served from the caches)
+batch = [clouds[b % U].clone() for b in range(B)]
 for it in range(3):
-    est.setInputCloudsEstimatePlanes([clouds[b % U] for b in range(B)], list(range(1, B + 1)))
+    est.setInputCloudsEstimatePlanes(batch, list(range(1, B + 1)))
     est.synchronize()
     assert lib.mld_debug_rs_phases(out) == 0
     v = np.array(list(out), dtype=np.float64)
@@ -52,6 +54,12 @@ for it in range(3):
     print("slots per CU min/mean/max", min(per_cu), round(float(np.mean(per_cu)), 2), max(per_cu), "| gap between a block's end and the next block's start on its CU: mean",
           round(float(np.mean(gaps)), 1), "percentiles 50/90/max", [round(float(x), 1) for x in np.percentile(gaps, [50, 90, 100])],
           "| block starts (us after the first): the 64th / 128th / 192nd / 256th / 512th", [round(float(x) / 100, 1) for x in np.sort(start - t0)[[63, 127, 191, 255, 511]]])
+    stamps = (C.c_ulonglong * 4)()
+    lib.mld_debug_rs_stamps.argtypes = [C.POINTER(C.c_ulonglong)]
+    assert lib.mld_debug_rs_stamps(stamps) == 0
+    lo = lambda v: float(v % 2**32)  # noqa: E731
+    print("stream order: stamp kernel before the launch -> first block start", round(((t0 - lo(stamps[0])) % 2**32) / 100, 1),
+          "us; last block end -> stamp kernel after the launch", round(((lo(stamps[1]) - end.max()) % 2**32) / 100, 1), "us")
     xcc = hw >> 20
     print("per XCD: blocks", [int((xcc == x).sum()) for x in range(8)], "| last end (us after the first start)",
           [round(float(end[xcc == x].max() - t0) / 100, 1) for x in range(8)], "| sum of block durations / 32 CUs",
