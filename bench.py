@@ -1007,7 +1007,7 @@ def main():
         for e in res.ests:
             e.setSharedGpu(res.shared_mode if len(res.ests) > 1 else 0)
         ok_e = True
-        for fr in sorted({0, min(14, B - 1), B - 1}):  # (frame 14 of the synthetic sequence: most draws are skipped)
+        for fr in sorted({0, min(14, B - 1), B - 1}):  # (three of the batch's 16 distinct clouds)
             ref = oracle.OracleDepthEstimator(P, cam_struct, T)
             ref.set_cloud(res.clouds_h[fr % U])
             ref.estimate_ground_plane((fr % res.est_S) + 1)

@@ -136,7 +136,6 @@ struct mld_ctx {
     size_t rsb_mask_words = 0;       // per slot
     PlaneDev* rsb_planes = nullptr;  // one per slot
     uint32_t* rsb_seeds = nullptr;
-    int* rsb_order = nullptr;  // k_rs_batch: slots by the cost of their previous estimation (k_rs_order)
     size_t rsb_lds = 0;                 // dynamic LDS the kernel has been enabled for
     hipStream_t side = nullptr;  // the plane's inlier mask is built here while the cloud is still in flight
     hipEvent_t side_done = nullptr;
@@ -873,7 +872,6 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->rsb_masks) (void)hipFree(ctx->rsb_masks);
     if (ctx->rsb_planes) (void)hipFree(ctx->rsb_planes);
     if (ctx->rsb_seeds) (void)hipFree(ctx->rsb_seeds);
-    if (ctx->rsb_order) (void)hipFree(ctx->rsb_order);
     if (ctx->fr_host) (void)hipHostFree(ctx->fr_host);
     if (ctx->fr_dev) (void)hipFree(ctx->fr_dev);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
@@ -1086,8 +1084,6 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
         if (!ctx->rsb_planes) {
             HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_planes, ctx->slots.size() * sizeof(PlaneDev)));
             HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_seeds, ctx->slots.size() * sizeof(uint32_t)));
-            HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_order, ctx->slots.size() * sizeof(int)));
-            HIP_TRY(ctx, hipMemsetAsync(ctx->rsb_planes, 0, ctx->slots.size() * sizeof(PlaneDev), ctx->stream));
         }
     }
     if (lds > ctx->rsb_lds) {
@@ -1113,19 +1109,13 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
         s.plane_decided = true;
     }
     if ((rc = upload_descs(ctx, n_slots, st))) return rc;
-    // launches of more than one block per CU: the slots that were expensive last time go first
-    const bool by_cost = n_slots > 256 && n_slots <= kRsOrderMax;
-    if (by_cost) {
-        hipLaunchKernelGGL(k_rs_order, dim3(1), dim3(1024), 0, st, ctx->rsb_planes, n_slots, ctx->rsb_order);
-        HIP_TRY(ctx, hipGetLastError());
-    }
 #ifdef MLD_DIAG_RS_PHASES
     hipLaunchKernelGGL(k_rs_stamp, dim3(1), dim3(1), 0, st, 0);
 #endif
     {
         ScopedTimer tm(ctx, 4, st);
         hipLaunchKernelGGL(k_rs_batch, dim3((unsigned)n_slots), dim3(kRsThreads), lds, st, ctx->d_slots, ctx->rsb_seeds,
-                           by_cost ? ctx->rsb_order : nullptr, n_draws, P.ransac_plane_max_iterations, P.ransac_plane_probability,
+                           n_draws, P.ransac_plane_max_iterations, P.ransac_plane_probability,
                            P.ransac_plane_distance_treshold, P.ransac_plane_refinement_treshold,
                            P.ransac_plane_use_refinement, ctx->rsb_planes, pass ? 1 : 0, (float)P.ransac_plane_min_z,
                            (float)P.ransac_plane_max_z, ctx->calib.far_elin, ctx->calib.far_econst,

@@ -78,8 +78,7 @@ struct PlaneDev {
     float coeffs[4];
     int has_plane;   // 0: the estimation failed (GroundPlane::ExceptionPclInvalid): the road fallback is off for the frame
     int status;      // 0 ok, 1 too few points / no model
-    int n_inliers, iterations, best_draw, best_count, S;
-    int draws;  // draws the estimation went through (what it cost: the next call of the slot is scheduled by it)
+    int n_inliers, iterations, best_draw, best_count, S, pad_;
     float far_mg0, far_mg1;  // margins of the projection's single-precision far test for this plane (far_margins)
 };
 

@@ -355,42 +355,6 @@ __device__ inline int select_bit(unsigned long long m, int k) {
     return __ffsll((long long)m) - 1;
 }
 
-// Slots of a batch ordered by what their previous plane estimation cost (PlaneDev::draws of the last call, whatever it
-// holds), most first: one block, bitonic sort of (cost, slot) keys in LDS.  Any content gives a permutation.
-constexpr int kRsOrderMax = 4096;
-__global__ __launch_bounds__(1024) void k_rs_order(const PlaneDev* __restrict__ planes, int n, int* __restrict__ order) {
-    __shared__ uint32_t key[kRsOrderMax];
-    int p2 = 1;
-    while (p2 < n) p2 <<= 1;
-    for (int i = threadIdx.x; i < p2; i += blockDim.x) {
-        uint32_t k = 0u;  // padding sorts last
-        if (i < n) {
-            int d = planes[i].draws;
-            d = d < 0 ? 0 : (d > 0x7FFFF ? 0x7FFFF : d);
-            k = ((uint32_t)d << 12) | (uint32_t)(kRsOrderMax - 1 - i);  // ties: lower slot first
-            k += 1u << 31;                                               // above the padding
-        }
-        key[i] = k;
-    }
-    __syncthreads();
-    for (int len = 2; len <= p2; len <<= 1)
-        for (int stride = len >> 1; stride > 0; stride >>= 1) {
-            for (int i = threadIdx.x; i < p2; i += blockDim.x) {
-                const int j = i ^ stride;
-                if (j > i) {
-                    const uint32_t a = key[i], b = key[j];
-                    const bool desc = (i & len) == 0;  // descending overall
-                    if (desc ? a < b : a > b) {
-                        key[i] = b;
-                        key[j] = a;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) order[i] = kRsOrderMax - 1 - (int)(key[i] & 0xFFFu);
-}
-
 // Inliers of NM planes among the S sample points (three coordinate arrays in LDS), by one wavefront: a lane reads four
 // consecutive points with three 16-byte LDS loads - once for all NM planes (the loop is bound by LDS bandwidth with one
 // plane per pass).  Two points per instruction (v_pk_mul_f32 / v_pk_add_f32: the same IEEE operations as plane_dist,
@@ -482,7 +446,6 @@ constexpr int kRsMisc = 8;
 // pass != 0: pcl::PassThrough on z with the float limits [lo, hi] ahead of the sub-sampling.  LDS beyond the fixed part:
 // one byte per 64 points + one int per 1024 points.
 __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restrict__ slots, const uint32_t* __restrict__ seeds,
-                                                        const int* __restrict__ order,
                                                         int n_draws, int max_it, double probability, double thr,
                                                         double refine_thr, int use_refinement, PlaneDev* out, int pass,
                                                         float lo, float hi,
@@ -517,14 +480,9 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
     const double log_probability = log(1.0 - probability);
     asm volatile("" ::"v"(log_probability));  // here, beside the first cloud reads, not where it is first used
     const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid >> 6;
-    // Workgroups go to the XCDs round-robin and, within an XCD, in order to whichever CU is free - four of these blocks
-    // per CU in a 1024-slot launch, so a slot that needs many draws (80 us instead of 45) and starts late is the
-    // launch's tail.  `order` lists the slots by the draws their previous estimation went through, most first
-    // (k_rs_order; consecutive frames of a sequence use the same slot).
-    const int slot = order ? order[blockIdx.x] : (int)blockIdx.x;
-    const SlotDesc s = slots[slot];
-    PlaneDev* pd = out + slot;
-    const uint32_t seed = seeds[slot];
+    const SlotDesc s = slots[blockIdx.x];
+    PlaneDev* pd = out + blockIdx.x;
+    const uint32_t seed = seeds[blockIdx.x];
     asm volatile("" ::"s"(s.cloud), "s"(s.inlier_mask), "s"(s.n), "s"(s.stride), "s"(seed), "s"(pd));
     long long M = s.n;
     int S = M > kSample ? kSample : (int)M;
@@ -670,7 +628,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
     // (about half) need their inliers counted, so a round hands the next VALID draws to the wavefronts: most slots are
     // decided in one round.  The stopping rule is replayed over the draws in order (skipped and invalid ones included)
     // by every thread on the same data. ----
-    int iterations = 0, best = -2147483647, best_draw = -1, draws = 0;
+    int iterations = 0, best = -2147483647, best_draw = -1;
     double k = 1.0;
     const double one_over = 1.0 / (double)S;
     bool done = false;
@@ -796,7 +754,6 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
                 }
                 next += nb;
             }
-            draws = e0 + next;
         }
         __syncthreads();  // the next epoch rewrites the models and counts
     }
@@ -953,7 +910,6 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         far_margins(coeffs, far_elin, far_econst, far_thr, pd->far_mg0, pd->far_mg1);
         pd->n_inliers = misc[1];
         pd->iterations = iterations;
-        pd->draws = draws;
         pd->best_draw = best_draw;
         pd->best_count = best;
         pd->S = S;
