@@ -443,8 +443,9 @@ constexpr int kRsMisc = 8;
 #define RS_FLUSH() do {} while (0)
 #endif
 
-// pass != 0: pcl::PassThrough on z with the float limits [lo, hi] ahead of the sub-sampling.  LDS beyond the fixed part:
-// one byte per 64 points + one int per 1024 points.
+// One block per frame slot.  pass != 0: pcl::PassThrough on z with the float limits [lo, hi] ahead of the sub-sampling
+// (LDS beyond the fixed part: one byte per 64 points + one int per 1024 points).  Where a block's time goes:
+// DESIGN.md "k_rs_batch" (more than half of it is the wait for the 6000 scattered cloud reads of the sample).
 __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restrict__ slots, const uint32_t* __restrict__ seeds,
                                                         int n_draws, int max_it, double probability, double thr,
                                                         double refine_thr, int use_refinement, PlaneDev* out, int pass,
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
                                                         float far_elin, float far_econst, float far_thr) {
     extern __shared__ __align__(16) unsigned char rs_smem[];
     // the sample as three coordinate arrays (structure of arrays): a lane reads four consecutive points with three
-    // 16-byte LDS loads in the hypothesis loop, which is what this kernel spends its time in
+    // 16-byte LDS loads in the hypothesis loop
     float* sx = reinterpret_cast<float*>(rs_smem);                 // [kSample]
     float* sy = sx + kSample;                                      // [kSample]
     float* sz = sy + kSample;                                      // [kSample]
