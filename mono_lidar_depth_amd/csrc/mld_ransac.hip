@@ -503,16 +503,31 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
     uint32_t ids[kRsPerThread];
 #pragma unroll
     for (int q = 0; q < kRsPerThread; q++) ids[q] = 0u;
-    // the sample itself: all of a thread's loads in flight at once (they are ~300 B apart: every one its own line)
+    // A cloud read: 16-byte records on a 16-byte boundary take ONE global, non-temporal 16-byte load per point (the
+    // sample's points are ~300 B apart, every one its own line that nothing else wants: three scalar loads through the
+    // flat path cost 1.17 memory requests per point and 300 us per 1024 frames, this 0.98 and 234).
+    const bool vec = (s.stride & 15) == 0 && (((size_t)s.cloud) & 15) == 0;
+    auto load_point = [](const unsigned char* rec, bool vec16, float& x, float& y, float& z) {
+        if (vec16) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 v = __builtin_nontemporal_load((const f4 __attribute__((address_space(1)))*)rec);
+            x = v.x;
+            y = v.y;
+            z = v.z;
+        } else {
+            const float* p = reinterpret_cast<const float*>(rec);
+            x = p[0];
+            y = p[1];
+            z = p[2];
+        }
+    };
+    // the sample itself: all of a thread's loads in flight at once
     auto gather_sample = [&]() {
         float px[kRsPerThread], py[kRsPerThread], pz[kRsPerThread];
 #pragma unroll
         for (int q = 0; q < kRsPerThread; q++) {
-            const float* p = reinterpret_cast<const float*>(s.cloud + (size_t)ids[q] * (size_t)s.stride);
-            const bool in = tid + q * kRsThreads < S;
-            px[q] = in ? p[0] : 0.0f;
-            py[q] = in ? p[1] : 0.0f;
-            pz[q] = in ? p[2] : 0.0f;
+            px[q] = py[q] = pz[q] = 0.0f;
+            if (tid + q * kRsThreads < S) load_point(s.cloud + (size_t)ids[q] * (size_t)s.stride, vec, px[q], py[q], pz[q]);
         }
 #pragma unroll
         for (int q = 0; q < kRsPerThread; q++) {
@@ -536,8 +551,8 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
             const long long i = (long long)g * kWave + lane;
             bool f = false;
             if (i < n) {
-                const float* p = reinterpret_cast<const float*>(s.cloud + (size_t)i * (size_t)s.stride);
-                const float x = p[0], y = p[1], z = p[2];
+                float x, y, z;
+                load_point(s.cloud + (size_t)i * (size_t)s.stride, vec, x, y, z);
                 f = isfinite(x) && isfinite(y) && isfinite(z) && !(z < lo) && !(z > hi);  // k_rs_flags
             }
             const unsigned long long m = __ballot(f);
