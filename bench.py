@@ -76,8 +76,11 @@ def parse_args():
     ap.add_argument("--verify-slots", type=int, default=16,
                     help="frames of the timed batch checked against the oracle, spread over the output sets of all contexts")
     ap.add_argument("--repeats", type=int, default=5,
-                    help="the timed loop of --steps steps runs this many times back to back; value / ms_per_step are the "
-                         "median loop, ms_per_step_min / _max the spread")
+                    help="the timed loop of --steps steps runs at least this many times back to back; value / "
+                         "ms_per_step are the median loop, ms_per_step_min / _max the spread")
+    ap.add_argument("--min-timed-seconds", type=float, default=0.5,
+                    help="the timed loop is repeated beyond --repeats until this much time has been timed in all (at "
+                         "most 64 loops): a 20-step loop is 15 ms, less than the GPU clocks take to settle")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--timing-every", type=int, default=4,
                     help="record hipEvents around the kernels of every n-th timed step (event records cost ~6 us each)")
@@ -485,9 +488,10 @@ def kernel_times(ests):
 
 
 def timed_resident(res, steps, warmup, timing, timing_every, barrier=lambda: None, estimated=False, repeats=1,
-                   reduce_max=lambda x: x):
-    """`repeats` timed loops of `steps` steps each, every loop bracketed by barrier + synchronize on both sides.  Returns
-    (per-loop elapsed seconds, each the max over ranks; kernel times averaged over the sampled steps of all loops)."""
+                   reduce_max=lambda x: x, min_timed_s=0.0):
+    """At least `repeats` timed loops of `steps` steps each (more until `min_timed_s` seconds have been timed, at most
+    64), every loop bracketed by barrier + synchronize on both sides.  Returns (per-loop elapsed seconds, each the max
+    over ranks; kernel times averaged over the sampled steps of all loops)."""
     import torch
     step = res.run_step_estimated if estimated else res.run_step
     for _ in range(warmup):
@@ -501,7 +505,8 @@ def timed_resident(res, steps, warmup, timing, timing_every, barrier=lambda: Non
             e.timingEnable(False)
     loops, local = [], []
     res.local_loops = local
-    for _ in range(max(1, repeats)):
+    # (the loop count follows the max-over-ranks times, which every rank holds: all ranks run the same number)
+    while len(loops) < max(1, repeats) or (sum(loops) < min_timed_s and len(loops) < 64):
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -844,7 +849,8 @@ def main():
 
     timing = not args.no_kernel_timing
     loops, kt = timed_resident(res, args.steps, args.warmup, timing, args.timing_every, barrier, repeats=args.repeats,
-                               reduce_max=lambda x: sharding.max_over_ranks(x, device=coll_dev))
+                               reduce_max=lambda x: sharding.max_over_ranks(x, device=coll_dev),
+                               min_timed_s=args.min_timed_seconds)
     elapsed = float(np.median(loops))  # every loop: exactly --steps steps, max over ranks
     loop_start = "idle GPU (synchronised): exactly --steps steps per loop, first projection and last feature kernels unpartnered"
     elapsed_local = float(np.median(res.local_loops)) if getattr(res, "local_loops", None) else elapsed
