@@ -445,7 +445,7 @@ constexpr int kRsMisc = 8;
 
 // One block per frame slot.  pass != 0: pcl::PassThrough on z with the float limits [lo, hi] ahead of the sub-sampling
 // (LDS beyond the fixed part: one byte per 64 points + one int per 1024 points).  Where a block's time goes:
-// DESIGN.md "k_rs_batch" (more than half of it is the wait for the 6000 scattered cloud reads of the sample).
+// DESIGN.md "k_rs_batch" (about half of it is the wait for the 6000 scattered cloud reads of the sample).
 __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restrict__ slots, const uint32_t* __restrict__ seeds,
                                                         int n_draws, int max_it, double probability, double thr,
                                                         double refine_thr, int use_refinement, PlaneDev* out, int pass,
