@@ -62,6 +62,12 @@ struct TimedLaunch {
 
 }  // namespace
 
+// The projection stream two paired contexts share (mld_pair_contexts).  Either context may be destroyed first.
+struct ProjShare {
+    hipStream_t stream = nullptr;
+    int refs = 0;
+};
+
 struct mld_ctx {
     mld_params P{};
     mld_camera cam{};
@@ -136,14 +142,13 @@ struct mld_ctx {
     size_t rsb_mask_words = 0;       // per slot
     PlaneDev* rsb_planes = nullptr;  // one per slot
     uint32_t* rsb_seeds = nullptr;
-    size_t rsb_lds = 0;                 // dynamic LDS the kernel has been enabled for
     hipStream_t side = nullptr;  // the plane's inlier mask is built here while the cloud is still in flight
     hipEvent_t side_done = nullptr;
     hipEvent_t order_ev = nullptr;  // mld_order_after
     // mld_pair_contexts: the batched projections of two contexts share ONE stream (back to back, no cross-stream
     // hand-over between them); each context's feature kernels stay on its own stream, joined by two events per batch
     hipStream_t proj_stream = nullptr;  // nullptr: projections run on `stream`
-    bool proj_owned = false;
+    struct ProjShare* proj_share = nullptr;  // the pair's stream, reference counted: the last context to go destroys it
     hipEvent_t proj_fork = nullptr, proj_join = nullptr;
     size_t lds_fused_pad = 0;       // mld_set_shared_gpu
     int shared_arg = 0;             // its last argument (re-applied when the list capacities change)
@@ -383,6 +388,37 @@ int projection_join(mld_ctx* ctx) {
     if (!ctx->proj_stream) return MLD_OK;
     HIP_TRY(ctx, hipEventRecord(ctx->proj_join, ctx->proj_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->proj_join, 0));
+    return MLD_OK;
+}
+// After a successful fork every exit joins: whatever was queued on the projection stream before an error is ordered
+// before the context's own stream again (mld_synchronize relies on it).  finish() is the normal exit and reports the
+// join's own status; the destructor covers the early returns without touching the error text of the failed call.
+struct ProjectionScope {
+    mld_ctx* ctx;
+    bool open = true;
+    explicit ProjectionScope(mld_ctx* c) : ctx(c) {}
+    int finish() {
+        open = false;
+        return projection_join(ctx);
+    }
+    ~ProjectionScope() {
+        if (open && ctx->proj_stream) {
+            const std::string keep = ctx->err;
+            (void)projection_join(ctx);
+            ctx->err = keep;
+        }
+    }
+};
+
+// The dynamic-LDS limit of k_rs_batch is an attribute of the FUNCTION on a device, not of a context: contexts with
+// clouds of different sizes share it, so the size enabled so far is kept per device (it only ever grows).
+int enable_rs_batch_lds(mld_ctx* ctx, size_t lds) {
+    static size_t enabled[64] = {};
+    size_t& cur = enabled[ctx->device & 63];
+    if (lds <= cur) return MLD_OK;
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ransac::k_rs_batch),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    cur = lds;
     return MLD_OK;
 }
 
@@ -880,7 +916,10 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->proj_stream) (void)hipStreamSynchronize(ctx->proj_stream);
     if (ctx->proj_fork) (void)hipEventDestroy(ctx->proj_fork);
     if (ctx->proj_join) (void)hipEventDestroy(ctx->proj_join);
-    if (ctx->proj_stream && ctx->proj_owned) (void)hipStreamDestroy(ctx->proj_stream);
+    if (ctx->proj_share && --ctx->proj_share->refs == 0) {  // the partner is gone already (or never came to be)
+        (void)hipStreamDestroy(ctx->proj_share->stream);
+        delete ctx->proj_share;
+    }
     for (TimedLaunch& t : ctx->timed) {
         (void)hipEventDestroy(t.e0);
         (void)hipEventDestroy(t.e1);
@@ -907,9 +946,17 @@ int mld_pair_contexts(mld_ctx* a, mld_ctx* b) {
     if (a->proj_stream || b->proj_stream) return fail(a, MLD_ERR_INVALID_ARG, "context already paired");
     int rc = bind_device(a);
     if (rc) return rc;
-    HIP_TRY(a, hipStreamCreateWithFlags(&a->proj_stream, hipStreamNonBlocking));
-    a->proj_owned = true;
-    b->proj_stream = a->proj_stream;
+    ProjShare* sh = new ProjShare();
+    hipError_t e = hipStreamCreateWithFlags(&sh->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete sh;
+        return fail(a, MLD_ERR_HIP, std::string("hipStreamCreate(projection stream): ") + hipGetErrorString(e));
+    }
+    for (mld_ctx* c : {a, b}) {  // (the stream is reference counted: the contexts may be destroyed in any order)
+        c->proj_share = sh;
+        c->proj_stream = sh->stream;
+        sh->refs++;
+    }
     for (mld_ctx* c : {a, b}) {
         HIP_TRY(c, hipEventCreateWithFlags(&c->proj_fork, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&c->proj_join, hipEventDisableTiming));
@@ -934,9 +981,13 @@ int mld_set_shared_gpu(mld_ctx* ctx, int shared) {
     // k_feature_fused is capped by its LDS request: 14 KB per wavefront -> 11 per CU (3 per SIMD, which is all the
     // VGPRs there are at 168 per wave); 20 KB -> 8 per CU, 2 per SIMD, and a third of the register file stays free
     // for the projection wavefronts (48 VGPRs each) of a context running beside this one.
-    ctx->shared_arg = shared;
     int blocks = (shared >> 8) & 0xFF;  // bits 8..15: wavefronts per CU (0 = the default, 8)
     if (blocks <= 0) blocks = 8;
+    // 4..16 wavefronts per CU: fewer would ask for more dynamic LDS per one-wave block (53 KB and up) than the kernel
+    // is enabled for, more than 16 cannot be reached at its register count anyway
+    if (blocks < 4 || blocks > 16 || (shared & ~0xFF01) != 0)
+        return fail(ctx, MLD_ERR_INVALID_ARG, "mld_set_shared_gpu: bit 0 = on, bits 8..15 = wavefronts per CU (0 or 4..16)");
+    ctx->shared_arg = shared;
     ctx->fused_blocks_per_cu = blocks;
     const size_t per_cu = ctx->lds_per_cu ? ctx->lds_per_cu : 160 * 1024, want = (per_cu / (size_t)blocks) & ~(size_t)255;
     ctx->lds_fused_pad = ((shared & 1) && ctx->lds_fused < want) ? want - ctx->lds_fused : 0;
@@ -995,6 +1046,7 @@ static int set_clouds_common(mld_ctx* ctx, int n_slots, const void* const* pts_d
     int64_t max_n = 0;
     hipStream_t st = projection_fork(ctx, rc);
     if (rc) return rc;
+    ProjectionScope joined(ctx);
     // the slots' occupancy bitmaps are contiguous: one fill for the whole batch
     HIP_TRY(ctx, hipMemsetAsync(ctx->bitmaps + (size_t)first * ctx->bitmap_words, 0,
                                 ctx->bitmap_words * (size_t)n_slots * sizeof(uint32_t), st));
@@ -1012,7 +1064,7 @@ static int set_clouds_common(mld_ctx* ctx, int n_slots, const void* const* pts_d
     }
     if ((rc = upload_descs(ctx, n_slots, st, first))) return rc;
     if ((rc = launch_project(ctx, n_slots, max_n, false, first, st))) return rc;
-    return projection_join(ctx);
+    return joined.finish();
 }
 
 int mld_set_clouds_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev, const int64_t* n, int stride_bytes) {
@@ -1086,13 +1138,10 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
             HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_seeds, ctx->slots.size() * sizeof(uint32_t)));
         }
     }
-    if (lds > ctx->rsb_lds) {
-        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_batch),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ctx->rsb_lds = lds;
-    }
+    if ((rc = enable_rs_batch_lds(ctx, lds))) return rc;
     hipStream_t st = projection_fork(ctx, rc);
     if (rc) return rc;
+    ProjectionScope joined(ctx);
     // occupancy bitmaps and inlier masks of the batch: one fill each
     HIP_TRY(ctx, hipMemsetAsync(ctx->bitmaps, 0, ctx->bitmap_words * (size_t)n_slots * sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->rsb_masks, 0, ctx->rsb_mask_words * (size_t)n_slots * sizeof(uint32_t), st));
@@ -1109,9 +1158,7 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
         s.plane_decided = true;
     }
     if ((rc = upload_descs(ctx, n_slots, st))) return rc;
-#ifdef MLD_DIAG_RS_PHASES
-    hipLaunchKernelGGL(k_rs_stamp, dim3(1), dim3(1), 0, st, 0);
-#endif
+    RS_STAMP_LAUNCH(st, 0);
     {
         ScopedTimer tm(ctx, 4, st);
         hipLaunchKernelGGL(k_rs_batch, dim3((unsigned)n_slots), dim3(kRsThreads), lds, st, ctx->d_slots, ctx->rsb_seeds,
@@ -1122,11 +1169,9 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
                            ctx->calib.roadDistThrF);
         HIP_TRY(ctx, hipGetLastError());
     }
-#ifdef MLD_DIAG_RS_PHASES
-    hipLaunchKernelGGL(k_rs_stamp, dim3(1), dim3(1), 0, st, 1);
-#endif
+    RS_STAMP_LAUNCH(st, 1);
     if ((rc = launch_project(ctx, n_slots, max_n, false, 0, st))) return rc;
-    return projection_join(ctx);
+    return joined.finish();
 }
 
 // The planes of the last mld_set_clouds_estimate_planes_device: coefficients (n_slots x 4), inlier counts and status
@@ -2082,15 +2127,6 @@ int mld_kernel_time_ms(mld_ctx* ctx, int which, double* avg_ms, int64_t* launche
 
 }  // extern "C"
 
-#ifdef MLD_STAMPS
-// Diagnostic build only: read and clear the per-wave phase stamps of the feature kernels (2 x 32768 x 16 uint32).
-extern "C" int mld_debug_read_stamps(unsigned* out) {
-    const size_t bytes = sizeof(unsigned) * 2 * mld::kStampWaves * 16;
-    hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpyFromSymbol(out, HIP_SYMBOL(mld::g_stamps), bytes);
-    void* sym = nullptr;
-    if (e == hipSuccess) e = hipGetSymbolAddress(&sym, HIP_SYMBOL(mld::g_stamps));
-    if (e == hipSuccess) e = hipMemset(sym, 0, bytes);
-    return e == hipSuccess ? 0 : -7;
-}
-#endif
+// read-back entry points of the diagnostic builds' instrumentation (nothing in the product build)
+#define MLD_DIAG_HOST_PART
+#include "mld_diag.h"

@@ -116,7 +116,7 @@ struct SlotDesc {
     double prior_off;
     float coeffs[4];              // plane a,b,c,d (lidar frame)
     int stride;
-    uint32_t tag;  // current map tag, 1..255
+    uint32_t tag;  // current map tag, 1..kMaxTag (127)
     int has_plane;
     int mask_in_key;  // 1: the inlier / far flags of every map key are valid (the plane was known when the cloud was projected)
     float far_mg0, far_mg1;  // margins of the projection's single-precision far test for `coeffs` (far_margins)

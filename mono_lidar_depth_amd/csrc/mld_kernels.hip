@@ -25,6 +25,7 @@
 // camera-frame copy of the cloud is ever written.
 #include "mld_device.h"
 #include "../../include/mld.h"
+#include "mld_diag.h"  // instrumentation of the diagnostic builds; every macro is empty in the product build
 
 namespace mld {
 
@@ -34,50 +35,6 @@ namespace mld {
 #define GPTRW(T, p) ((T __attribute__((address_space(1)))*)(p))
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
-
-// Diagnostic build only (-DMLD_STAMPS, profiles/tools): s_memtime stamps around the phases of the feature kernels,
-// summed over all wavefronts into g_stamps[kernel][phase].  The product build compiles none of this.
-#ifdef MLD_STAMPS
-constexpr int kStampWaves = 32768;  // per-wave slots (no atomics: contended adds would distort what they measure)
-__device__ unsigned g_stamps[2][kStampWaves][16];
-struct Stamps {
-    unsigned long long last;
-    unsigned acc[16];
-    int kern;
-    __device__ __forceinline__ void begin(int k) {
-        kern = k;
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc[i] = 0;
-        last = __builtin_amdgcn_s_memtime();
-    }
-    __device__ __forceinline__ void mark(int i) {
-        __builtin_amdgcn_sched_barrier(0);
-        const unsigned long long t = __builtin_amdgcn_s_memtime();
-        acc[i] += (unsigned)(t - last);
-        last = t;
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    __device__ __forceinline__ void flush() {
-        const unsigned w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        if ((threadIdx.x & 63) == 0 && kern < 2 && w < (unsigned)kStampWaves) {
-#pragma unroll
-            for (int i = 0; i < 15; i++) g_stamps[kern][w][i] += acc[i];
-            g_stamps[kern][w][15] += 1u;
-        }
-    }
-};
-#define ST_ARG , Stamps& st
-#define ST_PASS , st
-#define ST_MARK(i) st.mark(i)
-#define ST_USE_F64(x) asm volatile("" ::"v"(x))
-#define ST_USE_U32(x) asm volatile("" ::"v"(x))
-#else
-#define ST_ARG
-#define ST_PASS
-#define ST_MARK(i)
-#define ST_USE_F64(x)
-#define ST_USE_U32(x)
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
@@ -1437,9 +1394,7 @@ struct RawP {
     float x, y, z;
 };
 __device__ __forceinline__ RawP load_raw(const SlotDesc& s, uint32_t i) {
-#ifdef MLD_DIAG_NO_POINTS  // diagnostic build only (profiles/tools): no cloud gathers - wrong results, same instruction stream
-    return RawP{5.0f + (float)(i & 1023u) * 0.01f, (float)(i & 63u) * 0.05f - 1.6f, -1.7f + (float)(i & 7u) * 0.01f};
-#endif
+    MLD_DIAG_FAKE_POINT(i);
     const unsigned char* p = s.cloud + (size_t)i * (size_t)s.stride;
     RawP r;
     if ((((size_t)s.cloud) & 15) == 0) {
@@ -2150,10 +2105,7 @@ __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restri
         const unsigned long long full = __ballot(active && code < 0);
         double corners[9];
         bool has_corners = false;
-#ifdef MLD_STAMPS
-        Stamps st;
-        st.begin(1);
-#endif
+        ST_BEGIN(1);
         wave_path(c, s, smem, lane, all, myu, myv, mytype, mydepth, full, corners, has_corners ST_PASS);
         if (active) {
             GPTRW(double, s.depth)[f] = mydepth;
@@ -2163,10 +2115,8 @@ __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restri
                 for (int t = 0; t < 9; t++) GPTRW(double, s.corners)[9 * f + t] = corners[t];
             }
         }
-#ifdef MLD_STAMPS
-        st.mark(12);
-        st.flush();
-#endif
+        ST_MARK(12);
+        ST_END();
     }
 }
 
@@ -2504,12 +2454,7 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDes
 #pragma unroll
         for (int q = 0; q < kKeyBatchF; q++) cell[q] = (e0 + q < kk) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
 #pragma unroll
-#ifdef MLD_DIAG_NO_KEYS  // diagnostic build only: no key gathers
-        for (int q = 0; q < kKeyBatchF; q++) key[q] = make_key(s.tag, (cell[q] * 2654435761u) >> 15, 1u);
-        (void)mp;
-#else
-        for (int q = 0; q < kKeyBatchF; q++) key[q] = (e0 + q < kk) ? mp[cell[q] & 0x7FFFFFFFu] : 0u;
-#endif
+        for (int q = 0; q < kKeyBatchF; q++) key[q] = (e0 + q < kk) ? MLD_DIAG_KEY(mp[cell[q] & 0x7FFFFFFFu], s.tag, cell[q]) : 0u;
 #pragma unroll
         for (int q = 0; q < kKeyBatchF; q++)
             if (e0 + q < kk) LST(e0 + q) = key_index(key[q]) | ((key[q] & 3u) << kEntStateShift) | (cell[q] & kEntNarrow);
@@ -2539,10 +2484,7 @@ __global__ __launch_bounds__(kWave, MLD_FUSED_WAVES) void k_feature_fused(const 
         const int count = *GPTR(int32_t, s.live_count);
         const int e0 = j * kWave;
         if (e0 >= count) continue;
-#ifdef MLD_STAMPS
-        Stamps st;
-        st.begin(0);
-#endif
+        ST_BEGIN(0);
         const int lane = threadIdx.x;
         const bool active = e0 + lane < count;
         uint32_t* lst = reinterpret_cast<uint32_t*>(smem);  // wide list
@@ -2635,9 +2577,7 @@ __global__ __launch_bounds__(kWave, MLD_FUSED_WAVES) void k_feature_fused(const 
             if (s.type) GPTRW(int32_t, s.type)[f] = mytype;
         }
         ST_MARK(12);
-#ifdef MLD_STAMPS
-        st.flush();
-#endif
+        ST_END();
     }
 }
 

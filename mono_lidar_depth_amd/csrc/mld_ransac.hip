@@ -402,47 +402,6 @@ __device__ inline void rs_count_inliers(const float* sx, const float* sy, const 
     }
 }
 
-#ifdef MLD_DIAG_RS_PHASES
-// diagnostic build only: time per phase of k_rs_batch (100 MHz ticks of thread 0, collected in LDS, summed over the
-// blocks at the end)
-__device__ unsigned long long g_rs_phase[4096 * 16];  // per block (no atomics: they would sit between a block's end and the next block's start)
-__device__ unsigned long long g_rs_stamp[4];  // wall clock just before / after the launch (k_rs_stamp), in stream order
-__global__ void k_rs_stamp(int i) { g_rs_stamp[i] = wall_clock64(); }
-__device__ unsigned int g_rs_slot[4096 * 4];  // per slot: ticks in all, ticks of the rounds, iterations, epochs
-constexpr int kRsMisc = 8 + 32;
-#define RS_PHASE(i)                                                                     \
-    do {                                                                                \
-        if (threadIdx.x == 0) {                                                         \
-            const unsigned long long t_now = wall_clock64();                            \
-            reinterpret_cast<unsigned long long*>(misc + 8)[i] += t_now - t_prev;       \
-            t_prev = t_now;                                                             \
-        }                                                                               \
-    } while (0)
-#define RS_COUNT(i, v) reinterpret_cast<unsigned long long*>(misc + 8)[i] += (unsigned long long)(v)
-#define RS_PIN(x) asm volatile("" ::"v"(x))  /* the value is computed before the next marker */
-#define RS_FLUSH()                                                                                              \
-    do {                                                                                                        \
-        if (threadIdx.x == 0 && blockIdx.x < 4096) {                                                            \
-            unsigned long long* a_ = reinterpret_cast<unsigned long long*>(misc + 8);                           \
-            unsigned long long all_ = 0;                                                                        \
-            for (int i_ = 0; i_ < 16; i_++) all_ += i_ == 8 ? 0 : a_[i_];                                       \
-            g_rs_slot[4 * blockIdx.x + 0] = (unsigned int)all_;                                                 \
-            g_rs_slot[4 * blockIdx.x + 1] = (unsigned int)wall_clock64(); /* end, absolute */                    \
-            g_rs_slot[4 * blockIdx.x + 2] = (unsigned int)a_[8];                                                \
-            g_rs_slot[4 * blockIdx.x + 3] = (__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xFFFFF) | /* HW_ID */ \
-                                            ((__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xF) << 20); /* XCC_ID */ \
-        }                                                                                                       \
-        if (threadIdx.x == 0)                                                                                   \
-            for (int i_ = 0; i_ < 16; i_++) g_rs_phase[16 * (blockIdx.x & 4095) + i_] = reinterpret_cast<unsigned long long*>(misc + 8)[i_]; \
-    } while (0)
-#else
-constexpr int kRsMisc = 8;
-#define RS_PHASE(i) do {} while (0)
-#define RS_COUNT(i, v) do {} while (0)
-#define RS_PIN(x) do {} while (0)
-#define RS_FLUSH() do {} while (0)
-#endif
-
 // One block per frame slot.  pass != 0: pcl::PassThrough on z with the float limits [lo, hi] ahead of the sub-sampling
 // (LDS beyond the fixed part: one byte per 64 points + one int per 1024 points).  Where a block's time goes:
 // DESIGN.md "k_rs_batch" (about half of it is the wait for the 6000 scattered cloud reads of the sample).
@@ -462,11 +421,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
     float* acc = reinterpret_cast<float*>(sidx + kSample);         // [kPartials * 9]
     // [0] inliers of the best draw, [1] inlier total, [2] pass-through candidates
     int* misc = reinterpret_cast<int*>(acc + kPartials * 9) + 2 * kRsRound;
-#ifdef MLD_DIAG_RS_PHASES
-    unsigned long long t_prev = wall_clock64();
-    if (threadIdx.x == 0)
-        for (int i_ = 0; i_ < 16; i_++) reinterpret_cast<unsigned long long*>(misc + 8)[i_] = 0ull;
-#endif
+    RS_BEGIN();
     // kernel arguments are otherwise fetched where they are first used, in the middle of a slot's serial phases
     asm volatile("" ::"s"(n_draws), "s"(max_it), "s"(probability), "s"(thr), "s"(refine_thr), "s"(use_refinement), "s"(pass));
     asm volatile("" ::"s"(lo), "s"(hi), "s"(far_elin), "s"(far_econst), "s"(far_thr));
@@ -1066,24 +1021,3 @@ __global__ void k_mask_from_flags(const int32_t* __restrict__ flags, long long n
 }  // namespace ransac
 }  // namespace mld
 
-#ifdef MLD_DIAG_RS_PHASES
-// diagnostic build only (profiles/tools/rs_phases.sh): reads and clears the phase clocks of k_rs_batch
-extern "C" int mld_debug_rs_phases(unsigned long long* out16) {  // sums over the blocks; clears
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    static unsigned long long h[4096 * 16];
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(mld::ransac::g_rs_phase), sizeof(h)) != hipSuccess) return -1;
-    for (int i = 0; i < 16; i++) out16[i] = 0;
-    for (int b = 0; b < 4096; b++)
-        for (int i = 0; i < 16; i++) out16[i] += h[16 * b + i];
-    for (auto& v : h) v = 0;
-    return hipMemcpyToSymbol(HIP_SYMBOL(mld::ransac::g_rs_phase), h, sizeof(h)) == hipSuccess ? 0 : -1;
-}
-extern "C" int mld_debug_rs_stamps(unsigned long long* out4) {
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(mld::ransac::g_rs_stamp), 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
-}
-extern "C" int mld_debug_rs_slots(unsigned int* out) {  // 4096 x (ticks, ticks of the rounds, iterations, epochs)
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mld::ransac::g_rs_slot), 4096 * 4 * sizeof(unsigned int)) == hipSuccess ? 0 : -1;
-}
-#endif

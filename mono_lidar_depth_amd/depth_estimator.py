@@ -249,10 +249,10 @@ class DepthEstimator:
         self._check(self._lib.mld_set_list_capacity(self._ctx, int(wide), int(narrow)))
 
     def pairWith(self, other: "DepthEstimator"):
-        """The batched projections of this context and `other` run back to back on one stream (owned by this context),
-        each context's feature kernels on its own (mld_pair_contexts).  Close `other` first."""
+        """The batched projections of this context and `other` run back to back on one stream (shared, reference
+        counted: either context may be closed first), each context's feature kernels on its own (mld_pair_contexts)."""
         self._check(self._lib.mld_pair_contexts(self._ctx, other._ctx))
-        self._paired = other._paired = True
+        self._pair, other._pair = other, self
 
     def setSharedGpu(self, shared: bool = True):
         """This context alternates with another one on the same GPU (see `runBatchesAlternating`): its feature kernel
@@ -370,8 +370,9 @@ class DepthEstimator:
 
     def featuresBatchBeside(self, b, nxt: "DepthEstimator"):
         """CalculateDepth of a prepared batch whose projection is already queued; the NEXT context's projection is
-        released first (unless the two are paired: their projections are in call order on the shared stream)."""
-        if nxt is not self and not getattr(self, "_paired", False):
+        released first (unless `nxt` is this context's pair partner: their projections are in call order on the shared
+        stream; any other context - three or more in rotation - still needs the hand-over)."""
+        if nxt is not self and getattr(self, "_pair", None) is not nxt:
             nxt.orderAfter(self)
         self._check(self._lib.mld_calculate_depths_device(self._ctx, b["n"], b["uv_ptrs"], b["F"], b["depth_ptrs"],
                                                           b["type_ptrs"]))

@@ -63,7 +63,7 @@ def test_tracklets_without_tracks():
 
 
 def test_tag_wraparound_in_the_batched_path():
-    """More than 255 batched setInputCloud calls: the per-batch tag (passed as a kernel argument) wraps and every
+    """More than 127 (kMaxTag) batched setInputCloud calls: the per-batch tag (passed as a kernel argument) wraps and every
     slot's map is re-zeroed; results after the wrap equal the oracle."""
     import torch
     P = capi.params_c0()

@@ -66,7 +66,7 @@ def test_pcl_stride_and_repeat_calls():
 
 
 def test_tag_wraparound():
-    """More than 255 setInputCloud calls on one slot: the map tag wraps and the map is re-zeroed."""
+    """More than 127 (kMaxTag) setInputCloud calls on one slot: the map tag wraps and the map is re-zeroed."""
     P = capi.params_c0()
     sc = synth.Scanner(16, 360, 2.0, -24.9)
     est = make_estimator(P)
