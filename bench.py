@@ -34,6 +34,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0  # same table: what a float4 copy reaches on this part (79 % of the spec)
 K_PROJECT, K_FUSED, K_WAVE, K_RANSAC, K_CLASSIFY = 0, 1, 3, 4, 5  # mld_kernel_time_ms ids (include/mld.h)
 
 
@@ -73,8 +74,10 @@ def parse_args():
                     help="resident frames of the config-3 leg / sequence length of the config-5 leg (0 = skip both)")
     ap.add_argument("--only-config", type=int, default=0, choices=[0, 3, 5],
                     help="run only that BASELINE config's leg and print its object (for per-config rocprofv3 runs)")
-    ap.add_argument("--verify-slots", type=int, default=16,
-                    help="frames of the timed batch checked against the oracle, spread over the output sets of all contexts")
+    ap.add_argument("--verify-slots", type=int, default=-1,
+                    help="frames of the timed batch checked against the oracle: -1 (default) = EVERY frame of every "
+                         "context's output set (a few seconds: the oracle sets each distinct cloud once); n > 0 = n frames "
+                         "spread over the output sets; 0 = no check")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed loop of --steps steps runs at least this many times back to back; value / "
                          "ms_per_step are the median loop, ms_per_step_min / _max the spread")
@@ -406,33 +409,68 @@ class Resident:
         for e in reversed(self.ests):  # a pair's borrower before the owner of the projection stream
             e.close()
 
-    def verify(self, n_slots):
-        """Frames of the timed batch against the CPU oracle (checker only, outside every timed region): result types
-        identical, depths bit-exact on the main path and within 1e-4 m on the road path.  The picks are spread over the
-        output sets of all contexts (each holds the last step that context ran).  Returns (ok, report)."""
+    def poison_left(self, sets=None):
+        """Device-side scan of the output sets (all, or the listed ones) for entries the timed region did not rewrite
+        (poison(): type -77, depth NaN).  A result type is written with every depth, so a surviving -77 is a feature
+        nobody processed."""
+        import torch
+        left = {"type_minus77": 0, "nan_depth": 0}
+        for o, (d, t) in enumerate(zip(self.out_depth, self.out_type)):
+            if sets is not None and o not in sets:
+                continue
+            left["type_minus77"] += int((t == -77).sum().item())
+            left["nan_depth"] += int(torch.isnan(d).sum().item())
+        return left
+
+    def verify(self, n_slots=-1):
+        """The timed batch against the CPU oracle (checker only, outside every timed region): result types identical,
+        depths bit-exact on the main path and within 1e-4 m on the road path.  n_slots < 0: every frame of every output
+        set (each context's set holds the last step that context ran); n_slots > 0: that many frames spread over the sets.
+        The frames are grouped by their cloud, so the oracle's serial stage A runs once per distinct cloud.
+        Returns (ok, report)."""
         from oracle import oracle
         ref = oracle.OracleDepthEstimator(self.P, self.cam.as_struct(), self.T)
         n_out = len(self.out_depth)
-        per = max(1, (n_slots + n_out - 1) // n_out)
-        worst, bad, checked = 0.0, [], []
+        worst, bad, picks_all = 0.0, [], []
         for o in range(n_out):
-            lo = (self.B * o) // (2 * n_out) if n_out > 1 else 0  # different frames per output set
-            picks = sorted({int(x) for x in np.linspace(lo, self.B - 1, per)})
-            for fr in picks:
-                ref.set_cloud(self.clouds_h[fr % self.U])
-                ref.set_ground_plane(*self.planes_h[fr % self.U])
-                d0, t0 = ref.calculate_depth(self.uvs_h[fr], 8)
-                d, t = self.out_depth[o][fr].cpu().numpy(), self.out_type[o][fr].cpu().numpy()
+            if n_slots < 0:
+                picks = list(range(self.B))
+            else:
+                per = max(1, (n_slots + n_out - 1) // n_out)
+                lo = (self.B * o) // (2 * n_out) if n_out > 1 else 0  # different frames per output set
+                picks = sorted({int(x) for x in np.linspace(lo, self.B - 1, per)})
+            picks_all.append(picks)
+        host = [(d.cpu().numpy(), t.cpu().numpy()) for d, t in zip(self.out_depth, self.out_type)]
+        t_begin = time.perf_counter()
+        n_checked = 0
+        for u in range(self.U):
+            todo = [(o, fr) for o in range(n_out) for fr in picks_all[o] if fr % self.U == u]
+            if not todo:
+                continue
+            ref.set_cloud(self.clouds_h[u])
+            ref.set_ground_plane(*self.planes_h[u])
+            cache = {}
+            for o, fr in todo:
+                if fr not in cache:
+                    cache[fr] = ref.calculate_depth(self.uvs_h[fr], 8)
+                d0, t0 = cache[fr]
+                d, t = host[o][0][fr], host[o][1][fr]
                 same_t = np.array_equal(t, t0)
                 diff = np.abs(np.nan_to_num(d, nan=-7.0) - np.nan_to_num(d0, nan=-7.0))
                 main = t0 != 16
                 ok = same_t and diff.max(initial=0.0) <= 1e-4 and np.array_equal(d[main], d0[main], equal_nan=True)
                 worst = max(worst, float(diff.max(initial=0.0)))
-                checked.append([o, fr])
+                n_checked += 1
                 if not ok:
                     bad.append([o, fr])
-        return (not bad), {"frames_checked": checked, "output_sets": n_out, "max_abs_depth_diff_m": worst,
-                           "mismatching_frames": bad}
+        left = self.poison_left()
+        ok_all = (not bad) and left["type_minus77"] == 0
+        rep = {"frames_checked": n_checked, "frames_per_output_set": [len(p) for p in picks_all], "output_sets": n_out,
+               "all_frames": bool(n_slots < 0), "max_abs_depth_diff_m": worst, "mismatching_frames": bad[:64],
+               "mismatching_count": len(bad), "poison_left": left, "oracle_seconds": time.perf_counter() - t_begin}
+        if n_slots >= 0:
+            rep["frames"] = [[o, fr] for o in range(n_out) for fr in picks_all[o]]
+        return ok_all, rep
 
 
 def design_bytes_project(cloud, cam, T, inl):
@@ -857,14 +895,14 @@ def main():
     units = sharding.sum_over_ranks(float(B * F * args.steps), device=coll_dev)
 
     # ---- the timed batch against the oracle (every rank checks its own sequence) ---------------------------
-    verified, vrep = res.verify(args.verify_slots) if args.verify_slots > 0 else (None, {})
+    verified, vrep = res.verify(args.verify_slots) if args.verify_slots != 0 else (None, {})
     n_bad = sharding.sum_over_ranks(0.0 if verified in (True, None) else 1.0, device=coll_dev)
     per_rank_value = sharding.gather_over_ranks(B * F * args.steps / elapsed_local, device=coll_dev)
     distributed = None
     streaming_ranks = None
     if world > 1:
         distributed = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                       "ranks_verified": int(world - n_bad) if args.verify_slots > 0 else 0,
+                       "ranks_verified": int(world - n_bad) if args.verify_slots != 0 else 0,
                        "resident_associations_per_s_per_rank": {"min": min(per_rank_value), "max": max(per_rank_value)}}
         if args.streaming_batches > 0:
             # BASELINE config 4 as written: every rank STREAMS its own sequence from pinned host memory (PCIe-inclusive)
@@ -881,7 +919,7 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         sys.exit(0 if verified in (True, None) else 1)
-    if args.verify_slots > 0:
+    if args.verify_slots != 0:
         verified = n_bad == 0
 
     est = res.ests[0]
@@ -898,8 +936,9 @@ def main():
         est.timingEnable(False)
     # ---- byte counts (sampled slots, outside the timed region) --------------------------------------------
     type_hist = np.zeros(capi.MLD_RESULT_TYPE_COUNT, dtype=np.int64)
-    for b in range(B):
-        type_hist += est.resultHistogram(res.all_type[b])
+    for t_set in res.out_type:  # every context's output set (a poisoned -77 entry would fall outside the histogram)
+        type_hist += est.resultHistogram(t_set.reshape(-1))
+    type_hist_sets = len(res.out_type)
     stat_slots = list(range(0, S, max(1, S // 4)))[:4]
     stats, design = [], []
     last_est = res.last_context()
@@ -999,6 +1038,33 @@ def main():
         "whole_step_formula_GBps": ((formula_project + formula_feature) * (B // S) * args.steps / elapsed) / 1e9,
         "whole_step_design_GBps": (design_project * (B // S) * args.steps / elapsed) / 1e9,
     }
+    # The step as a whole, stated physically.  SURVEY 8(d)'s per-unit formula exceeds the 8 TB/s peak for this design
+    # (whole_step_formula_GBps) because it charges a per-frame map clear and a 24 B/point camera-frame copy that tagged map
+    # keys and re-derived neighbours make unnecessary - saved work (maps / _pointIndex / depths equal the oracle's), not
+    # skipped work.  What the step physically moves: the HBM bytes the PMC counters saw for its kernels (committed profile,
+    # profiles/traffic.json) and, as the floor, the compulsory bytes (every cloud read once).
+    step_s = elapsed / args.steps
+    sets_per_step = B // S
+    counter_bytes = None
+    if tj:
+        scale = float(S) / float(tj["frames_per_launch"])
+        counter_bytes = sum(float(tj[k]["hbm_bytes_per_launch"]) for k in
+                            ("k_project_scatter", "k_classify", "k_feature_fused", "k_feature_wave") if k in tj) * scale * sets_per_step
+    compulsory = 16.0 * N * B
+    roofline["whole_step"] = {
+        "counter_bytes": counter_bytes,
+        "compulsory_bytes": compulsory,
+        "step_ms": 1e3 * step_s,
+        "frac_of_peak": (counter_bytes / step_s / 1e9 / HBM_PEAK_GBS) if counter_bytes else None,
+        "frac_of_copy_rate": (counter_bytes / step_s / 1e9 / HBM_COPY_GBS) if counter_bytes else None,
+        "compulsory_frac_of_peak": compulsory / step_s / 1e9 / HBM_PEAK_GBS,
+        "compulsory_frac_of_copy_rate": compulsory / step_s / 1e9 / HBM_COPY_GBS,
+        "copy_rate_GBps": HBM_COPY_GBS,
+        "counter_source": (tj or {}).get("source", None),
+        "formula_note": "SURVEY 8(d)'s formula (whole_step_formula_GBps) exceeds the HBM peak for this design: it charges a "
+                        "map clear and a camera-frame copy that are never performed; this object prices the step on "
+                        "counter bytes (committed PMC profile) and on compulsory bytes (each cloud read once)",
+    }
 
     cpu = latency = streaming = estimated = None
     configs = {}
@@ -1013,7 +1079,11 @@ def main():
         for e in res.ests:
             e.setSharedGpu(res.shared_mode if len(res.ests) > 1 else 0)
         ok_e = True
-        for fr in sorted({0, min(14, B - 1), B - 1}):  # (three of the batch's 16 distinct clouds)
+        # sixteen frames, one of every distinct cloud of the batch (frame 14 is the one whose draws are mostly skipped)
+        est_frames = sorted({min(B - 1, k * max(1, B // 16) + (k % U)) for k in range(16)} | {min(14, B - 1), B - 1})
+        poison_e = res.poison_left(sets=[0])  # (this leg writes every frame into the first output set)
+        ok_e = poison_e["type_minus77"] == 0
+        for fr in est_frames:
             ref = oracle.OracleDepthEstimator(P, cam_struct, T)
             ref.set_cloud(res.clouds_h[fr % U])
             ref.estimate_ground_plane((fr % res.est_S) + 1)
@@ -1024,7 +1094,8 @@ def main():
         estimated = {"plane": "estimated", "value": B * F * n_e / el_e, "ms_per_step": 1e3 * el_e / n_e,
                      "kernels_ms_per_launch": {k: v["avg_ms"] for k, v in kt_e.items()},
                      "ransac_us_per_frame": 1e3 * kt_e.get("k_rs_batch", {}).get("avg_ms", 0.0) / res.est_S,
-                     "frame_slots_per_launch": res.est_S, "verified": ok_e}
+                     "frame_slots_per_launch": res.est_S, "verified": ok_e, "frames_checked": len(est_frames),
+                     "poison_left": poison_e}
     if world == 1:
         if args.cpu_seconds > 0:
             cpu = cpu_baseline(P, cam_struct, T, res.clouds_h, res.planes_h, res.uvs_h, args.cpu_seconds)
@@ -1082,6 +1153,7 @@ def main():
             "parallelism": f"sequence-per-gpu x{world}",
         },
         "result_types": {capi.RESULT_TYPE_NAMES[i]: int(c) for i, c in enumerate(type_hist) if c},
+        "result_types_output_sets": type_hist_sets,
         "success_fraction": float((type_hist[1] + type_hist[16]) / max(1, type_hist.sum())),
         "frame_stats": {**{k: float(np.mean([s[k] for s in stats])) for k in
                            ("n_visible", "k1_mean", "k2_mean_fallback", "fallback_features")},

@@ -53,8 +53,16 @@ def test_bench_single_rank_line_is_physical():
     ks = r["kernels"]
     assert r["kernel"] == max(("k_project_scatter", "k_feature_fused"), key=lambda k: ks[k]["avg_ms"])
     assert ks["k_feature_fused"]["bound"] == "hbm" and 0.0 < ks["k_feature_fused"]["frac"] <= 1.0
-    # both contexts' outputs were checked, several timed loops ran
-    assert out["verification"]["output_sets"] == 2 and {o for o, _ in out["verification"]["frames_checked"]} == {0, 1}
+    # EVERY frame of both contexts' output sets was checked against the oracle, no poisoned entry survived the timed
+    # region, several timed loops ran
+    v = out["verification"]
+    assert v["output_sets"] == 2 and v["all_frames"] is True and v["frames_checked"] == 2 * 32
+    assert v["frames_per_output_set"] == [32, 32] and v["poison_left"]["type_minus77"] == 0
+    pe = out["plane_estimated"]
+    assert pe["verified"] is True and pe["frames_checked"] >= 16 and pe["poison_left"]["type_minus77"] == 0
+    ws = r["whole_step"]
+    assert ws["compulsory_bytes"] == 16.0 * 131072 * 32 and 0.0 < ws["compulsory_frac_of_peak"] < 1.0
+    assert ws["counter_bytes"] > ws["compulsory_bytes"] * 0.9 and 0.0 < ws["frac_of_peak"] < 1.0
     assert out["timed_loops"]["repeats"] >= 2 and out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
 
 
@@ -65,8 +73,11 @@ def test_bench_schedules_agree():
     a = _run(SMALL)
     assert a["config"]["contexts"] == 2 and a["config"]["frame_slots_per_launch"] == 32
     assert a["roofline"]["kernel"] in ("k_project_scatter", "k_feature_fused") and a["roofline"]["exclusive"]["frac"] > 0
-    b = _run(SMALL + ["--slots", "8"])
+    b = _run(SMALL + ["--slots", "8", "--verify-slots", "6"])  # (the opt-down: six frames instead of all)
     assert b["verified"] is True and b["config"]["frame_slots_per_launch"] == 8
+    assert b["verification"]["all_frames"] is False and b["verification"]["frames_checked"] == 6
     c = _run(SMALL + ["--contexts", "1"])
     assert c["verified"] is True and c["roofline"]["exclusive"] is None and c["config"]["contexts"] == 1
-    assert a["result_types"] == b["result_types"] == c["result_types"]
+    # (result types are summed over the output sets: two with the default schedule, one otherwise)
+    assert b["result_types"] == c["result_types"]
+    assert a["result_types_output_sets"] == 2 and a["result_types"] == {k: 2 * v for k, v in c["result_types"].items()}
