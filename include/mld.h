@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MLD_ABI_VERSION 5
+#define MLD_ABI_VERSION 6
 
 typedef enum mld_status {
     MLD_OK = 0,
@@ -306,6 +306,59 @@ int mld_calculate_depth_device(mld_ctx* ctx, int slot, const double* uv_dev, int
 int mld_calculate_depth_frame(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, int stride_bytes,
                               const float coeffs[4], const int32_t* inlier_idx_host, int64_t n_inliers,
                               const double* uv_host, int64_t F, double* depth_out_host, int32_t* type_out_host);
+/*
+ * The same single call for the reference's PRODUCTION use: the GroundPlane handed to CalculateDepth(cloud, uv, depths,
+ * types, groundPlane) is NOT segmented yet - TrackletDepthModule::process builds a fresh one for every frame
+ * (tracklet_depth_module.cpp:269-284) and setInputCloud estimates it (DepthEstimator.cpp:275-283) before the feature loop
+ * runs.  One asynchronous chain on the context's stream, no host round trip before the result:
+ *     H2D (cloud, features, label image) -> plane estimation on the slot (RansacPlane::CalculateInliersPlane,
+ *     RansacPlane.cpp:41-140, one block; or SemanticPlane::CalculateInliersPlane, :195-274) -> projection WITH that plane
+ *     (the points' ground-plane state rides in the pixel-map keys) -> feature kernel -> one D2H (depths, types, plane)
+ * The estimated plane stays installed on the slot (later mld_calculate_depth calls use it); its inlier index list is
+ * not produced here - mld_get_ground_plane_inliers fetches it on demand (GroundPlane::getInlinersIndex).
+ *   plane->kind MLD_PLANE_RANSAC:   `seed` fixes the draws (the reference's pcl::RandomSample is time-seeded)
+ *   plane->kind MLD_PLANE_SEMANTIC: label_image (HOST memory, rows x cols uint8, row_stride_bytes apart), ground_labels,
+ *                                   inlier_threshold as mld_estimate_semantic_plane
+ *   plane_out (optional): coefficients, inlier count, status 0 / 1, RANSAC iterations.
+ * Without do_use_ransac_plane the plane request is ignored (as setInputCloud does, :274).  A failed estimation
+ * (GroundPlane::ExceptionPclInvalid: fewer than 3 usable points / no model) returns MLD_ERR_CLOUD_TOO_SMALL and leaves
+ * depth_out / type_out untouched - the reference throws out of setInputCloud before any depth is computed
+ * (tracklet_depth_module.cpp:321,338 catch it).  Synchronises.  type_out may be NULL.
+ */
+#define MLD_PLANE_RANSAC 0
+#define MLD_PLANE_SEMANTIC 1
+typedef struct mld_plane_request {
+    int32_t kind;
+    uint32_t seed;
+    const uint8_t* label_image;
+    int32_t rows, cols, row_stride_bytes;
+    int32_t n_labels;
+    const int32_t* ground_labels;
+    double inlier_threshold;
+} mld_plane_request;
+typedef struct mld_plane_result {
+    float coeffs[4];
+    int64_t n_inliers;
+    int32_t status;      /* 0 ok, 1 = ExceptionPclInvalid */
+    int32_t iterations;  /* RANSAC iterations PCL's stopping rule counted (0 for the semantic plane) */
+} mld_plane_result;
+int mld_calculate_depth_frame_estimate(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, int stride_bytes,
+                                       const mld_plane_request* plane, const double* uv_host, int64_t F,
+                                       double* depth_out_host, int32_t* type_out_host, mld_plane_result* plane_out);
+/*
+ * Where the time of the LAST one-frame call (mld_calculate_depth_frame / _frame_estimate) went, when timing is enabled
+ * (mld_timing_enable; the hipEvents that bracket the phases cost a few microseconds themselves, so the un-instrumented
+ * call is a little faster than their sum).  out_us[8]:
+ *   [0] h2d      cloud copy on the context's stream (the small inputs travel beside it on a side stream)
+ *   [1] plane    plane estimation kernels (0 for a supplied plane)
+ *   [2] kernels  projection + feature kernel(s)
+ *   [3] d2h      result copy
+ *   [4] api      host time to enqueue everything (entry -> last enqueue returned)
+ *   [5] wait     host time blocked in the final synchronise
+ *   [6] total    host wall time of the call
+ *   [7] gpu      first event -> last event on the stream ([0]+[1]+[2]+[3] plus the gaps between them)
+ */
+int mld_frame_timing(mld_ctx* ctx, double out_us[8]);
 /* All slots [0, n_slots) in ONE launch set (host arrays of device pointers / counts). */
 int mld_calculate_depths_device(mld_ctx* ctx, int n_slots, const double* const* uv_dev, const int64_t* F,
                                 double* const* depth_out_dev, int32_t* const* type_out_dev);

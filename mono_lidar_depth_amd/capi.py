@@ -12,7 +12,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libmld_hip.so"
 
-MLD_ABI_VERSION = 5  # include/mld.h
+MLD_ABI_VERSION = 6  # include/mld.h
 MLD_OK = 0
 MLD_ERR_INVALID_ARG = -1
 MLD_ERR_NOT_INITIALIZED = -2
@@ -105,6 +105,28 @@ class MldParams(C.Structure):
         return out
 
 
+MLD_PLANE_RANSAC, MLD_PLANE_SEMANTIC = 0, 1
+
+
+class MldPlaneRequest(C.Structure):
+    """mld_plane_request (include/mld.h): how the not-yet-segmented plane of a one-frame call is estimated."""
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("seed", C.c_uint32),
+        ("label_image", C.c_void_p),
+        ("rows", C.c_int32),
+        ("cols", C.c_int32),
+        ("row_stride_bytes", C.c_int32),
+        ("n_labels", C.c_int32),
+        ("ground_labels", C.c_void_p),
+        ("inlier_threshold", C.c_double),
+    ]
+
+
+class MldPlaneResult(C.Structure):
+    _fields_ = [("coeffs", C.c_float * 4), ("n_inliers", C.c_int64), ("status", C.c_int32), ("iterations", C.c_int32)]
+
+
 # Every symbol include/mld.h declares: (name, restype, argtypes)
 _P = C.POINTER
 _SIGNATURES = [
@@ -145,6 +167,10 @@ _SIGNATURES = [
     ("mld_calculate_depth_opts", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_uint32]),
     ("mld_calculate_depth_frame", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, _P(C.c_float), C.c_void_p,
                                             C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    ("mld_calculate_depth_frame_estimate", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int,
+                                                     _P(MldPlaneRequest), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                                     _P(MldPlaneResult)]),
+    ("mld_frame_timing", C.c_int, [C.c_void_p, _P(C.c_double)]),
     ("mld_calculate_depth_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("mld_calculate_depths_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64),
                                               _P(C.c_void_p), _P(C.c_void_p)]),

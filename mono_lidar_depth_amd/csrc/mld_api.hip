@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <limits>
 #include <string>
 #include <vector>
@@ -137,6 +138,8 @@ struct mld_ctx {
     unsigned char* fr_host = nullptr;  // pinned: [inlier indices | uv] in, [depth | type] out
     unsigned char* fr_dev = nullptr;
     size_t fr_cap = 0;
+    hipEvent_t fr_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // phase marks of a timed one-frame call
+    double fr_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};                           // mld_frame_timing
     // batched ground-plane estimation (mld_set_clouds_estimate_planes_device)
     uint32_t* rsb_masks = nullptr;   // inlier bitmasks of all slots, contiguous
     size_t rsb_mask_words = 0;       // per slot
@@ -910,6 +913,8 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->rsb_seeds) (void)hipFree(ctx->rsb_seeds);
     if (ctx->fr_host) (void)hipHostFree(ctx->fr_host);
     if (ctx->fr_dev) (void)hipFree(ctx->fr_dev);
+    for (hipEvent_t e : ctx->fr_ev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->side_done) (void)hipEventDestroy(ctx->side_done);
     if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
@@ -1166,7 +1171,7 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
                            P.ransac_plane_distance_treshold, P.ransac_plane_refinement_treshold,
                            P.ransac_plane_use_refinement, ctx->rsb_planes, pass ? 1 : 0, (float)P.ransac_plane_min_z,
                            (float)P.ransac_plane_max_z, ctx->calib.far_elin, ctx->calib.far_econst,
-                           ctx->calib.roadDistThrF);
+                           ctx->calib.roadDistThrF, -1, SlotDesc{}, 0u, (PlaneDev*)nullptr);
         HIP_TRY(ctx, hipGetLastError());
     }
     RS_STAMP_LAUNCH(st, 1);
@@ -1338,11 +1343,11 @@ int mld_estimate_ground_plane(mld_ctx* ctx, int slot, uint32_t seed, float coeff
     return MLD_OK;
 }
 
-static int semantic_plane_core(mld_ctx* ctx, Slot& s, const unsigned char* img_dev, int rows, int cols, int row_stride,
-                               const int32_t* labels, int n_labels, double inlier_threshold, float coeffs_out[4],
-                               int64_t* n_inliers_out) {
+// SemanticPlane::CalculateInliersPlane (RansacPlane.cpp:195-274) for the slot's cloud, asynchronous part: the launches
+// that leave coefficients / counts / status in ctx->sem_res and the inlier bitmask in s.mask_buf, on stream `st`.
+static int semantic_plane_launch(mld_ctx* ctx, Slot& s, const unsigned char* img_dev, int rows, int cols, int row_stride,
+                                 const int32_t* labels, int n_labels, double inlier_threshold, hipStream_t st) {
     using namespace ransac;
-    int rc = MLD_OK;
     const long long n = s.d.n;
     LabelSet ls{};
     for (int i = 0; i < n_labels; i++)
@@ -1352,6 +1357,36 @@ static int semantic_plane_core(mld_ctx* ctx, Slot& s, const unsigned char* img_d
     sc.f = ctx->cam.focal_length;
     sc.cu = ctx->cam.principal_point_x;
     sc.cv = ctx->cam.principal_point_y;
+    const size_t words = (size_t)((n + 31) / 32);
+    const int nb = (int)((n + kScanBlock - 1) / kScanBlock);
+    const dim3 gp((unsigned)((n + 255) / 256)), bp(256);
+    auto compact = [&]() {
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(kScanBlock), 0, st, ctx->rs_flags, n, ctx->rs_block);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, st, ctx->rs_block, nb, ctx->rs_M);
+        hipLaunchKernelGGL(k_rs_compact, dim3(nb), dim3(kScanBlock), 0, st, ctx->rs_flags, n, ctx->rs_block, ctx->rs_cand);
+    };
+    // candidates by label, first fit
+    hipLaunchKernelGGL(k_sem_flags, gp, bp, 0, st, s.d.cloud, n, s.d.stride, sc, img_dev, rows, cols, row_stride, ls,
+                       ctx->rs_flags);
+    compact();
+    hipLaunchKernelGGL(k_ls_fit, dim3(1), dim3(kPartials), 0, st, s.d.cloud, s.d.stride, ctx->rs_cand, ctx->rs_M,
+                       ctx->sem_coeffs, ctx->sem_coeffs + 4, 3, 0, ctx->sem_res);
+    // re-selection over the whole cloud, second fit, inlier mask
+    hipLaunchKernelGGL(k_sem_select, gp, bp, 0, st, s.d.cloud, n, s.d.stride, ctx->sem_coeffs + 4, inlier_threshold,
+                       ctx->rs_flags);
+    compact();
+    hipLaunchKernelGGL(k_ls_fit, dim3(1), dim3(kPartials), 0, st, s.d.cloud, s.d.stride, ctx->rs_cand, ctx->rs_M,
+                       ctx->sem_coeffs + 4, ctx->sem_coeffs + 8, 0, 1, ctx->sem_res);
+    hipLaunchKernelGGL(k_mask_from_flags, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ctx->rs_flags, n,
+                       s.mask_buf);
+    HIP_TRY(ctx, hipGetLastError());
+    return MLD_OK;
+}
+
+// scratch of the semantic estimator (allocated on first use; may synchronise then)
+static int semantic_plane_scratch(mld_ctx* ctx, Slot& s) {
+    using namespace ransac;
+    int rc = MLD_OK;
     if (!ctx->sem_res) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->sem_coeffs, 12 * sizeof(float)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->sem_res, sizeof(SemResult)));
@@ -1360,32 +1395,19 @@ static int semantic_plane_core(mld_ctx* ctx, Slot& s, const unsigned char* img_d
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     if (!ctx->rs_M) HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_M, sizeof(int32_t)));
-    if ((rc = ensure_scan_buffers(ctx, n))) return rc;
-    const size_t words = (size_t)((n + 31) / 32);
-    if ((rc = grow(ctx, s.mask_buf, s.mask_words, words))) return rc;
-    const int nb = (int)((n + kScanBlock - 1) / kScanBlock);
-    const dim3 gp((unsigned)((n + 255) / 256)), bp(256);
-    auto compact = [&]() {
-        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(kScanBlock), 0, ctx->stream, ctx->rs_flags, n, ctx->rs_block);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, ctx->stream, ctx->rs_block, nb, ctx->rs_M);
-        hipLaunchKernelGGL(k_rs_compact, dim3(nb), dim3(kScanBlock), 0, ctx->stream, ctx->rs_flags, n, ctx->rs_block,
-                           ctx->rs_cand);
-    };
-    // candidates by label, first fit
-    hipLaunchKernelGGL(k_sem_flags, gp, bp, 0, ctx->stream, s.d.cloud, n, s.d.stride, sc, img_dev, rows, cols, row_stride,
-                       ls, ctx->rs_flags);
-    compact();
-    hipLaunchKernelGGL(k_ls_fit, dim3(1), dim3(kPartials), 0, ctx->stream, s.d.cloud, s.d.stride, ctx->rs_cand, ctx->rs_M,
-                       ctx->sem_coeffs, ctx->sem_coeffs + 4, 3, 0, ctx->sem_res);
-    // re-selection over the whole cloud, second fit, inlier mask
-    hipLaunchKernelGGL(k_sem_select, gp, bp, 0, ctx->stream, s.d.cloud, n, s.d.stride, ctx->sem_coeffs + 4,
-                       inlier_threshold, ctx->rs_flags);
-    compact();
-    hipLaunchKernelGGL(k_ls_fit, dim3(1), dim3(kPartials), 0, ctx->stream, s.d.cloud, s.d.stride, ctx->rs_cand, ctx->rs_M,
-                       ctx->sem_coeffs + 4, ctx->sem_coeffs + 8, 0, 1, ctx->sem_res);
-    hipLaunchKernelGGL(k_mask_from_flags, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, ctx->stream, ctx->rs_flags, n,
-                       s.mask_buf);
-    HIP_TRY(ctx, hipGetLastError());
+    if ((rc = ensure_scan_buffers(ctx, s.d.n))) return rc;
+    return grow(ctx, s.mask_buf, s.mask_words, (size_t)((s.d.n + 31) / 32));
+}
+
+static int semantic_plane_core(mld_ctx* ctx, Slot& s, const unsigned char* img_dev, int rows, int cols, int row_stride,
+                               const int32_t* labels, int n_labels, double inlier_threshold, float coeffs_out[4],
+                               int64_t* n_inliers_out) {
+    using namespace ransac;
+    int rc = MLD_OK;
+    if (s.d.n < 3) return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");  // (:224-227)
+    if ((rc = semantic_plane_scratch(ctx, s))) return rc;
+    if ((rc = semantic_plane_launch(ctx, s, img_dev, rows, cols, row_stride, labels, n_labels, inlier_threshold, ctx->stream)))
+        return rc;
     SemResult res;
     HIP_TRY(ctx, hipMemcpyAsync(&res, ctx->sem_res, sizeof(SemResult), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1574,11 +1596,29 @@ int mld_calculate_depth_opts(mld_ctx* ctx, int slot, const double* uv_host, int6
 
 // setInputCloud + CalculateDepth of ONE frame from host memory in a single call (the reference's
 // CalculateDepth(cloud, uv, depths, types, groundPlane), DepthEstimator.cpp:404-420): the small inputs travel in one
-// pinned block and one DMA, the results come back in one, and the plane is installed BEFORE the projection so that
-// the inlier flags ride in the map keys.
-int mld_calculate_depth_frame(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, int stride_bytes,
-                              const float coeffs[4], const int32_t* inlier_idx_host, int64_t n_inliers,
-                              const double* uv_host, int64_t F, double* depth_out_host, int32_t* type_out_host) {
+// pinned block and one DMA on a side stream, the results come back in one, and the plane - supplied, or ESTIMATED on the
+// slot when the GroundPlane handed in is not segmented yet (:275-283) - is in place BEFORE the projection, so that the
+// points' ground-plane state rides in the map keys.  One asynchronous chain, one synchronisation at the end.
+namespace {
+struct FramePlane {
+    enum Kind { NONE, SUPPLIED, RANSAC, SEMANTIC } kind = NONE;
+    const float* coeffs = nullptr;  // SUPPLIED
+    const int32_t* inliers = nullptr;
+    int64_t n_inliers = 0;
+    const mld_plane_request* req = nullptr;  // RANSAC / SEMANTIC
+};
+double now_us() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+}  // namespace
+
+static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, int stride_bytes, const FramePlane& fp,
+                      const double* uv_host, int64_t F, double* depth_out_host, int32_t* type_out_host,
+                      mld_plane_result* plane_out) {
+    using namespace ransac;
+    const double t_entry = now_us();
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     if ((rc = bind_device(ctx))) return rc;
@@ -1587,13 +1627,52 @@ int mld_calculate_depth_frame(mld_ctx* ctx, int slot, const void* pts_host, int6
     if (n > kMaxPoints) return fail(ctx, MLD_ERR_CAPACITY, "cloud larger than 8 388 607 points");
     if (F < 0 || F > 0x7FFFFFFFLL) return fail(ctx, MLD_ERR_INVALID_ARG, "bad feature count");
     if (F > 0 && (!uv_host || !depth_out_host)) return fail(ctx, MLD_ERR_INVALID_ARG, "null feature/output pointer");
-    if (coeffs && (n_inliers < 0 || (!inlier_idx_host && n_inliers > 0))) return fail(ctx, MLD_ERR_INVALID_ARG, "bad inlier list");
+    const mld_params& P = ctx->P;
+    FramePlane::Kind kind = fp.kind;
+    if (!P.do_use_ransac_plane && kind != FramePlane::NONE) kind = FramePlane::NONE;  // the plane is ignored (:274)
+    if (kind == FramePlane::SUPPLIED && (fp.n_inliers < 0 || (!fp.inliers && fp.n_inliers > 0)))
+        return fail(ctx, MLD_ERR_INVALID_ARG, "bad inlier list");
+    const bool estimate = kind == FramePlane::RANSAC || kind == FramePlane::SEMANTIC;
+    const mld_plane_request* rq = fp.req;
+    if (kind == FramePlane::SEMANTIC &&
+        (!rq->label_image || rq->rows <= 0 || rq->cols <= 0 || rq->row_stride_bytes < rq->cols || rq->n_labels < 0 ||
+         (rq->n_labels > 0 && !rq->ground_labels)))
+        return fail(ctx, MLD_ERR_INVALID_ARG, "bad label image / label set");
+    const int n_draws = P.ransac_plane_max_iterations + 1;
+    if (kind == FramePlane::RANSAC && n_draws < 1) return fail(ctx, MLD_ERR_INVALID_ARG, "ransac_plane_max_iterations must be >= 0");
+    // RansacPlane.cpp:44-50 / :224-227: fewer than three points cannot carry a plane - the reference throws out of
+    // setInputCloud before anything else happens
+    if (estimate && n < 3) return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");
     Slot& s = ctx->slots[slot];
-    const size_t n_inl = coeffs ? (size_t)n_inliers : 0;
+    // RANSAC with the z pass-through on a cloud too large for the one-block kernel's LDS: the per-slot estimator
+    // (it synchronises once before the feature kernels)
+    const bool pass = P.ransac_plane_min_z > -1001.;
+    size_t rs_lds = 0;
+    if (kind == FramePlane::RANSAC) {
+        const size_t lds_fixed = (size_t)kSample * 5 * sizeof(float) + (size_t)kPartials * 9 * sizeof(float) +
+                                 (2 * kRsRound + kRsMisc + kRsEpochInts) * sizeof(int);
+        const size_t n_chunks = (size_t)((n + 1023) / 1024);
+        rs_lds = lds_fixed + (pass ? (n_chunks + 1) * sizeof(int) + 16 * n_chunks + 16 : 0);
+        if (rs_lds > 158 * 1024) {
+            float co[4];
+            int64_t ni = 0;
+            if ((rc = mld_set_cloud(ctx, slot, pts_host, n, stride_bytes))) return rc;
+            if ((rc = mld_estimate_ground_plane(ctx, slot, rq->seed, co, &ni))) return rc;
+            if (plane_out) {
+                for (int t = 0; t < 4; t++) plane_out->coeffs[t] = co[t];
+                plane_out->n_inliers = ni;
+                plane_out->status = 0;
+                plane_out->iterations = 0;
+            }
+            return F > 0 ? mld_calculate_depth(ctx, slot, uv_host, F, depth_out_host, type_out_host) : MLD_OK;
+        }
+    }
+    const size_t n_inl = kind == FramePlane::SUPPLIED ? (size_t)fp.n_inliers : 0;
     const size_t off_uv = (n_inl * sizeof(int32_t) + 15) & ~(size_t)15;
     const size_t off_depth = off_uv + (size_t)F * 2 * sizeof(double);
     const size_t off_type = off_depth + (size_t)F * sizeof(double);
-    const size_t total = off_type + (size_t)F * sizeof(int32_t) + 16;
+    const size_t off_plane = (off_type + (size_t)F * sizeof(int32_t) + 15) & ~(size_t)15;
+    const size_t total = off_plane + sizeof(PlaneDev) + 16;
     if (total > ctx->fr_cap) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->fr_host) HIP_TRY(ctx, hipHostFree(ctx->fr_host));
@@ -1608,22 +1687,40 @@ int mld_calculate_depth_frame(mld_ctx* ctx, int slot, const void* pts_host, int6
     }
     const size_t bytes = (size_t)n * (size_t)stride_bytes;
     if ((rc = grow(ctx, s.cloud_buf, s.cloud_cap, bytes))) return rc;
-    const size_t words = (size_t)((n + 31) / 32);
-    if (coeffs && (rc = grow(ctx, s.mask_buf, s.mask_words, words))) return rc;
+    // inlier bitmask of the slot; the one-block RANSAC also keeps its 64-bit pass-through group masks there (even word count)
+    const size_t words = kind == FramePlane::RANSAC ? (((size_t)((n + 31) / 32) + 2) & ~(size_t)1) : (size_t)((n + 31) / 32);
+    if (kind != FramePlane::NONE && (rc = grow(ctx, s.mask_buf, s.mask_words, words))) return rc;
     if ((rc = ensure_queues(ctx, s, F))) return rc;
     if (!ctx->side) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
     }
+    if (estimate && !ctx->rsb_planes) {
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_planes, ctx->slots.size() * sizeof(PlaneDev)));
+        HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_seeds, ctx->slots.size() * sizeof(uint32_t)));
+    }
+    size_t img_bytes = 0;
+    if (kind == FramePlane::SEMANTIC) {
+        s.d.n = n;  // (the scratch is sized by the cloud)
+        if ((rc = semantic_plane_scratch(ctx, s))) return rc;
+        img_bytes = (size_t)rq->rows * (size_t)rq->row_stride_bytes;
+        if ((rc = grow(ctx, ctx->sem_img, ctx->sem_img_cap, img_bytes))) return rc;
+    }
+    if (kind == FramePlane::RANSAC && (rc = enable_rs_batch_lds(ctx, rs_lds))) return rc;
+    const bool timed = ctx->timing;
+    if (timed && !ctx->fr_ev[0])
+        for (int i = 0; i < 5; i++) HIP_TRY(ctx, hipEventCreate(&ctx->fr_ev[i]));
     // The small inputs go first, on the side stream: their DMA and the mask build run while the cloud is in flight.
     // (The side stream starts after whatever is already queued on the context's stream: an earlier asynchronous call
     // on this slot may still read the mask buffer and the staging block that are rewritten here.)
     HIP_TRY(ctx, hipEventRecord(ctx->side_done, ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->side_done, 0));
-    if (n_inl) std::memcpy(ctx->fr_host, inlier_idx_host, n_inl * sizeof(int32_t));
+    if (n_inl) std::memcpy(ctx->fr_host, fp.inliers, n_inl * sizeof(int32_t));
     if (F) std::memcpy(ctx->fr_host + off_uv, uv_host, (size_t)F * 2 * sizeof(double));
     if (off_depth) HIP_TRY(ctx, hipMemcpyAsync(ctx->fr_dev, ctx->fr_host, off_depth, hipMemcpyHostToDevice, ctx->side));
-    if (coeffs) {
+    if (kind == FramePlane::SEMANTIC)
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->sem_img, rq->label_image, img_bytes, hipMemcpyHostToDevice, ctx->side));
+    if (kind == FramePlane::SUPPLIED || kind == FramePlane::RANSAC) {
         HIP_TRY(ctx, hipMemsetAsync(s.mask_buf, 0, (words < 1 ? 1 : words) * sizeof(uint32_t), ctx->side));
         if (n_inl) {
             hipLaunchKernelGGL(k_build_mask, dim3((unsigned)((n_inl + 255) / 256)), dim3(256), 0, ctx->side,
@@ -1634,32 +1731,71 @@ int mld_calculate_depth_frame(mld_ctx* ctx, int slot, const void* pts_host, int6
     // (the slot's occupancy bitmap is cleared there as well: off the cloud copy's critical path)
     if ((rc = begin_cloud(ctx, s, s.cloud_buf, n, stride_bytes, true, ctx->side))) return rc;
     HIP_TRY(ctx, hipEventRecord(ctx->side_done, ctx->side));
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->fr_ev[0], ctx->stream));
     // The cloud, straight from the caller's memory (measured: the runtime's own staging of a pageable source moves
     // 2.1 MB in 51 us, as fast as from pinned memory; copying through a pinned buffer of ours in pieces was slower).
     if (bytes) HIP_TRY(ctx, hipMemcpyAsync(s.cloud_buf, pts_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->fr_ev[1], ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
-    if (coeffs) {
-        set_plane_coeffs(ctx, s, coeffs);
+    PlaneDev* pd_copy = reinterpret_cast<PlaneDev*>(ctx->fr_dev + off_plane);
+    if (kind == FramePlane::SUPPLIED) {
+        set_plane_coeffs(ctx, s, fp.coeffs);
         s.d.inlier_mask = s.mask_buf;
         s.d.mask_in_key = 1;
-    } else {
+    } else if (kind == FramePlane::NONE) {
         clear_plane(s);
+    } else {
+        // the plane is estimated on the slot and stays in device memory (PlaneDev): no host round trip before the
+        // projection, which reads it there for the points' ground-plane state
+        PlaneDev* pd = ctx->rsb_planes + slot;
+        s.d.inlier_mask = s.mask_buf;
+        if (kind == FramePlane::RANSAC) {
+            hipLaunchKernelGGL(k_rs_batch, dim3(1), dim3(kRsThreads), rs_lds, ctx->stream, ctx->d_slots, ctx->rsb_seeds, n_draws,
+                               P.ransac_plane_max_iterations, P.ransac_plane_probability, P.ransac_plane_distance_treshold,
+                               P.ransac_plane_refinement_treshold, P.ransac_plane_use_refinement, ctx->rsb_planes, pass ? 1 : 0,
+                               (float)P.ransac_plane_min_z, (float)P.ransac_plane_max_z, ctx->calib.far_elin,
+                               ctx->calib.far_econst, ctx->calib.roadDistThrF, slot, s.d, rq->seed, pd_copy);
+            HIP_TRY(ctx, hipGetLastError());
+        } else {
+            if ((rc = semantic_plane_launch(ctx, s, ctx->sem_img, rq->rows, rq->cols, rq->row_stride_bytes, rq->ground_labels,
+                                            rq->n_labels, rq->inlier_threshold, ctx->stream)))
+                return rc;
+            hipLaunchKernelGGL(k_sem_finish, dim3(1), dim3(1), 0, ctx->stream, ctx->sem_res, pd, pd_copy, ctx->calib.far_elin,
+                               ctx->calib.far_econst, ctx->calib.roadDistThrF);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        s.d.mask_in_key = 1;
+        s.d.plane_dev = pd;
+        s.d.has_plane = 1;  // the device copy decides (PlaneDev::has_plane)
+        s.plane_decided = true;
     }
+    if (timed) HIP_TRY(ctx, hipEventRecord(ctx->fr_ev[2], ctx->stream));
     if ((rc = launch_project(ctx, 1, n, true, slot))) return rc;
-    if (F == 0) {
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        return MLD_OK;
-    }
     double* d_depth = reinterpret_cast<double*>(ctx->fr_dev + off_depth);
     int32_t* d_type = reinterpret_cast<int32_t*>(ctx->fr_dev + off_type);
-    rc = calc_one(ctx, slot, reinterpret_cast<const double*>(ctx->fr_dev + off_uv), F, d_depth, d_type);
+    if (F > 0) rc = calc_one(ctx, slot, reinterpret_cast<const double*>(ctx->fr_dev + off_uv), F, d_depth, d_type);
     if (rc == MLD_OK) {
-        hipError_t e = hipMemcpyAsync(ctx->fr_host + off_depth, d_depth, off_type - off_depth + (size_t)F * sizeof(int32_t),
-                                      hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipSuccess;
+        if (timed) e = hipEventRecord(ctx->fr_ev[3], ctx->stream);
+        const size_t out_bytes = (estimate ? off_plane + sizeof(PlaneDev) : off_type + (size_t)F * sizeof(int32_t)) - off_depth;
+        if (e == hipSuccess && out_bytes)
+            e = hipMemcpyAsync(ctx->fr_host + off_depth, d_depth, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && timed) e = hipEventRecord(ctx->fr_ev[4], ctx->stream);
+        const double t_enq = now_us();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        const double t_done = now_us();
         if (e != hipSuccess) {
             ctx->err = std::string("mld_calculate_depth_frame: ") + hipGetErrorString(e);
             rc = MLD_ERR_HIP;
+        } else if (timed) {
+            float ms[4] = {0, 0, 0, 0}, all = 0;
+            for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&ms[i], ctx->fr_ev[i], ctx->fr_ev[i + 1]);
+            (void)hipEventElapsedTime(&all, ctx->fr_ev[0], ctx->fr_ev[4]);
+            for (int i = 0; i < 4; i++) ctx->fr_us[i] = 1e3 * (double)ms[i];
+            ctx->fr_us[4] = t_enq - t_entry;
+            ctx->fr_us[5] = t_done - t_enq;
+            ctx->fr_us[6] = t_done - t_entry;  // (up to here: the copies into the caller's arrays follow)
+            ctx->fr_us[7] = 1e3 * (double)all;
         }
     }
     // the slot must not keep pointers into the staging block (it is reused by the next call)
@@ -1668,8 +1804,62 @@ int mld_calculate_depth_frame(mld_ctx* ctx, int slot, const void* pts_host, int6
     s.d.type = nullptr;
     s.d.F = 0;
     if (rc) return rc;
-    std::memcpy(depth_out_host, ctx->fr_host + off_depth, (size_t)F * sizeof(double));
-    if (type_out_host) std::memcpy(type_out_host, ctx->fr_host + off_type, (size_t)F * sizeof(int32_t));
+    if (estimate) {
+        PlaneDev h;
+        std::memcpy(&h, ctx->fr_host + off_plane, sizeof(PlaneDev));
+        if (plane_out) {
+            for (int t = 0; t < 4; t++) plane_out->coeffs[t] = h.status == 0 ? h.coeffs[t] : 0.f;
+            plane_out->n_inliers = h.status == 0 ? h.n_inliers : 0;
+            plane_out->status = h.status;
+            plane_out->iterations = h.iterations;
+        }
+        if (h.status != 0) {  // GroundPlane::ExceptionPclInvalid: the reference never gets to the feature loop
+            clear_plane(s);
+            s.plane_decided = false;
+            return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");
+        }
+        // host-side copy of what the kernels read from the slot's PlaneDev (for the getters)
+        std::memcpy(s.d.coeffs, h.coeffs, sizeof(float) * 4);
+        for (int t = 0; t < 3; t++) s.d.prior_n[t] = h.prior_n[t];
+        s.d.prior_off = h.prior_off;
+        s.d.far_mg0 = h.far_mg0;
+        s.d.far_mg1 = h.far_mg1;
+    }
+    if (F > 0) {
+        std::memcpy(depth_out_host, ctx->fr_host + off_depth, (size_t)F * sizeof(double));
+        if (type_out_host) std::memcpy(type_out_host, ctx->fr_host + off_type, (size_t)F * sizeof(int32_t));
+    }
+    return MLD_OK;
+}
+
+int mld_calculate_depth_frame(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, int stride_bytes,
+                              const float coeffs[4], const int32_t* inlier_idx_host, int64_t n_inliers,
+                              const double* uv_host, int64_t F, double* depth_out_host, int32_t* type_out_host) {
+    FramePlane fp;
+    if (coeffs) {
+        fp.kind = FramePlane::SUPPLIED;
+        fp.coeffs = coeffs;
+        fp.inliers = inlier_idx_host;
+        fp.n_inliers = n_inliers;
+    }
+    return frame_call(ctx, slot, pts_host, n, stride_bytes, fp, uv_host, F, depth_out_host, type_out_host, nullptr);
+}
+
+int mld_calculate_depth_frame_estimate(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, int stride_bytes,
+                                       const mld_plane_request* plane, const double* uv_host, int64_t F,
+                                       double* depth_out_host, int32_t* type_out_host, mld_plane_result* plane_out) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    if (!plane || (plane->kind != MLD_PLANE_RANSAC && plane->kind != MLD_PLANE_SEMANTIC))
+        return fail(ctx, MLD_ERR_INVALID_ARG, "mld_plane_request: kind must be MLD_PLANE_RANSAC or MLD_PLANE_SEMANTIC");
+    FramePlane fp;
+    fp.kind = plane->kind == MLD_PLANE_RANSAC ? FramePlane::RANSAC : FramePlane::SEMANTIC;
+    fp.req = plane;
+    return frame_call(ctx, slot, pts_host, n, stride_bytes, fp, uv_host, F, depth_out_host, type_out_host, plane_out);
+}
+
+int mld_frame_timing(mld_ctx* ctx, double out_us[8]) {
+    if (!ctx || !out_us) return MLD_ERR_INVALID_ARG;
+    for (int i = 0; i < 8; i++) out_us[i] = ctx->fr_us[i];
     return MLD_OK;
 }
 

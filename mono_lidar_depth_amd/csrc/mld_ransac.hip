@@ -405,11 +405,16 @@ __device__ inline void rs_count_inliers(const float* sx, const float* sy, const 
 // One block per frame slot.  pass != 0: pcl::PassThrough on z with the float limits [lo, hi] ahead of the sub-sampling
 // (LDS beyond the fixed part: one byte per 64 points + one int per 1024 points).  Where a block's time goes:
 // DESIGN.md "k_rs_batch" (about half of it is the wait for the 6000 scattered cloud reads of the sample).
+// single_slot >= 0 (ONE frame per call, mld_calculate_depth_frame_estimate): a grid of one block works on the descriptor
+// passed by value, takes `single_seed`, writes that slot's PlaneDev and leaves a second copy of the plane in `copy_out` - the staging block that travels
+// back to the host with the depths - beside the slot's resident PlaneDev.
 __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restrict__ slots, const uint32_t* __restrict__ seeds,
                                                         int n_draws, int max_it, double probability, double thr,
                                                         double refine_thr, int use_refinement, PlaneDev* out, int pass,
                                                         float lo, float hi,
-                                                        float far_elin, float far_econst, float far_thr) {
+                                                        float far_elin, float far_econst, float far_thr,
+                                                        int single_slot, SlotDesc single, uint32_t single_seed,
+                                                        PlaneDev* copy_out) {
     extern __shared__ __align__(16) unsigned char rs_smem[];
     // the sample as three coordinate arrays (structure of arrays): a lane reads four consecutive points with three
     // 16-byte LDS loads in the hypothesis loop
@@ -436,9 +441,10 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
     const double log_probability = log(1.0 - probability);
     asm volatile("" ::"v"(log_probability));  // here, beside the first cloud reads, not where it is first used
     const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid >> 6;
-    const SlotDesc s = slots[blockIdx.x];
-    PlaneDev* pd = out + blockIdx.x;
-    const uint32_t seed = seeds[blockIdx.x];
+    const int slot_i = single_slot >= 0 ? single_slot : (int)blockIdx.x;
+    const SlotDesc s = single_slot >= 0 ? single : slots[slot_i];
+    PlaneDev* pd = out + slot_i;
+    const uint32_t seed = single_slot >= 0 ? single_seed : seeds[slot_i];
     asm volatile("" ::"s"(s.cloud), "s"(s.inlier_mask), "s"(s.n), "s"(s.stride), "s"(seed), "s"(pd));
     long long M = s.n;
     int S = M > kSample ? kSample : (int)M;
@@ -448,6 +454,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
             pd->status = 1;
             pd->n_inliers = 0;
             pd->S = S;
+            if (copy_out) *copy_out = *pd;
         }
     };
     if (M < 3) {  // RansacPlane.cpp:44-50
@@ -886,6 +893,7 @@ __global__ __launch_bounds__(kRsThreads) void k_rs_batch(const SlotDesc* __restr
         pd->S = S;
         pd->status = 0;
         pd->has_plane = 1;
+        if (copy_out) *copy_out = *pd;
     }
     RS_PHASE(7);  // plane written
     RS_FLUSH();
@@ -1004,6 +1012,38 @@ __global__ __launch_bounds__(kPartials) void k_ls_fit(const unsigned char* cloud
             if (stage == 1) res->coeffs[t] = c[t];
         }
     }
+}
+
+// The semantic plane as the projection and the feature kernels consume it (what set_plane_coeffs prepares on the host for
+// a plane that was read back): coefficients, M-estimator prior (DepthEstimator.cpp:286-292), margins of the projection's
+// far test.  One thread; `copy_out` as in k_rs_batch.
+__global__ void k_sem_finish(const SemResult* __restrict__ res, PlaneDev* pd, PlaneDev* copy_out, float far_elin,
+                             float far_econst, float far_thr) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const float co[4] = {res->coeffs[0], res->coeffs[1], res->coeffs[2], res->coeffs[3]};
+    const int ok = res->status == 0;
+    for (int t = 0; t < 4; t++) pd->coeffs[t] = co[t];
+    double a = (double)co[0], b = (double)co[1], cc = (double)co[2];
+    const double z = a * a + (b * b + cc * cc);
+    if (z > 0.0) {
+        const double nrm = sqrt(z);
+        a /= nrm;
+        b /= nrm;
+        cc /= nrm;
+    }
+    pd->prior_n[0] = a;
+    pd->prior_n[1] = b;
+    pd->prior_n[2] = cc;
+    pd->prior_off = (double)co[3];
+    far_margins(co, far_elin, far_econst, far_thr, pd->far_mg0, pd->far_mg1);
+    pd->n_inliers = ok ? res->n_inliers : 0;
+    pd->iterations = 0;
+    pd->best_draw = -1;
+    pd->best_count = res->n_candidates;
+    pd->S = res->n_candidates;
+    pd->status = ok ? 0 : 1;
+    pd->has_plane = ok;
+    if (copy_out) *copy_out = *pd;
 }
 
 // inlier bitmask from per-point flags: one word per thread
