@@ -162,27 +162,83 @@ def cpu_baseline(P, cam_struct, T, clouds, planes, uvs, seconds):
 def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
     """One frame per call through the host-pointer entry points (the reference's ROS usage): H2D of the cloud, the
     plane's inlier list and the features, kernels, D2H of depths/types, synchronise.  PCIe-inclusive; reported beside
-    the resident-throughput `value`, never as it."""
-    from mono_lidar_depth_amd import DepthEstimator, GroundPlane
+    the resident-throughput `value`, never as it.  Three variants of the same call:
+      supplied            the GroundPlane handed in is segmented (mld_calculate_depth_frame)
+      estimated.ransac    a fresh RansacPlane per frame - setInputCloud estimates it (DepthEstimator.cpp:275-283)
+      estimated.semantic  a fresh SemanticPlane per frame - what TrackletDepthModule::process does
+                          (tracklet_depth_module.cpp:269-284); both through mld_calculate_depth_frame_estimate
+    each with the median / p99 of the un-instrumented call and a phase breakdown (hipEvents + host clock,
+    mld_frame_timing) from a second, instrumented pass."""
+    from mono_lidar_depth_amd import DepthEstimator, GroundPlane, RansacPlane, SemanticPlane, synth
+    from oracle import oracle
     est = DepthEstimator(device=device, max_points=clouds[0].shape[0], max_features=uvs[0].shape[0])
     est.InitConfig(P)
     est.Initialize(cam, T)
-    ts = []
-    for it in range(n_frames + 10):
+    labels = (6, 7, 8, 9)
+    thr = float(P.ransac_plane_refinement_treshold)
+    imgs = [synth.make_label_image(c) for c in clouds[:4]]
+
+    def plane_for(kind, it):
         i = it % len(clouds)
-        t0 = time.perf_counter()
-        est.CalculateDepth(clouds[i], uvs[i], GroundPlane(*planes[i]))
-        ts.append(time.perf_counter() - t0)
-    est.close()
-    ts = np.array(ts[10:]) * 1e3
-    return {
+        if kind == "supplied":
+            return GroundPlane(*planes[i])
+        if kind == "ransac":
+            return RansacPlane(seed=it + 1)
+        return SemanticPlane(imgs[i % len(imgs)], labels, thr)
+
+    def run(kind):
+        ts = []
+        last = None
+        for it in range(n_frames + 10):
+            i = it % len(clouds) if kind != "semantic" else it % len(imgs)
+            gp = plane_for(kind, it)
+            t0 = time.perf_counter()
+            d, t = est.CalculateDepth(clouds[i], uvs[i], gp)
+            ts.append(time.perf_counter() - t0)
+            last = (it, i, d, t)
+        ts = np.array(ts[10:]) * 1e3
+        # phase breakdown: the same call with the phase events on
+        est.timingEnable(True)
+        ph = []
+        for it in range(min(60, n_frames)):
+            i = it % len(clouds) if kind != "semantic" else it % len(imgs)
+            est.CalculateDepth(clouds[i], uvs[i], plane_for(kind, it))
+            ph.append(est.frameTiming())
+        est.timingEnable(False)
+        breakdown = {k: float(np.median([p[k] for p in ph[5:]])) for k in ph[0]} if len(ph) > 5 else None
+        out = {"frames": int(n_frames), "ms_per_frame_median": float(np.median(ts)),
+               "ms_per_frame_p99": float(np.percentile(ts, 99)),
+               "associations_per_s": float(uvs[0].shape[0] / np.median(ts) * 1e3),
+               "breakdown_us_median": breakdown}
+        if kind != "supplied":  # the last frame against the oracle with the restatement's plane for the same request
+            it, i, d, t = last
+            ref = oracle.OracleDepthEstimator(P, cam.as_struct(), T)
+            ref.set_cloud(clouds[i])
+            if kind == "ransac":
+                ref.estimate_ground_plane(it + 1)
+            else:
+                ref.estimate_semantic_plane(imgs[i % len(imgs)], labels, thr)
+            d0, t0_ = ref.calculate_depth(uvs[i], 8)
+            out["verified"] = bool(np.array_equal(t, t0_) and np.allclose(d, d0, rtol=0, atol=1e-4, equal_nan=True))
+        return out
+
+    sup = run("supplied")
+    res = {
         "path": "host pointers, one frame per call: setInputCloud (H2D 2.1 MB) + ground plane (inlier list H2D) + "
                 "CalculateDepth (uv H2D, kernels, depth/type D2H, sync)",
-        "frames": int(n_frames),
-        "ms_per_frame_median": float(np.median(ts)),
-        "ms_per_frame_p99": float(np.percentile(ts, 99)),
-        "associations_per_s": float(uvs[0].shape[0] / np.median(ts) * 1e3),
+        **sup,
+        "breakdown_keys": "h2d = cloud copy, plane = plane estimation kernels, kernels = projection + feature kernel, d2h = "
+                          "result copy (hipEvents on the context's stream); api = host time to enqueue, wait = host time in "
+                          "the final synchronise, total = host wall time; gpu = first to last event",
     }
+    if P.do_use_ransac_plane:
+        res["estimated"] = {
+            "path": "the same call with a GroundPlane that is not segmented yet (the reference's production call): plane "
+                    "estimated on the GPU ahead of the projection, one C call, one synchronisation "
+                    "(mld_calculate_depth_frame_estimate)",
+            "ransac": run("ransac"), "semantic": run("semantic")}
+    est.close()
+    return res
 
 
 def mask_words(inl, n):
@@ -1170,6 +1226,8 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     bad_cfg = any(c.get("verified") is False for c in configs.values()) or bool(estimated and not estimated["verified"])
+    if latency and latency.get("estimated"):
+        bad_cfg = bad_cfg or not all(latency["estimated"][k]["verified"] for k in ("ransac", "semantic"))
     sys.exit(1 if (verified is False or bad_cfg) else 0)
 
 

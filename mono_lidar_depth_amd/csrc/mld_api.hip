@@ -114,6 +114,8 @@ struct mld_ctx {
     unsigned char* sem_img = nullptr;
     size_t sem_img_cap = 0;
     float* sem_coeffs = nullptr;  // dummy prior, first fit, second fit
+    unsigned char* sem_groups = nullptr;  // per 64 points: the moment sums of the group's members (ransac::GroupSums)
+    size_t sem_groups_cap = 0;
     ransac::SemResult* sem_res = nullptr;
     // tracklet gather/scatter scratch (device)
     double* trk_uv_cur = nullptr;
@@ -138,6 +140,8 @@ struct mld_ctx {
     unsigned char* fr_host = nullptr;  // pinned: [inlier indices | uv] in, [depth | type] out
     unsigned char* fr_dev = nullptr;
     size_t fr_cap = 0;
+    unsigned char* fr_host_dev = nullptr;  // the pinned block as the kernels address it (results are written there directly)
+    bool fr_zero_copy = true;              // false (test build: MLD_FRAME_COPY=1): results through device memory + a D2H copy
     hipEvent_t fr_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // phase marks of a timed one-frame call
     double fr_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};                           // mld_frame_timing
     // batched ground-plane estimation (mld_set_clouds_estimate_planes_device)
@@ -361,6 +365,9 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     if (const char* e = std::getenv("MLD_FORCE_THREAD_PATH")) ctx->force_thread_path = e[0] == '1';
     //   MLD_PROJ_LDS=bytes     occupancy experiments: the batched projection asks for that much (unused) LDS per block
     if (const char* e = std::getenv("MLD_PROJ_LDS")) ctx->proj_lds = (size_t)std::atoll(e);
+    //   MLD_FRAME_COPY=1       one-frame calls return their results through device memory and a D2H copy (A/B of the
+    //                          direct stores into the pinned block)
+    if (const char* e = std::getenv("MLD_FRAME_COPY")) ctx->fr_zero_copy = e[0] != '1';
     if (const char* e = std::getenv("MLD_K1MAX")) c.k1max = std::min(std::max(std::atoi(e), 8), kK1MaxLimit);
     if (const char* e = std::getenv("MLD_KMAIN")) c.kMain = std::min(std::max(std::atoi(e), 8), c.k1max);
 #endif
@@ -731,7 +738,7 @@ int ensure_full(mld_ctx* ctx, Slot& s) {
                            ctx->calib, s.cam, s.img, s.vis);
         hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(kScanBlock), 0, ctx->stream, s.vis, (long long)n,
                            s.block_sums);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, ctx->stream, s.block_sums, nb, s.d_total);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, s.block_sums, nb, s.d_total);
         hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(kScanBlock), 0, ctx->stream, s.vis, (long long)n,
                            s.block_sums, s.img, s.rank, s.pidx, s.img_vis);
         HIP_TRY(ctx, hipGetLastError());
@@ -899,7 +906,7 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->dummy) (void)hipFree(ctx->dummy);
     if (ctx->queue_counts) (void)hipFree(ctx->queue_counts);  // also holds the bitmaps
     void* rsp[] = {ctx->rs_flags, ctx->rs_cand, ctx->rs_block, ctx->rs_M, ctx->rs_S, ctx->rs_sample, ctx->rs_sp,
-                   ctx->rs_counts, ctx->rs_inl, ctx->rs_res, ctx->sem_img, ctx->sem_coeffs, ctx->sem_res};
+                   ctx->rs_counts, ctx->rs_inl, ctx->rs_res, ctx->sem_img, ctx->sem_coeffs, ctx->sem_res, ctx->sem_groups};
     for (void* p : rsp)
         if (p) (void)hipFree(p);
     if (ctx->trkb) (void)hipFree(ctx->trkb);
@@ -1309,7 +1316,7 @@ int mld_estimate_ground_plane(mld_ctx* ctx, int slot, uint32_t seed, float coeff
         hipLaunchKernelGGL(k_rs_flags, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, s.d.cloud, n,
                            s.d.stride, (float)P.ransac_plane_min_z, (float)P.ransac_plane_max_z, ctx->rs_flags);
         hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(kScanBlock), 0, ctx->stream, ctx->rs_flags, n, ctx->rs_block);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, ctx->stream, ctx->rs_block, nb, ctx->rs_M);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kScanBlock), 0, ctx->stream, ctx->rs_block, nb, ctx->rs_M);
         hipLaunchKernelGGL(k_rs_compact, dim3(nb), dim3(kScanBlock), 0, ctx->stream, ctx->rs_flags, n, ctx->rs_block,
                            ctx->rs_cand);
     }
@@ -1343,10 +1350,12 @@ int mld_estimate_ground_plane(mld_ctx* ctx, int slot, uint32_t seed, float coeff
     return MLD_OK;
 }
 
-// SemanticPlane::CalculateInliersPlane (RansacPlane.cpp:195-274) for the slot's cloud, asynchronous part: the launches
-// that leave coefficients / counts / status in ctx->sem_res and the inlier bitmask in s.mask_buf, on stream `st`.
+// SemanticPlane::CalculateInliersPlane (RansacPlane.cpp:195-274) for the slot's cloud, asynchronous part: four launches
+// on stream `st` that leave coefficients / counts / status in ctx->sem_res, the inlier bitmask in s.mask_buf and - with
+// pd - the plane in device memory.
 static int semantic_plane_launch(mld_ctx* ctx, Slot& s, const unsigned char* img_dev, int rows, int cols, int row_stride,
-                                 const int32_t* labels, int n_labels, double inlier_threshold, hipStream_t st) {
+                                 const int32_t* labels, int n_labels, double inlier_threshold, hipStream_t st,
+                                 PlaneDev* pd = nullptr, PlaneDev* pd_copy = nullptr) {
     using namespace ransac;
     const long long n = s.d.n;
     LabelSet ls{};
@@ -1357,28 +1366,18 @@ static int semantic_plane_launch(mld_ctx* ctx, Slot& s, const unsigned char* img
     sc.f = ctx->cam.focal_length;
     sc.cu = ctx->cam.principal_point_x;
     sc.cv = ctx->cam.principal_point_y;
-    const size_t words = (size_t)((n + 31) / 32);
-    const int nb = (int)((n + kScanBlock - 1) / kScanBlock);
     const dim3 gp((unsigned)((n + 255) / 256)), bp(256);
-    auto compact = [&]() {
-        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(kScanBlock), 0, st, ctx->rs_flags, n, ctx->rs_block);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(64), 0, st, ctx->rs_block, nb, ctx->rs_M);
-        hipLaunchKernelGGL(k_rs_compact, dim3(nb), dim3(kScanBlock), 0, st, ctx->rs_flags, n, ctx->rs_block, ctx->rs_cand);
-    };
+    const int G = (int)((n + kWave - 1) / kWave);
+    GroupSums* gs = reinterpret_cast<GroupSums*>(ctx->sem_groups);
+    unsigned long long* inl = reinterpret_cast<unsigned long long*>(s.mask_buf);
     // candidates by label, first fit
-    hipLaunchKernelGGL(k_sem_flags, gp, bp, 0, st, s.d.cloud, n, s.d.stride, sc, img_dev, rows, cols, row_stride, ls,
-                       ctx->rs_flags);
-    compact();
-    hipLaunchKernelGGL(k_ls_fit, dim3(1), dim3(kPartials), 0, st, s.d.cloud, s.d.stride, ctx->rs_cand, ctx->rs_M,
-                       ctx->sem_coeffs, ctx->sem_coeffs + 4, 3, 0, ctx->sem_res);
-    // re-selection over the whole cloud, second fit, inlier mask
-    hipLaunchKernelGGL(k_sem_select, gp, bp, 0, st, s.d.cloud, n, s.d.stride, ctx->sem_coeffs + 4, inlier_threshold,
-                       ctx->rs_flags);
-    compact();
-    hipLaunchKernelGGL(k_ls_fit, dim3(1), dim3(kPartials), 0, st, s.d.cloud, s.d.stride, ctx->rs_cand, ctx->rs_M,
-                       ctx->sem_coeffs + 4, ctx->sem_coeffs + 8, 0, 1, ctx->sem_res);
-    hipLaunchKernelGGL(k_mask_from_flags, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, ctx->rs_flags, n,
-                       s.mask_buf);
+    hipLaunchKernelGGL(k_sem_candidates, gp, bp, 0, st, s.d.cloud, n, s.d.stride, sc, img_dev, rows, cols, row_stride, ls, gs);
+    hipLaunchKernelGGL(k_sem_fit, dim3(1), dim3(kPartials), 0, st, gs, G, ctx->sem_coeffs, ctx->sem_coeffs + 4, 3, 0,
+                       ctx->sem_res, (PlaneDev*)nullptr, (PlaneDev*)nullptr, 0.f, 0.f, 0.f);
+    // re-selection over the whole cloud (its ballots are the inlier mask), second fit
+    hipLaunchKernelGGL(k_sem_select, gp, bp, 0, st, s.d.cloud, n, s.d.stride, ctx->sem_coeffs + 4, inlier_threshold, inl, gs);
+    hipLaunchKernelGGL(k_sem_fit, dim3(1), dim3(kPartials), 0, st, gs, G, ctx->sem_coeffs + 4, ctx->sem_coeffs + 8, 0, 1,
+                       ctx->sem_res, pd, pd_copy, ctx->calib.far_elin, ctx->calib.far_econst, ctx->calib.roadDistThrF);
     HIP_TRY(ctx, hipGetLastError());
     return MLD_OK;
 }
@@ -1394,9 +1393,10 @@ static int semantic_plane_scratch(mld_ctx* ctx, Slot& s) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->sem_coeffs, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-    if (!ctx->rs_M) HIP_TRY(ctx, hipMalloc((void**)&ctx->rs_M, sizeof(int32_t)));
-    if ((rc = ensure_scan_buffers(ctx, s.d.n))) return rc;
-    return grow(ctx, s.mask_buf, s.mask_words, (size_t)((s.d.n + 31) / 32));
+    // per 64 points: the group's moment sums (40 bytes) and one 64-bit word of the inlier mask
+    const size_t groups = (size_t)((s.d.n + 63) / 64);
+    if ((rc = grow(ctx, ctx->sem_groups, ctx->sem_groups_cap, groups * sizeof(GroupSums)))) return rc;
+    return grow(ctx, s.mask_buf, s.mask_words, groups * 2);
 }
 
 static int semantic_plane_core(mld_ctx* ctx, Slot& s, const unsigned char* img_dev, int rows, int cols, int row_stride,
@@ -1683,8 +1683,12 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
         const size_t cap = total + total / 2;
         HIP_TRY(ctx, hipHostMalloc((void**)&ctx->fr_host, cap, hipHostMallocDefault));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->fr_dev, cap));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&ctx->fr_host_dev, ctx->fr_host, 0));
         ctx->fr_cap = cap;
     }
+    // Results (depths, types, the estimated plane: 24 KB for 2000 features) are written by the kernels straight into the
+    // pinned host block: no copy node between the last kernel and the synchronisation (a 24 KB DMA is 15 us of latency)
+    unsigned char* const out_base = ctx->fr_zero_copy ? ctx->fr_host_dev : ctx->fr_dev;
     const size_t bytes = (size_t)n * (size_t)stride_bytes;
     if ((rc = grow(ctx, s.cloud_buf, s.cloud_cap, bytes))) return rc;
     // inlier bitmask of the slot; the one-block RANSAC also keeps its 64-bit pass-through group masks there (even word count)
@@ -1737,7 +1741,7 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
     if (bytes) HIP_TRY(ctx, hipMemcpyAsync(s.cloud_buf, pts_host, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->fr_ev[1], ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
-    PlaneDev* pd_copy = reinterpret_cast<PlaneDev*>(ctx->fr_dev + off_plane);
+    PlaneDev* pd_copy = reinterpret_cast<PlaneDev*>(out_base + off_plane);
     if (kind == FramePlane::SUPPLIED) {
         set_plane_coeffs(ctx, s, fp.coeffs);
         s.d.inlier_mask = s.mask_buf;
@@ -1758,11 +1762,8 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
             HIP_TRY(ctx, hipGetLastError());
         } else {
             if ((rc = semantic_plane_launch(ctx, s, ctx->sem_img, rq->rows, rq->cols, rq->row_stride_bytes, rq->ground_labels,
-                                            rq->n_labels, rq->inlier_threshold, ctx->stream)))
+                                            rq->n_labels, rq->inlier_threshold, ctx->stream, pd, pd_copy)))
                 return rc;
-            hipLaunchKernelGGL(k_sem_finish, dim3(1), dim3(1), 0, ctx->stream, ctx->sem_res, pd, pd_copy, ctx->calib.far_elin,
-                               ctx->calib.far_econst, ctx->calib.roadDistThrF);
-            HIP_TRY(ctx, hipGetLastError());
         }
         s.d.mask_in_key = 1;
         s.d.plane_dev = pd;
@@ -1771,14 +1772,14 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
     }
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->fr_ev[2], ctx->stream));
     if ((rc = launch_project(ctx, 1, n, true, slot))) return rc;
-    double* d_depth = reinterpret_cast<double*>(ctx->fr_dev + off_depth);
-    int32_t* d_type = reinterpret_cast<int32_t*>(ctx->fr_dev + off_type);
+    double* d_depth = reinterpret_cast<double*>(out_base + off_depth);
+    int32_t* d_type = reinterpret_cast<int32_t*>(out_base + off_type);
     if (F > 0) rc = calc_one(ctx, slot, reinterpret_cast<const double*>(ctx->fr_dev + off_uv), F, d_depth, d_type);
     if (rc == MLD_OK) {
         hipError_t e = hipSuccess;
         if (timed) e = hipEventRecord(ctx->fr_ev[3], ctx->stream);
         const size_t out_bytes = (estimate ? off_plane + sizeof(PlaneDev) : off_type + (size_t)F * sizeof(int32_t)) - off_depth;
-        if (e == hipSuccess && out_bytes)
+        if (e == hipSuccess && out_bytes && !ctx->fr_zero_copy)
             e = hipMemcpyAsync(ctx->fr_host + off_depth, d_depth, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess && timed) e = hipEventRecord(ctx->fr_ev[4], ctx->stream);
         const double t_enq = now_us();

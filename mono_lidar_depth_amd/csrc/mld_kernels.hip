@@ -2764,17 +2764,35 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_block_sums(const int32_t* _
         block_sums[blockIdx.x] = t;
     }
 }
-__global__ void k_scan_sums(int32_t* block_sums, int n_blocks, int32_t* total) {
-    // one thread: n_blocks <= 16384 for 16.7 M points; debug path only
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        int acc = 0;
-        for (int b = 0; b < n_blocks; b++) {
-            int t = block_sums[b];
-            block_sums[b] = acc;
+// Exclusive scan of the block sums in place + their total, by ONE block of kScanBlock threads (n_blocks <= 16384 for
+// 16.7 M points): a thread owns a run of consecutive entries, the runs' totals are scanned across the block.  (A single
+// thread walking the array - a dependent global load and store per entry - took 60 us for the 128 blocks of a 131 072-point
+// cloud, twice per semantic plane.)
+__global__ __launch_bounds__(kScanBlock) void k_scan_sums(int32_t* block_sums, int n_blocks, int32_t* total) {
+    __shared__ int wsum[kScanBlock / kWave];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), w = tid / kWave;
+    const int per = (n_blocks + kScanBlock - 1) / kScanBlock;
+    const int b0 = tid * per;
+    int loc = 0;
+    for (int q = 0; q < per; q++)
+        if (b0 + q < n_blocks) loc += block_sums[b0 + q];
+    int incl = loc;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == kWave - 1) wsum[w] = incl;
+    __syncthreads();
+    int acc = incl - loc;
+    for (int q = 0; q < w; q++) acc += wsum[q];
+    for (int q = 0; q < per; q++)
+        if (b0 + q < n_blocks) {
+            const int t = block_sums[b0 + q];
+            block_sums[b0 + q] = acc;
             acc += t;
         }
-        *total = acc;
-    }
+    if (tid == kScanBlock - 1) *total = acc;
 }
 // rank[i] = visible index of point i (valid where vis[i]); also emits the compacted lists.
 __global__ __launch_bounds__(kScanBlock) void k_scan_final(const int32_t* __restrict__ vis, long long n,

@@ -919,53 +919,132 @@ struct SemResult {
     int32_t pad_;
 };
 
+// Four launches, no index lists and no host round trip: (1) candidates by label, (2) first fit, (3) selection over the
+// whole cloud - its ballots ARE the slot's inlier bitmask -, (4) second fit + the plane as the other kernels consume it.
+// The least-squares fits (optimizeModelCoefficients = computeMeanAndCovarianceMatrix, float accumulators) never see an
+// index list: the kernels that decide membership also reduce the nine moment terms of their members per GROUP of 64
+// consecutive cloud points (non-members contribute +0.0f, which leaves a float sum unchanged; a fixed binary tree over the
+// 64 positions - strides 32, 16, ..., 1), and the fit kernel adds the group sums, in group order, into 256 interleaved
+// partials (group g -> partial g % 256) that are combined in index order.  PCL adds the members one after the other;
+// neither order is the other's (parity unpinned, as stated in mld.h) - this one is the same in the CPU restatement the tests
+// compare with and on the GPU, bit for bit, and needs no ordered compaction.
+struct GroupSums {
+    float s[9];  // xx, xy, xz, yy, yz, zz, x, y, z of the group's members
+    int count;   // members
+};
+
+// the nine terms of a member (zeros for a non-member) reduced over the wavefront's 64 points; lane 0 stores them
+__device__ inline void sem_group_reduce(bool member, float x, float y, float z, GroupSums* __restrict__ out, long long g,
+                                        bool store) {
+    float a[9];
+    a[0] = member ? x * x : 0.0f;
+    a[1] = member ? x * y : 0.0f;
+    a[2] = member ? x * z : 0.0f;
+    a[3] = member ? y * y : 0.0f;
+    a[4] = member ? y * z : 0.0f;
+    a[5] = member ? z * z : 0.0f;
+    a[6] = member ? x : 0.0f;
+    a[7] = member ? y : 0.0f;
+    a[8] = member ? z : 0.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int t = 0; t < 9; t++) a[t] = a[t] + __shfl_xor(a[t], o);  // (commutative: every lane holds the tree's value)
+    const int cnt = (int)__popcll(__ballot(member));
+    if (store && (threadIdx.x & (kWave - 1)) == 0) {
+        GroupSums r;
+#pragma unroll
+        for (int t = 0; t < 9; t++) r.s[t] = a[t];
+        r.count = cnt;
+        out[g] = r;
+    }
+}
+
 // :198-221  pcl::transformPointCloud (double arithmetic, float result), project() (K * p as Eigen evaluates a
 // 3x3 * 3x1 product: x0 + (x1 + x2); p /= p[2]; cv::Point truncation), image bounds, label lookup.  The pixels
 // x == cols / y == rows the reference reads out of bounds count as unlabeled; non-finite projections as invalid.
-__global__ void k_sem_flags(const unsigned char* cloud, long long n, int stride, SemCalib sc, const unsigned char* img,
-                            int rows, int cols, int row_stride, LabelSet ls, int32_t* flags) {
+__global__ __launch_bounds__(256) void k_sem_candidates(const unsigned char* cloud, long long n, int stride, SemCalib sc,
+                                                        const unsigned char* img, int rows, int cols, int row_stride,
+                                                        LabelSet ls, GroupSums* __restrict__ gs) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* q = reinterpret_cast<const float*>(cloud + (size_t)i * stride);
-    const double x = q[0], y = q[1], z = q[2];
-    const float xc = (float)(((sc.T[0] * x + sc.T[1] * y) + sc.T[2] * z) + sc.T[3]);
-    const float yc = (float)(((sc.T[4] * x + sc.T[5] * y) + sc.T[6] * z) + sc.T[7]);
-    const float zc = (float)(((sc.T[8] * x + sc.T[9] * y) + sc.T[10] * z) + sc.T[11]);
-    const double px = (double)xc, py = (double)yc, pz = (double)zc;
-    const double p0 = sc.f * px + (0.0 * py + sc.cu * pz);
-    const double p1 = 0.0 * px + (sc.f * py + sc.cv * pz);
-    const double p2 = 0.0 * px + (0.0 * py + 1.0 * pz);
-    const double u = p0 / p2, v = p1 / p2;
-    int flag = 0;
-    if (isfinite(u) && isfinite(v) && fabs(u) < 2147483648.0 && fabs(v) < 2147483648.0) {
-        const int ix = (int)u, iy = (int)v;
-        if (ix >= 0 && ix < cols && iy >= 0 && iy < rows) {
-            const unsigned l = img[(size_t)iy * row_stride + ix];
-            flag = (ls.w[l >> 5] >> (l & 31)) & 1u;
+    bool flag = false;
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    if (i < n) {
+        const float* q = reinterpret_cast<const float*>(cloud + (size_t)i * stride);
+        fx = q[0];
+        fy = q[1];
+        fz = q[2];
+        const double x = fx, y = fy, z = fz;
+        const float xc = (float)(((sc.T[0] * x + sc.T[1] * y) + sc.T[2] * z) + sc.T[3]);
+        const float yc = (float)(((sc.T[4] * x + sc.T[5] * y) + sc.T[6] * z) + sc.T[7]);
+        const float zc = (float)(((sc.T[8] * x + sc.T[9] * y) + sc.T[10] * z) + sc.T[11]);
+        const double px = (double)xc, py = (double)yc, pz = (double)zc;
+        const double p0 = sc.f * px + (0.0 * py + sc.cu * pz);
+        const double p1 = 0.0 * px + (sc.f * py + sc.cv * pz);
+        const double p2 = 0.0 * px + (0.0 * py + 1.0 * pz);
+        const double u = p0 / p2, v = p1 / p2;
+        if (isfinite(u) && isfinite(v) && fabs(u) < 2147483648.0 && fabs(v) < 2147483648.0) {
+            const int ix = (int)u, iy = (int)v;
+            if (ix >= 0 && ix < cols && iy >= 0 && iy < rows) {
+                const unsigned l = img[(size_t)iy * row_stride + ix];
+                flag = (ls.w[l >> 5] >> (l & 31)) & 1u;
+            }
         }
     }
-    flags[i] = flag;
+    const long long i0 = i - (long long)(threadIdx.x & (kWave - 1));  // the wavefront's first point
+    sem_group_reduce(flag, fx, fy, fz, gs, i0 >> 6, i0 < n);
 }
 
-// SampleConsensusModelPlane::selectWithinDistance over the whole cloud (:252), float distance < double threshold
-__global__ void k_sem_select(const unsigned char* cloud, long long n, int stride, const float* __restrict__ coeffs,
-                             double thr, int32_t* flags) {
+// SampleConsensusModelPlane::selectWithinDistance over the whole cloud (:252), float distance < double threshold.  The
+// ballots ARE the slot's inlier bitmask (bit i of 32-bit word i / 32).
+__global__ __launch_bounds__(256) void k_sem_select(const unsigned char* cloud, long long n, int stride,
+                                                    const float* __restrict__ coeffs, double thr,
+                                                    unsigned long long* __restrict__ gm, GroupSums* __restrict__ gs) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float c[4] = {coeffs[0], coeffs[1], coeffs[2], coeffs[3]};
-    const float* q = reinterpret_cast<const float*>(cloud + (size_t)i * stride);
-    flags[i] = ((double)plane_dist(c, q) < thr) ? 1 : 0;
+    bool flag = false;
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    if (i < n) {
+        const float c[4] = {coeffs[0], coeffs[1], coeffs[2], coeffs[3]};
+        const float* q = reinterpret_cast<const float*>(cloud + (size_t)i * stride);
+        fx = q[0];
+        fy = q[1];
+        fz = q[2];
+        flag = (double)plane_dist(c, q) < thr;
+    }
+    const unsigned long long m = __ballot(flag);
+    const long long i0 = i - (long long)(threadIdx.x & (kWave - 1));
+    if ((threadIdx.x & (kWave - 1)) == 0 && i0 < n) gm[i0 >> 6] = m;
+    sem_group_reduce(flag, fx, fy, fz, gs, i0 >> 6, i0 < n);
 }
 
-// optimizeModelCoefficients over the cloud points idx[0..*m_dev): fewer than 4 entries return `fallback`.
-// One block of kPartials threads; thread p owns entries p, p+256, ...; partials combined in index order.
-// Also records the entry count (and the < min_count failure) in the result.
-__global__ __launch_bounds__(kPartials) void k_ls_fit(const unsigned char* cloud, int stride, const int32_t* __restrict__ idx,
-                                                     const int32_t* __restrict__ m_dev, const float* __restrict__ fallback,
-                                                     float* __restrict__ out, int min_count, int stage, SemResult* res) {
+// optimizeModelCoefficients from the group sums (see above): fewer than 4 members return `fallback`.  ONE block of 256
+// threads.  stage 0: the candidates' fit (records their number; fewer than min_count = ExceptionPclInvalid, :224-227).
+// stage 1: the refit on the selected points (records the inlier count) and, with pd, the plane as the projection and the
+// feature kernels consume it (what set_plane_coeffs prepares on the host for a plane that was read back): coefficients,
+// M-estimator prior (DepthEstimator.cpp:286-292), margins of the projection's far test; copy_out as in k_rs_batch.
+__global__ __launch_bounds__(kPartials) void k_sem_fit(const GroupSums* __restrict__ gs, int G,
+                                                       const float* __restrict__ fallback, float* __restrict__ out,
+                                                       int min_count, int stage, SemResult* res, PlaneDev* pd,
+                                                       PlaneDev* copy_out, float far_elin, float far_econst, float far_thr) {
     __shared__ float acc[kPartials][9];
+    __shared__ float s9s[9];
+    __shared__ int wcnt[kPartials / kWave];
     const int tid = threadIdx.x;
-    const int m = *m_dev;
+    float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int cnt = 0;
+    for (int g = tid; g < G; g += kPartials) {
+        const GroupSums r = gs[g];
+#pragma unroll
+        for (int t = 0; t < 9; t++) a[t] += r.s[t];
+        cnt += r.count;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((tid & (kWave - 1)) == 0) wcnt[tid / kWave] = cnt;
+    for (int t = 0; t < 9; t++) acc[tid][t] = a[t];
+    __syncthreads();
+    int m = 0;
+    for (int q = 0; q < kPartials / kWave; q++) m += wcnt[q];
     if (tid == 0) {
         if (stage == 0) {
             res->n_candidates = m;
@@ -974,88 +1053,58 @@ __global__ __launch_bounds__(kPartials) void k_ls_fit(const unsigned char* cloud
             res->n_inliers = m;
         }
     }
-    if (m < 4) {
-        if (tid < 4) out[tid] = fallback[tid];
-        if (stage == 1 && tid < 4) res->coeffs[tid] = fallback[tid];
-        return;
+    // the 256 partials of each sum combined in index order, by nine lanes side by side
+    if (tid < 9) {
+        float sum = 0.0f;
+#pragma unroll 16
+        for (int p = 0; p < kPartials; p++) sum += acc[p][tid];
+        s9s[tid] = sum / (float)m;
     }
-    float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int q = tid; q < m; q += kPartials) {
-        const float* v = reinterpret_cast<const float*>(cloud + (size_t)idx[q] * stride);
-        a[0] += v[0] * v[0];
-        a[1] += v[0] * v[1];
-        a[2] += v[0] * v[2];
-        a[3] += v[1] * v[1];
-        a[4] += v[1] * v[2];
-        a[5] += v[2] * v[2];
-        a[6] += v[0];
-        a[7] += v[1];
-        a[8] += v[2];
-    }
-    for (int t = 0; t < 9; t++) acc[tid][t] = a[t];
     __syncthreads();
-    if (tid == 0) {
+    if (tid != 0) return;
+    float c4[4] = {fallback[0], fallback[1], fallback[2], fallback[3]};
+    if (m >= 4) {
         float s9[9];
-        for (int t = 0; t < 9; t++) {
-            float sum = 0.0f;
-            for (int p = 0; p < kPartials; p++) sum += acc[p][t];
-            s9[t] = sum / (float)m;
-        }
-        float cov[6] = {s9[0] - s9[6] * s9[6], s9[1] - s9[6] * s9[7], s9[2] - s9[6] * s9[8],
-                        s9[3] - s9[7] * s9[7], s9[4] - s9[7] * s9[8], s9[5] - s9[8] * s9[8]};
+        for (int t = 0; t < 9; t++) s9[t] = s9s[t];
+        const float cov[6] = {s9[0] - s9[6] * s9[6], s9[1] - s9[6] * s9[7], s9[2] - s9[6] * s9[8],
+                              s9[3] - s9[7] * s9[7], s9[4] - s9[7] * s9[8], s9[5] - s9[8] * s9[8]};
         double sd[6] = {cov[0], cov[1], cov[2], cov[3], cov[4], cov[5]}, n0[3];
         rs_smallest_eigvec(sd, n0);
         const float e0 = (float)n0[0], e1 = (float)n0[1], e2 = (float)n0[2];
-        const float c[4] = {e0, e1, e2, -1.0f * (e0 * s9[6] + e1 * s9[7] + e2 * s9[8])};
-        for (int t = 0; t < 4; t++) {
-            out[t] = c[t];
-            if (stage == 1) res->coeffs[t] = c[t];
+        c4[0] = e0;
+        c4[1] = e1;
+        c4[2] = e2;
+        c4[3] = -1.0f * (e0 * s9[6] + e1 * s9[7] + e2 * s9[8]);
+    }
+    for (int t = 0; t < 4; t++) {
+        out[t] = c4[t];
+        if (stage == 1) res->coeffs[t] = c4[t];
+    }
+    if (stage == 1 && pd) {
+        const int ok = res->status == 0;
+        for (int t = 0; t < 4; t++) pd->coeffs[t] = c4[t];
+        double na = (double)c4[0], nb = (double)c4[1], nc = (double)c4[2];
+        const double z = na * na + (nb * nb + nc * nc);
+        if (z > 0.0) {
+            const double nrm = sqrt(z);
+            na /= nrm;
+            nb /= nrm;
+            nc /= nrm;
         }
+        pd->prior_n[0] = na;
+        pd->prior_n[1] = nb;
+        pd->prior_n[2] = nc;
+        pd->prior_off = (double)c4[3];
+        far_margins(c4, far_elin, far_econst, far_thr, pd->far_mg0, pd->far_mg1);
+        pd->n_inliers = ok ? m : 0;
+        pd->iterations = 0;
+        pd->best_draw = -1;
+        pd->best_count = res->n_candidates;
+        pd->S = res->n_candidates;
+        pd->status = ok ? 0 : 1;
+        pd->has_plane = ok;
+        if (copy_out) *copy_out = *pd;
     }
-}
-
-// The semantic plane as the projection and the feature kernels consume it (what set_plane_coeffs prepares on the host for
-// a plane that was read back): coefficients, M-estimator prior (DepthEstimator.cpp:286-292), margins of the projection's
-// far test.  One thread; `copy_out` as in k_rs_batch.
-__global__ void k_sem_finish(const SemResult* __restrict__ res, PlaneDev* pd, PlaneDev* copy_out, float far_elin,
-                             float far_econst, float far_thr) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    const float co[4] = {res->coeffs[0], res->coeffs[1], res->coeffs[2], res->coeffs[3]};
-    const int ok = res->status == 0;
-    for (int t = 0; t < 4; t++) pd->coeffs[t] = co[t];
-    double a = (double)co[0], b = (double)co[1], cc = (double)co[2];
-    const double z = a * a + (b * b + cc * cc);
-    if (z > 0.0) {
-        const double nrm = sqrt(z);
-        a /= nrm;
-        b /= nrm;
-        cc /= nrm;
-    }
-    pd->prior_n[0] = a;
-    pd->prior_n[1] = b;
-    pd->prior_n[2] = cc;
-    pd->prior_off = (double)co[3];
-    far_margins(co, far_elin, far_econst, far_thr, pd->far_mg0, pd->far_mg1);
-    pd->n_inliers = ok ? res->n_inliers : 0;
-    pd->iterations = 0;
-    pd->best_draw = -1;
-    pd->best_count = res->n_candidates;
-    pd->S = res->n_candidates;
-    pd->status = ok ? 0 : 1;
-    pd->has_plane = ok;
-    if (copy_out) *copy_out = *pd;
-}
-
-// inlier bitmask from per-point flags: one word per thread
-__global__ void k_mask_from_flags(const int32_t* __restrict__ flags, long long n, uint32_t* __restrict__ mask) {
-    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w * 32 >= n) return;
-    uint32_t bits = 0;
-    for (int b = 0; b < 32; b++) {
-        const long long i = w * 32 + b;
-        if (i < n && flags[i]) bits |= 1u << b;
-    }
-    mask[w] = bits;
 }
 
 }  // namespace ransac

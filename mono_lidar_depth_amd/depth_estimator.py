@@ -77,6 +77,8 @@ class RansacPlane(GroundPlane):
         self.coeffs = None
         self.inliers = None
         self.seed = int(seed)
+        self.n_inliers = None   # inlier count / RANSAC iterations reported by the one-call frame path
+        self.iterations = None
         self._segmented = False
         self._owner = None
 
@@ -518,22 +520,62 @@ class DepthEstimator:
         return (depth, types) if return_types else depth
 
     def _frame_call(self, cloud, uv, gp, slot, uv_layout=None):
-        """CalculateDepth(cloud, uv, groundPlane) entirely from host memory with a plane that needs no estimation: the
-        single-call entry point mld_calculate_depth_frame (one frame per call, the ROS usage).  None: not applicable."""
+        """CalculateDepth(cloud, uv, groundPlane) entirely from host memory as ONE C call (one frame per call, the ROS
+        usage): mld_calculate_depth_frame for a plane that needs no estimation, mld_calculate_depth_frame_estimate for a
+        RansacPlane / SemanticPlane that is not segmented yet - the reference's production call
+        (tracklet_depth_module.cpp:269-284): the plane is estimated on the GPU ahead of the projection, nothing returns
+        to the host before the depths do, and the plane object's inlier list is fetched only when asked for.
+        None: not applicable (debug mode, device inputs)."""
         self._require_init("CalculateDepth")
         if self._debug or _is_torch_cuda(cloud) or _is_torch_cuda(uv):
             return None
         road = bool(self._parameters.do_use_ransac_plane)
+        estimate = False
+        if road and gp is None:
+            gp = RansacPlane()  # the reference creates one for a null pointer (DepthEstimator.cpp:275-278)
         if road and gp is not NO_PLANE:
-            if gp is None or not isinstance(gp, GroundPlane) or not gp.isSegmented() or _is_torch_cuda(gp.inliers):
+            if isinstance(gp, RansacPlane) and not gp.isSegmented():
+                estimate = True
+                if isinstance(gp, SemanticPlane) and _is_torch_cuda(gp.img):
+                    return None
+            elif not isinstance(gp, GroundPlane) or not gp.isSegmented() or _is_torch_cuda(gp.inliers):
                 return None
-            if isinstance(gp, RansacPlane) and gp.inliers is None:
-                return None
+            elif isinstance(gp, RansacPlane) and gp.inliers is None:
+                gp.getInlinersIndex()  # (estimated earlier, list not fetched yet)
+                if gp.inliers is None:
+                    return None
         ptr, n, stride, keep = self._cloud_view(cloud)
         uvh = self._uv_host(uv, uv_layout)
         F = int(uvh.size // 2)
         depth = np.empty(F, dtype=np.float64)
         types = np.empty(F, dtype=np.int32)
+        if estimate:
+            req = capi.MldPlaneRequest()
+            req.kind, req.seed = capi.MLD_PLANE_RANSAC, gp.seed & 0xFFFFFFFF
+            hold = None
+            if isinstance(gp, SemanticPlane):
+                img = np.ascontiguousarray(gp.img, dtype=np.uint8)
+                if img.ndim != 2:
+                    raise DepthEstimatorError(capi.MLD_ERR_INVALID_ARG, "label image must be 2-D")
+                lab = np.ascontiguousarray(gp.groundplane_label, dtype=np.int32)
+                hold = (img, lab)
+                req.kind = capi.MLD_PLANE_SEMANTIC
+                req.label_image, req.rows, req.cols, req.row_stride_bytes = img.ctypes.data, img.shape[0], img.shape[1], img.strides[0]
+                req.ground_labels, req.n_labels = lab.ctypes.data, lab.size
+                req.inlier_threshold = gp.inlier_threshold
+            res = capi.MldPlaneResult()
+            self._check(self._lib.mld_calculate_depth_frame_estimate(self._ctx, slot, ptr, n, stride, C.byref(req),
+                                                                     uvh.ctypes.data, F, depth.ctypes.data,
+                                                                     types.ctypes.data, C.byref(res)))
+            del hold
+            gp.coeffs = np.array(list(res.coeffs), dtype=np.float32)
+            gp.inliers = None  # fetched on demand (getInlinersIndex)
+            gp.n_inliers = int(res.n_inliers)
+            gp.iterations = int(res.iterations)
+            gp._segmented = True
+            gp._owner = (self, slot)
+            self._last_types = types
+            return depth, types
         if road and gp is not NO_PLANE:
             coeffs = (C.c_float * 4)(*[float(x) for x in gp.coeffs])
             inl = np.ascontiguousarray(gp.inliers, dtype=np.int32)
@@ -703,6 +745,13 @@ class DepthEstimator:
         return out
 
     # ------------------------------------------------------------------ measurement hooks
+    def frameTiming(self) -> dict:
+        """Phases of the last one-frame call in microseconds (mld_frame_timing; needs timingEnable(True))."""
+        out = (C.c_double * 8)()
+        self._check(self._lib.mld_frame_timing(self._ctx, out))
+        keys = ("h2d_us", "plane_us", "kernels_us", "d2h_us", "api_us", "wait_us", "total_us", "gpu_us")
+        return {k: float(v) for k, v in zip(keys, out)}
+
     def timingEnable(self, on: bool = True):
         self._check(self._lib.mld_timing_enable(self._ctx, 1 if on else 0))
 

@@ -1156,29 +1156,52 @@ int orc_estimate_ground_plane(orc_frame* h, const void* pts_v, int64_t n, int st
 }
 
 // SampleConsensusModelPlane::optimizeModelCoefficients (PCL sac_model_plane.hpp, restated in SURVEY.md §9) over the
-// cloud points idx[0..m): computeMeanAndCovarianceMatrix with float accumulators (partial p takes the entries
-// q = p, p+256, ... and the partials are combined in index order — the association the HIP kernel uses), smallest
-// eigenvector of the covariance, d = -n.centroid.  Fewer than 4 entries: `fallback` is returned.
-static void ls_plane_fit(const uint8_t* pts, int stride, const int32_t* idx, size_t m, const float fallback[4], float out[4]) {
+// cloud points whose `member` flag is set: computeMeanAndCovarianceMatrix with float accumulators, smallest eigenvector of
+// the covariance, d = -n.centroid.  Fewer than 4 members: `fallback` is returned.  PCL adds the members one after the
+// other; the association here is the one the HIP kernels use (mld_ransac.hip, k_sem_candidates / k_sem_select /
+// k_sem_fit; parity with PCL's order is unpinned either way): the nine moment terms of the members of every GROUP of 64
+// consecutive cloud points are summed by a fixed binary tree over the 64 positions (non-members and positions beyond the
+// cloud contribute +0.0f; strides 32, 16, ..., 1), the group sums are added, in group order, into 256 interleaved
+// partials (group g -> partial g % 256), and the partials are combined in index order.
+static void ls_plane_fit(const uint8_t* pts, int stride, int64_t n, const std::vector<uint8_t>& member, const float fallback[4],
+                         float out[4], size_t* m_out = nullptr) {
     using namespace ransac;
     for (int t = 0; t < 4; t++) out[t] = fallback[t];
-    if (m < 4) return;
     std::vector<float> acc(static_cast<size_t>(kPartials) * 9, 0.0f);
-    for (int p = 0; p < kPartials; p++) {
-        float* a = &acc[static_cast<size_t>(p) * 9];
-        for (size_t q = p; q < m; q += kPartials) {
-            const float* v = reinterpret_cast<const float*>(pts + static_cast<int64_t>(idx[q]) * stride);
-            a[0] += v[0] * v[0];
-            a[1] += v[0] * v[1];
-            a[2] += v[0] * v[2];
-            a[3] += v[1] * v[1];
-            a[4] += v[1] * v[2];
-            a[5] += v[2] * v[2];
-            a[6] += v[0];
-            a[7] += v[1];
-            a[8] += v[2];
+    size_t m = 0;
+    const int64_t G = (n + 63) / 64;
+    for (int64_t g = 0; g < G; g++) {
+        float tree[64][9];
+        for (int l = 0; l < 64; l++) {
+            const int64_t i = g * 64 + l;
+            const bool in = i < n && member[static_cast<size_t>(i)];
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (in) {
+                const float* v = reinterpret_cast<const float*>(pts + i * stride);
+                x = v[0];
+                y = v[1];
+                z = v[2];
+                m++;
+            }
+            float* a = tree[l];
+            a[0] = in ? x * x : 0.0f;
+            a[1] = in ? x * y : 0.0f;
+            a[2] = in ? x * z : 0.0f;
+            a[3] = in ? y * y : 0.0f;
+            a[4] = in ? y * z : 0.0f;
+            a[5] = in ? z * z : 0.0f;
+            a[6] = in ? x : 0.0f;
+            a[7] = in ? y : 0.0f;
+            a[8] = in ? z : 0.0f;
         }
+        for (int o = 32; o > 0; o >>= 1)
+            for (int l = 0; l < o; l++)
+                for (int t = 0; t < 9; t++) tree[l][t] = tree[l][t] + tree[l + o][t];
+        float* a = &acc[static_cast<size_t>(g % kPartials) * 9];
+        for (int t = 0; t < 9; t++) a[t] += tree[0][t];
     }
+    if (m_out) *m_out = m;
+    if (m < 4) return;
     float a[9];
     for (int t = 0; t < 9; t++) {
         a[t] = 0.0f;
@@ -1220,7 +1243,8 @@ int orc_estimate_semantic_plane(orc_frame* h, const void* pts_v, int64_t n, int 
     bool is_ground[256] = {false};
     for (int i = 0; i < n_labels; i++)
         if (labels[i] >= 0 && labels[i] < 256) is_ground[labels[i]] = true;
-    std::vector<int32_t> cand;
+    std::vector<uint8_t> cand(static_cast<size_t>(n), 0);
+    size_t n_cand = 0;
     for (int64_t i = 0; i < n; i++) {
         const float* q = reinterpret_cast<const float*>(pts + i * stride);
         const double x = q[0], y = q[1], z = q[2];
@@ -1236,18 +1260,25 @@ int orc_estimate_semantic_plane(orc_frame* h, const void* pts_v, int64_t n, int 
         const int ix = static_cast<int>(u), iy = static_cast<int>(v);
         if (ix < 0 || ix > cols || iy < 0 || iy > rows) continue;  // :206-207
         if (ix == cols || iy == rows) continue;                    // out-of-bounds read in the reference
-        if (is_ground[img[static_cast<size_t>(iy) * row_stride + ix]]) cand.push_back(static_cast<int32_t>(i));
+        if (is_ground[img[static_cast<size_t>(iy) * row_stride + ix]]) {
+            cand[static_cast<size_t>(i)] = 1;
+            n_cand++;
+        }
     }
-    if (cand.size() < 3) return MLD_ERR_CLOUD_TOO_SMALL;  // :224-227
+    if (n_cand < 3) return MLD_ERR_CLOUD_TOO_SMALL;  // :224-227
     const float dummy[4] = {0.f, 0.f, 1.f, 0.f};
     float c1[4], c2[4];
-    ls_plane_fit(pts, stride, cand.data(), cand.size(), dummy, c1);
+    ls_plane_fit(pts, stride, n, cand, dummy, c1);
     std::vector<int32_t> inl;
+    std::vector<uint8_t> sel(static_cast<size_t>(n), 0);
     for (int64_t i = 0; i < n; i++) {
         const float* q = reinterpret_cast<const float*>(pts + i * stride);
-        if (static_cast<double>(ransac::plane_dist(c1, q)) < inlier_threshold) inl.push_back(static_cast<int32_t>(i));
+        if (static_cast<double>(ransac::plane_dist(c1, q)) < inlier_threshold) {
+            inl.push_back(static_cast<int32_t>(i));
+            sel[static_cast<size_t>(i)] = 1;
+        }
     }
-    ls_plane_fit(pts, stride, inl.data(), inl.size(), c1, c2);
+    ls_plane_fit(pts, stride, n, sel, c1, c2);
     for (int t = 0; t < 4; t++) coeffs_out[t] = c2[t];
     if (n_inliers_out) *n_inliers_out = static_cast<int64_t>(inl.size());
     return orc_set_ground_plane(h, c2, inl.data(), static_cast<int64_t>(inl.size()));

@@ -367,6 +367,41 @@ def ls_plane_fit(xyz: np.ndarray, idx: np.ndarray, fallback):
     return np.array([n[0], n[1], n[2], d], dtype=np.float32)
 
 
+def _f32_group_tree_sum(values: np.ndarray) -> np.float32:
+    """Sum of float32 `values` given for EVERY cloud point (0 for non-members), the association of the semantic plane's
+    fits (C++ restatement ls_plane_fit, HIP k_sem_*): a fixed binary tree over each group of 64 consecutive points
+    (strides 32, 16, ..., 1), then the group sums through 256 interleaved partials combined in index order."""
+    n = values.shape[0]
+    groups = (n + 63) // 64
+    a = np.zeros(groups * 64, dtype=np.float32)
+    a[:n] = values
+    a = a.reshape(groups, 64)
+    o = 32
+    while o > 0:
+        a = (a[:, :o] + a[:, o:2 * o]).astype(np.float32)
+        o //= 2
+    return _f32_partials_sum(a[:, 0])
+
+
+def ls_plane_fit_members(xyz: np.ndarray, member: np.ndarray, fallback):
+    """optimizeModelCoefficients over the cloud points flagged in `member` (semantic plane): float32 moments in the
+    group-tree association, smallest eigenvector (LAPACK here, Jacobi in the C++ restatement)."""
+    m_int = int(member.sum())
+    if m_int < 4:
+        return np.asarray(fallback, dtype=np.float32)
+    v = np.where(member[:, None], xyz.astype(np.float32), np.float32(0.0)).astype(np.float32)
+    x, y, z = v[:, 0], v[:, 1], v[:, 2]
+    m = np.float32(m_int)
+    a = [_f32_group_tree_sum(q) / m for q in (x * x, x * y, x * z, y * y, y * z, z * z, x, y, z)]
+    cov = np.array([[a[0] - a[6] * a[6], a[1] - a[6] * a[7], a[2] - a[6] * a[8]],
+                    [a[1] - a[6] * a[7], a[3] - a[7] * a[7], a[4] - a[7] * a[8]],
+                    [a[2] - a[6] * a[8], a[4] - a[7] * a[8], a[5] - a[8] * a[8]]], dtype=np.float64)
+    w, vec = np.linalg.eigh(cov)
+    n = vec[:, 0].astype(np.float32)
+    d = np.float32(-1.0) * (n[0] * a[6] + n[1] * a[7] + n[2] * a[8])
+    return np.array([n[0], n[1], n[2], d], dtype=np.float32)
+
+
 def semantic_plane(cloud: np.ndarray, T, f, cu, cv, img: np.ndarray, labels, thr: float):
     """SemanticPlane::CalculateInliersPlane (monolidar_fusion/src/RansacPlane.cpp:195-274), vectorised.
     Returns (candidate indices, first fit, inlier indices, refined fit)."""
@@ -390,10 +425,13 @@ def semantic_plane(cloud: np.ndarray, T, f, cu, cv, img: np.ndarray, labels, thr
     if cand.size < 3:
         raise ValueError("In GroundPlane: Input pointcloud is invalid")
     xyz32 = cloud[:, :3].astype(np.float32)
-    c1 = ls_plane_fit(xyz32, cand, [0, 0, 1, 0])
+    is_cand = np.zeros(cloud.shape[0], dtype=bool)
+    is_cand[cand] = True
+    c1 = ls_plane_fit_members(xyz32, is_cand, [0, 0, 1, 0])
     dist = np.abs(((c1[0] * xyz32[:, 0] + c1[1] * xyz32[:, 1]) + c1[2] * xyz32[:, 2]) + c1[3])
-    inl = np.nonzero(dist.astype(np.float64) < thr)[0].astype(np.int32)
-    c2 = ls_plane_fit(xyz32, inl, c1)
+    sel = dist.astype(np.float64) < thr
+    inl = np.nonzero(sel)[0].astype(np.int32)
+    c2 = ls_plane_fit_members(xyz32, sel, c1)
     return cand, c1, inl, c2
 
 
