@@ -14,6 +14,7 @@
 #include <array>
 #include <cstdint>
 #include <exception>
+#include <functional>
 #include <memory>
 #include <set>
 #include <stdexcept>
@@ -155,17 +156,25 @@ public:
     bool isSegmented() const { return is_segmented_; }
     std::array<float, 4>& getModelCoeffs() { return _modelCoeffs; }
     const std::array<float, 4>& getModelCoeffs() const { return _modelCoeffs; }
-    const std::vector<int>& getInlinersIndex() const { return _inliersIndex; }
+    const std::vector<int>& getInlinersIndex() const {
+        materialize();
+        return _inliersIndex;
+    }
     bool CheckPointInPlane(const int index) const {
+        materialize();
         for (int i : _inliersIndex)
             if (i == index) return true;
         return false;
     }
+    // A plane estimated on the GPU keeps its inlier set there (a bitmask the kernels read); the index list of
+    // getInlinersIndex (RansacPlane.h:100-103) is fetched when somebody asks for it - or when the frame slot that holds
+    // the mask is about to be reused.
+    virtual void materialize() const {}
 
 protected:
     bool is_segmented_ = false;
     std::array<float, 4> _modelCoeffs{{0, 0, 0, 0}};
-    std::vector<int> _inliersIndex;
+    mutable std::vector<int> _inliersIndex;
 };
 
 // RansacPlane (RansacPlane.h:129-170): a GroundPlane that DepthEstimator::setInputCloud estimates on the GPU while it
@@ -179,9 +188,30 @@ public:
     void assign(const std::array<float, 4>& coeffs, std::vector<int> inliers) {
         _modelCoeffs = coeffs;
         _inliersIndex = std::move(inliers);
+        _fetch = nullptr;
         is_segmented_ = true;
     }
+    // estimated on the GPU: coefficients and inlier count now, the index list on demand (`fetch` fills it)
+    void assignLazy(const std::array<float, 4>& coeffs, int64_t n_inliers, std::function<void(std::vector<int>&)> fetch) {
+        _modelCoeffs = coeffs;
+        _inliersIndex.clear();
+        _numInliers = n_inliers;
+        _fetch = std::move(fetch);
+        is_segmented_ = true;
+    }
+    void materialize() const override {
+        if (!_fetch) return;
+        auto f = std::move(_fetch);
+        _fetch = nullptr;
+        f(_inliersIndex);
+    }
+    bool inliersPending() const { return (bool)_fetch; }
+    int64_t numInliers() const { return _fetch ? _numInliers : (int64_t)_inliersIndex.size(); }
     uint32_t seed = 0;
+
+private:
+    mutable std::function<void(std::vector<int>&)> _fetch;
+    int64_t _numInliers = 0;
 };
 
 // SemanticPlane (RansacPlane.h:175-218): ground plane from a semantic label image, estimated on the GPU by
@@ -221,9 +251,19 @@ public:
     using SharedPtr = std::shared_ptr<DepthEstimator>;
 
     // max_frames > 1 exposes the C-ABI's frame slots (tracklets_depth keeps the previous frame resident in a second slot)
-    explicit DepthEstimator(int device = 0, int max_frames = 1) : _device(device), _maxFrames(max_frames) {}
+    explicit DepthEstimator(int device = 0, int max_frames = 1) : _device(device), _maxFrames(max_frames) {
+        _lazyPlane.resize((size_t)(max_frames > 0 ? max_frames : 1));
+    }
     mld_ctx* ctx() const { return _ctx; }
     ~DepthEstimator() {
+        // planes that still count on this estimator for their inlier lists get them now
+        for (size_t s = 0; s < _lazyPlane.size(); s++) {
+            try {
+                flushLazyPlane((int)s);
+            } catch (...) {
+            }
+        }
+        *_alive = false;
         if (_ctx) mld_destroy(_ctx);
     }
     DepthEstimator(const DepthEstimator&) = delete;
@@ -249,6 +289,7 @@ public:
         _camera = camera;
         _transform = transform_lidar_to_cam;
         if (_ctx) {
+            for (size_t s = 0; s < _lazyPlane.size(); s++) flushLazyPlane((int)s);
             mld_destroy(_ctx);
             _ctx = nullptr;
         }
@@ -273,37 +314,28 @@ public:
 
     void setInputCloud(const Cloud::ConstPtr& cloud, GroundPlane::Ptr& groundPlane, int slot = 0) {
         if (!_isInitialized) throw "call of 'setInputCloud' without 'initialize'";
-        check(mld_set_cloud(_ctx, slot, cloud->points.data(), (int64_t)cloud->points.size(), (int)sizeof(PointXYZI)));
-        _numPoints = (int64_t)cloud->points.size();
-        _isInitializedPointCloud = true;
-        _installedPlane = nullptr;
+        flushLazyPlane(slot);
         if (_parameters->do_use_ransac_plane) {
             if (groundPlane == nullptr) groundPlane = std::make_shared<RansacPlane>(_parameters);  // DepthEstimator.cpp:275-278
             if (!groundPlane->isSegmented()) {                                               // :281-283
-                // RansacPlane::CalculateInliersPlane on the GPU, on the cloud that was just uploaded
-                auto* rp = dynamic_cast<RansacPlane*>(groundPlane.get());
-                if (!rp) {
-                    groundPlane->CalculateInliersPlane(cloud, _parameters->ransac_plane_min_z, _parameters->ransac_plane_max_z);
-                } else {
-                    float coeffs[4];
-                    int64_t n_inl = 0;
-                    static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
-                    if (auto* sp = dynamic_cast<SemanticPlane*>(rp)) {
-                        check(mld_estimate_semantic_plane(_ctx, slot, sp->image().data(), sp->rows(), sp->cols(), sp->cols(),
-                                                          reinterpret_cast<const int32_t*>(sp->labels().data()),
-                                                          (int)sp->labels().size(), sp->inlierThreshold(), coeffs, &n_inl));
-                    } else {
-                        check(mld_estimate_ground_plane(_ctx, slot, rp->seed, coeffs, &n_inl));
-                    }
-                    std::vector<int> inl((size_t)n_inl);
-                    check(mld_get_ground_plane_inliers(_ctx, slot, reinterpret_cast<int32_t*>(inl.data()), n_inl, &n_inl));
-                    rp->assign({coeffs[0], coeffs[1], coeffs[2], coeffs[3]}, std::move(inl));
-                    _installedPlane = groundPlane.get();
-                    return;  // the estimator already installed the plane on the device
+                if (auto* rp = dynamic_cast<RansacPlane*>(groundPlane.get())) {
+                    // RansacPlane / SemanticPlane::CalculateInliersPlane on the GPU, in ONE asynchronous chain with the
+                    // upload and the projection (the plane is in place before the points are projected)
+                    estimateFrame(cloud, *rp, groundPlane, slot, nullptr, 0, nullptr, nullptr);
+                    return;
                 }
+                check(mld_set_cloud(_ctx, slot, cloud->points.data(), (int64_t)cloud->points.size(), (int)sizeof(PointXYZI)));
+                noteCloud(cloud);
+                groundPlane->CalculateInliersPlane(cloud, _parameters->ransac_plane_min_z, _parameters->ransac_plane_max_z);
+                installPlane(*groundPlane, slot);
+                return;
             }
+            check(mld_set_cloud(_ctx, slot, cloud->points.data(), (int64_t)cloud->points.size(), (int)sizeof(PointXYZI)));
+            noteCloud(cloud);
             installPlane(*groundPlane, slot);
         } else {
+            check(mld_set_cloud(_ctx, slot, cloud->points.data(), (int64_t)cloud->points.size(), (int)sizeof(PointXYZI)));
+            noteCloud(cloud);
             check(mld_set_ground_plane(_ctx, slot, nullptr, nullptr, 0));
         }
     }
@@ -385,10 +417,24 @@ public:
     void CalculateDepth(const Cloud::ConstPtr& pointCloud, const std::vector<double>& points_image_cs,
                         std::vector<double>& points_depths, std::vector<int>& resultType, GroundPlane::Ptr& ransacPlane) {
         const int64_t F = (int64_t)(points_image_cs.size() / 2);
+        if (estimateCall(pointCloud, ransacPlane)) {
+            // the reference's production call (tracklet_depth_module.cpp:269-284, DepthEstimator.cpp:275-283): the
+            // plane is not segmented yet - estimated on the GPU ahead of the projection, one C-ABI call for the frame
+            points_depths.resize((size_t)F);
+            resultType.resize((size_t)F);
+            static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
+            if (ransacPlane == nullptr) ransacPlane = std::make_shared<RansacPlane>(_parameters);
+            flushLazyPlane(0);
+            estimateFrame(pointCloud, *static_cast<RansacPlane*>(ransacPlane.get()), ransacPlane, 0, points_image_cs.data(), F,
+                          points_depths.data(), reinterpret_cast<int32_t*>(resultType.data()));
+            _depthCalcStats.SetFromTypes(reinterpret_cast<const int32_t*>(resultType.data()), F);
+            return;
+        }
         if (frameCall(pointCloud, points_image_cs.data(), F, ransacPlane)) {  // one C-ABI call for the whole frame
             points_depths.resize((size_t)F);
             resultType.resize((size_t)F);
             static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
+            flushLazyPlane(0);
             const bool road = _parameters->do_use_ransac_plane;
             check(mld_calculate_depth_frame(_ctx, 0, pointCloud->points.data(), (int64_t)pointCloud->points.size(),
                                             (int)sizeof(PointXYZI), road ? ransacPlane->getModelCoeffs().data() : nullptr,
@@ -448,8 +494,18 @@ public:
     }
     void CalculateDepth(const Cloud::ConstPtr& pointCloud, const Eigen::Matrix2Xd& points_image_cs,
                         Eigen::VectorXd& points_depths, Eigen::VectorXi& resultType, GroundPlane::Ptr& ransacPlane) {
-        setInputCloud(pointCloud, ransacPlane);
         const int64_t F = points_image_cs.cols();
+        if (estimateCall(pointCloud, ransacPlane)) {  // the production call: plane estimated inside the one frame call
+            points_depths.resize(F);
+            resultType.resize(F);
+            if (ransacPlane == nullptr) ransacPlane = std::make_shared<RansacPlane>(_parameters);
+            flushLazyPlane(0);
+            estimateFrame(pointCloud, *static_cast<RansacPlane*>(ransacPlane.get()), ransacPlane, 0, points_image_cs.data(), F,
+                          points_depths.data(), resultType.data());
+            _depthCalcStats.SetFromTypes(resultType.data(), F);
+            return;
+        }
+        setInputCloud(pointCloud, ransacPlane);
         points_depths.resize(F);
         resultType.resize(F);
         check(mld_calculate_depth(_ctx, 0, points_image_cs.data(), F, points_depths.data(), resultType.data()));
@@ -501,6 +557,60 @@ private:
         if (ransacPlane.get() != _installedPlane && ransacPlane->isSegmented()) installPlane(*ransacPlane);
         return 0u;
     }
+    // CalculateDepth(cloud, ..., plane) whose plane still has to be estimated on the GPU (a null pointer, or a RansacPlane /
+    // SemanticPlane that is not segmented): mld_calculate_depth_frame_estimate
+    bool estimateCall(const Cloud::ConstPtr& cloud, const GroundPlane::Ptr& gp) const {
+        if (!_isInitialized || _debugMode || !cloud || !_parameters->do_use_ransac_plane) return false;
+        if (gp == nullptr) return true;
+        return !gp->isSegmented() && dynamic_cast<RansacPlane*>(gp.get()) != nullptr;
+    }
+    // setInputCloud(cloud, unsegmented plane) [+ the feature loop when F > 0] as ONE call; the plane object receives the
+    // coefficients and the inlier count, its index list stays on the GPU until it is asked for
+    void estimateFrame(const Cloud::ConstPtr& cloud, RansacPlane& rp, const GroundPlane::Ptr& owner, int slot, const double* uv,
+                       int64_t F, double* depths, int32_t* types) {
+        mld_plane_request rq{};
+        rq.kind = MLD_PLANE_RANSAC;
+        rq.seed = rp.seed;
+        static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
+        if (auto* sp = dynamic_cast<SemanticPlane*>(&rp)) {
+            rq.kind = MLD_PLANE_SEMANTIC;
+            rq.label_image = sp->image().data();
+            rq.rows = sp->rows();
+            rq.cols = sp->cols();
+            rq.row_stride_bytes = sp->cols();
+            rq.ground_labels = reinterpret_cast<const int32_t*>(sp->labels().data());
+            rq.n_labels = (int)sp->labels().size();
+            rq.inlier_threshold = sp->inlierThreshold();
+        }
+        mld_plane_result pr{};
+        check(mld_calculate_depth_frame_estimate(_ctx, slot, cloud->points.data(), (int64_t)cloud->points.size(),
+                                                 (int)sizeof(PointXYZI), &rq, uv, F, depths, types, &pr));
+        noteCloud(cloud);
+        mld_ctx* ctx = _ctx;
+        std::shared_ptr<bool> alive = _alive;
+        const int64_t n_inl = pr.n_inliers;
+        rp.assignLazy({pr.coeffs[0], pr.coeffs[1], pr.coeffs[2], pr.coeffs[3]}, n_inl, [ctx, slot, alive, n_inl](std::vector<int>& out) {
+            if (!*alive) throw std::runtime_error("GroundPlane: the DepthEstimator that holds this plane's inliers is gone");
+            out.resize((size_t)n_inl);
+            int64_t n = 0;
+            if (mld_get_ground_plane_inliers(ctx, slot, reinterpret_cast<int32_t*>(out.data()), n_inl, &n) != MLD_OK)
+                throw std::runtime_error(std::string("GroundPlane: ") + mld_last_error(ctx));
+            out.resize((size_t)n);
+        });
+        if ((size_t)slot < _lazyPlane.size()) _lazyPlane[(size_t)slot] = owner;
+        _installedPlane = &rp;
+    }
+    // a plane whose inlier list still lives in `slot` gets it now: the slot's mask is about to be overwritten
+    void flushLazyPlane(int slot) {
+        if ((size_t)slot >= _lazyPlane.size()) return;
+        if (auto gp = _lazyPlane[(size_t)slot].lock()) gp->materialize();
+        _lazyPlane[(size_t)slot].reset();
+    }
+    void noteCloud(const Cloud::ConstPtr& cloud) {
+        _numPoints = (int64_t)cloud->points.size();
+        _isInitializedPointCloud = true;
+        _installedPlane = nullptr;
+    }
     // the whole frame can go through mld_calculate_depth_frame: no debug vectors wanted and nothing to estimate
     bool frameCall(const Cloud::ConstPtr& cloud, const double* uv, int64_t F, const GroundPlane::Ptr& gp) const {
         (void)uv;
@@ -510,6 +620,8 @@ private:
         return gp != nullptr && gp->isSegmented();
     }
     const GroundPlane* _installedPlane = nullptr;
+    std::vector<std::weak_ptr<GroundPlane>> _lazyPlane;  // per slot: the plane whose inlier list is still on the GPU
+    std::shared_ptr<bool> _alive = std::make_shared<bool>(true);
 
     void check(int rc) {
         if (rc == MLD_OK) return;

@@ -95,9 +95,21 @@ int main(int argc, char** argv) {
                                                                    est.getParameters()->ransac_plane_refinement_treshold);
             std::vector<double> d3;
             std::vector<int> t3;
-            est.CalculateDepth(ccloud, uv, d3, t3, sem);
+            est.CalculateDepth(ccloud, uv, d3, t3, sem);  // ONE C call: plane estimated on the GPU ahead of the projection
+            auto* lazy = static_cast<RansacPlane*>(sem.get());
+            const int pending = lazy->inliersPending() ? 1 : 0;  // the index list has not left the GPU yet
+            const long long counted = (long long)lazy->numInliers();
+            // a fresh RansacPlane on the next frame reuses the slot: the semantic plane's list is fetched just before
+            GroundPlane::Ptr rp = std::make_shared<RansacPlane>(est.getParameters(), 5u);
+            std::vector<double> d4;
+            std::vector<int> t4;
+            est.CalculateDepth(ccloud, uv, d4, t4, rp);
+            const int flushed = lazy->inliersPending() ? 0 : 1;
             std::cout << "semantic segmented " << (sem->isSegmented() ? 1 : 0) << " inliers " << sem->getInlinersIndex().size()
-                      << " nz " << sem->getModelCoeffs()[2] << "\n";
+                      << " nz " << sem->getModelCoeffs()[2] << " lazy " << pending << " counted " << counted << " flushed "
+                      << flushed << " ransac_pending " << (static_cast<RansacPlane*>(rp.get())->inliersPending() ? 1 : 0)
+                      << " ransac_inliers " << rp->getInlinersIndex().size() << " ransac_counted "
+                      << static_cast<RansacPlane*>(rp.get())->numInliers() << "\n";
         }
         // The reference decides about the road fallback per call (DepthEstimator.cpp:580): a null plane switches it off
         // for that call only, the plane handed in afterwards is used again, and so is a DIFFERENT plane object.

@@ -58,9 +58,18 @@ def test_cpp_shim_matches_oracle(tmp_path, with_plane):
         assert m, r.stdout
         same_after, road_null, road_other, road_first = map(int, m.groups())
         assert same_after == 1 and road_null == 0 and road_first > 0 and 0 < road_other < road_first
-        m = re.search(r"semantic segmented (\d+) inliers (\d+) nz (\S+)", r.stdout)
+        m = re.search(r"semantic segmented (\d+) inliers (\d+) nz (\S+) lazy (\d+) counted (\d+) flushed (\d+) "
+                      r"ransac_pending (\d+) ransac_inliers (\d+) ransac_counted (\d+)", r.stdout)
         assert m, r.stdout
         assert int(m.group(1)) == 1 and int(m.group(2)) > 1000 and abs(abs(float(m.group(3))) - 1.0) < 0.05
+        # the production call is one C call: the plane object had its coefficients and inlier COUNT at once, the index
+        # list stayed on the GPU until the slot was reused by the next frame (then it was fetched: nothing is lost)
+        assert int(m.group(4)) == 1 and int(m.group(5)) == int(m.group(2)) and int(m.group(6)) == 1
+        assert int(m.group(7)) == 1 and int(m.group(8)) == int(m.group(9))
+        # that next frame's RANSAC plane (seed 5) equals the restatement's
+        ref, _ = run_oracle(P, cloud, uv, None)
+        _, inl5 = ref.estimate_ground_plane(5)
+        assert int(m.group(8)) == inl5.size
 
 
 TRACKLET_DEMO = ROOT / "mono_lidar_depth_amd" / "lib" / "mld_tracklet_demo"
