@@ -959,7 +959,37 @@ int mld_pair_contexts(mld_ctx* a, mld_ctx* b) {
     int rc = bind_device(a);
     if (rc) return rc;
     ProjShare* sh = new ProjShare();
-    hipError_t e = hipStreamCreateWithFlags(&sh->stream, hipStreamNonBlocking);
+    hipError_t e = hipSuccess;
+#ifdef MLD_AB_SWITCHES
+    // Measurement build only.  MLD_CU_SPLIT="N[,s]": the pair's projection stream is confined to N of the 256 CUs and both
+    // contexts' own streams (classification, feature kernels) to the other 256 - N, so that the two kinds of kernels never
+    // share a register file (LAB.md "CU split").  Mask bits: the low N bits, or with ",s" every bit whose index mod 256/g
+    // falls in the first N/g (g = 8 groups), i.e. the same share of every group of 32 consecutive bits.
+    bool split = false;
+    if (const char* cs = std::getenv("MLD_CU_SPLIT")) {
+        const int n_proj = std::atoi(cs);
+        const bool strided = std::strchr(cs, 's') != nullptr;
+        if (n_proj > 0 && n_proj < 256) {
+            uint32_t mp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int b = 0; b < 256; b++) {
+                const bool proj = strided ? (b % 32) < n_proj / 8 : b < n_proj;
+                (proj ? mp : mf)[b >> 5] |= 1u << (b & 31);
+            }
+            e = hipExtStreamCreateWithCUMask(&sh->stream, 8, mp);
+            for (mld_ctx* c : {a, b}) {
+                if (e != hipSuccess) break;
+                (void)hipStreamSynchronize(c->stream);
+                if (c->own_stream) (void)hipStreamDestroy(c->stream);
+                c->stream = nullptr;
+                e = hipExtStreamCreateWithCUMask(&c->stream, 8, mf);
+                c->own_stream = true;
+            }
+            split = true;
+        }
+    }
+    if (!split)
+#endif
+    e = hipStreamCreateWithFlags(&sh->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete sh;
         return fail(a, MLD_ERR_HIP, std::string("hipStreamCreate(projection stream): ") + hipGetErrorString(e));
