@@ -164,7 +164,7 @@ void* mld_get_stream(mld_ctx* ctx);
 int mld_synchronize(mld_ctx* ctx);
 
 /*
- * Two (or more) contexts on one GPU, used alternately ("double buffering"; DESIGN.md §3 "Two contexts side by side").
+ * Two (or more) contexts on one GPU, used alternately ("double buffering"; DESIGN.md §4 "Batches").
  * The projection kernel streams the clouds from HBM and leaves most of a CU's issue slots idle; the feature kernels are
  * the opposite (gather- and issue-bound, ~10 % of the HBM bandwidth).  Run beside each other they finish sooner than
  * one after the other -- the reference has no counterpart: its stage A is serial and its feature loop is the only

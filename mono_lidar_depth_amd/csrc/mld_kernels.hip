@@ -180,7 +180,12 @@ constexpr int kProjPerThread = MLD_PROJ_PER_THREAD;
 
 // tag_all != 0: every slot of the batch carries this map tag (the per-slot tag of the descriptor array is then not
 // kept up to date, which lets steady-state batches run without re-uploading the descriptors).
-__global__ __launch_bounds__(kProjThreads) void k_project_scatter(const SlotDesc* __restrict__ slots, SlotDesc single,
+#ifdef MLD_PROJ_VGPRS  // measurement builds: cap the register allocation (how many projection wavefronts fit beside the feature kernel)
+#define MLD_PROJ_ATTR __attribute__((amdgpu_num_vgpr(MLD_PROJ_VGPRS)))
+#else
+#define MLD_PROJ_ATTR
+#endif
+__global__ __launch_bounds__(kProjThreads) MLD_PROJ_ATTR void k_project_scatter(const SlotDesc* __restrict__ slots, SlotDesc single,
                                                                   int use_single, Calib c, int n_slots, int per_slot,
                                                                   uint32_t tag_all) {
     // Raised issue priority: beside another context's feature kernels (long f64 sequences, always ready to issue)
@@ -2469,8 +2474,13 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDes
 #ifndef MLD_FUSED_WAVES
 #define MLD_FUSED_WAVES 3
 #endif
+#ifdef MLD_FUSED_VGPRS
+#define MLD_FUSED_ATTR __attribute__((amdgpu_num_vgpr(MLD_FUSED_VGPRS)))
+#else
+#define MLD_FUSED_ATTR
+#endif
 template <int ROAD_MODE>
-__global__ __launch_bounds__(kWave, MLD_FUSED_WAVES) void k_feature_fused(const SlotDesc* __restrict__ slots, SlotDesc single,
+__global__ __launch_bounds__(kWave, MLD_FUSED_WAVES) MLD_FUSED_ATTR void k_feature_fused(const SlotDesc* __restrict__ slots, SlotDesc single,
                                                          int use_single, Calib c, int n_slots, int per_slot,
                                                          uint32_t tag_all) {
     extern __shared__ __align__(16) unsigned char smem[];

@@ -404,7 +404,7 @@ __device__ inline void rs_count_inliers(const float* sx, const float* sy, const 
 
 // One block per frame slot.  pass != 0: pcl::PassThrough on z with the float limits [lo, hi] ahead of the sub-sampling
 // (LDS beyond the fixed part: one byte per 64 points + one int per 1024 points).  Where a block's time goes:
-// DESIGN.md "k_rs_batch" (about half of it is the wait for the 6000 scattered cloud reads of the sample).
+// LAB.md 3.17-3.21 (about half of it is the wait for the 6000 scattered cloud reads of the sample).
 // single_slot >= 0 (ONE frame per call, mld_calculate_depth_frame_estimate): a grid of one block works on the descriptor
 // passed by value, takes `single_seed`, writes that slot's PlaneDev and leaves a second copy of the plane in `copy_out` - the staging block that travels
 // back to the host with the depths - beside the slot's resident PlaneDev.

@@ -2,7 +2,7 @@
 # Profiles bench.py under rocprofv3 on the GPU box (invoke through gpurun from the repo root):
 #   gpurun -- 'bash profiles/run_profile.sh r3'
 # Writes raw output under gpurun_out/prof_<tag>/; profiles/summarize.py condenses it into profiles/<tag>_*.
-TAG=${1:-r3}
+TAG=${1:-r4}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -16,6 +16,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_x -- python3 $REPO/bench.py --contexts 1 $ARGS --no-estimated > $OUT/bench_trace_x.json 2> $OUT/trace_x.log
 # the plane-estimated leg on its own (k_rs_batch)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_e -- python3 $REPO/bench.py --steps 2 --warmup 1 --repeats 1 $COMMON --no-exclusive > $OUT/bench_trace_e.json 2> $OUT/trace_e.log
+# the one-frame-per-call legs (supplied plane, RANSAC and semantic plane estimated inside the call): kernels of a frame
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_l -- python3 $REPO/bench.py --steps 2 --warmup 1 --repeats 1 --min-timed-seconds 0 --frames-per-step 64 --verify-slots 4 --cpu-seconds 0 --latency-frames 100 --streaming-batches 0 --config-frames 0 --no-estimated --no-exclusive > $OUT/bench_trace_l.json 2> $OUT/trace_l.log
 # counters: rocprofv3 serialises the kernels in these passes, so they are collected on the one-context schedule
 PMCARGS="--contexts 1 --steps 4 --warmup 1 --repeats 1 $COMMON --no-kernel-timing --no-estimated"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log

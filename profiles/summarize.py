@@ -7,7 +7,7 @@ import sys
 
 import pandas as pd
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 src = f"gpurun_out/prof_{tag}"
 import os
 
@@ -78,6 +78,24 @@ if stats_e:
         lines.append("")
     except Exception as e:  # noqa: BLE001
         lines += [f"(plane-estimated leg not parsed: {e})", ""]
+stats_l = newest(f"{src}/trace_l/*/*kernel_stats.csv")
+if stats_l:
+    kl = pd.read_csv(stats_l)
+    kl = kl[kl.Name.str.contains("mld::")]
+    lines += ["## one frame per call (latency legs: supplied plane, RANSAC, semantic; `--latency-frames 100`)", "",
+              "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
+    for _, r in kl.iterrows():
+        lines.append(f"| `{r.Name.split('(')[0]}` | {r.Calls} | {r.AverageNs / 1e3:.1f} | {r.MinNs / 1e3:.1f} | {r.MaxNs / 1e3:.1f} |")
+    try:
+        bl = json.loads(open(f"{src}/bench_trace_l.json").read().strip().splitlines()[-1])["latency"]
+        for name, leg in (("supplied", bl), ("estimated.ransac", bl["estimated"]["ransac"]), ("estimated.semantic", bl["estimated"]["semantic"])):
+            lines.append("")
+            lines.append(f"bench.py `latency.{name}` (under the tracer): median {leg['ms_per_frame_median'] * 1e3:.1f} us, p99 "
+                         f"{leg['ms_per_frame_p99'] * 1e3:.1f} us; breakdown (instrumented pass) " +
+                         ", ".join(f"{k} {v:.1f}" for k, v in (leg.get('breakdown_us_median') or {}).items()))
+    except Exception as e:  # noqa: BLE001
+        lines += ["", f"(latency legs not parsed: {e})"]
+    lines.append("")
 lines += ["## PMC (per launch, mean over launches)", "",
           "FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane) "
           "coalesced read (MI355X_MICROARCH.md §HBM): `hbm_read_corrected` doubles it for k_project_scatter "
