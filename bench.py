@@ -336,7 +336,7 @@ class Resident:
     """B device-resident frames (U distinct clouds, B distinct feature sets) and a context with S frame slots."""
 
     def __init__(self, P, cam, T, scanner, B, U, F, seq, device, integer_uv=False, slots=0, contexts=1, shared_mode=1,
-                 pair=False):
+                 pair=False, near_points=False):
         import torch
         from mono_lidar_depth_amd import DepthEstimator, synth
         dev = torch.device("cuda", device)
@@ -344,7 +344,10 @@ class Resident:
         self.shared_mode = shared_mode
         self.clouds_h = [synth.make_cloud(scanner, seed=seq, frame=f) for f in range(U)]
         self.planes_h = [synth.make_ground_plane(c) for c in self.clouds_h]
-        self.uvs_h = [synth.make_features(F, seed=seq * 100000 + b, integer=integer_uv) for b in range(B)]
+        if near_points:  # features around the image positions of the frame's own returns (config 3, second variant)
+            self.uvs_h = [synth.make_features_near_points(self.clouds_h[b % U], F, seed=seq * 100000 + b) for b in range(B)]
+        else:
+            self.uvs_h = [synth.make_features(F, seed=seq * 100000 + b, integer=integer_uv) for b in range(B)]
         self.N = N = self.clouds_h[0].shape[0]
         self.U = U
         words = (N + 31) // 32
@@ -628,24 +631,30 @@ def config3_leg(cam, T, device, B, steps=8):
     P0 = capi.params_c0()
     out = {"workload": f"BASELINE config 3: VLP-16 16x1800 cloud x 5000 features/frame, {B} device-resident frames per "
                        "step, plane known at projection", "modes": {}}
-    for name, kw in (("c0_dispose", {}),
-                     ("adjust_relative", dict(treshold_depth_mode=1, treshold_depth_local_mode=1,
-                                              treshold_depth_local_valuetype=1)),
-                     ("adjust_absolute", dict(treshold_depth_mode=1, treshold_depth_local_mode=1,
-                                              treshold_depth_local_valuetype=0))):
-        res = Resident(P0.replace(**kw), cam, T, synth.VLP16, B, 8, 5000, 3, device)
+    def run_mode(kw, near):
+        res = Resident(P0.replace(**kw), cam, T, synth.VLP16, B, 8, 5000, 3, device, near_points=near)
         loops, kt = timed_resident(res, steps, 2, True, 2)
         el = loops[0]
-        ok, rep = res.verify(2)
+        ok, rep = res.verify(4 if near else 2)
         hist = np.zeros(capi.MLD_RESULT_TYPE_COUNT, dtype=np.int64)
         for b in range(0, B, max(1, B // 16)):
             hist += res.ests[0].resultHistogram(res.all_type[b])
-        out["modes"][name] = {
+        m = {
             "associations_per_s": B * 5000 * steps / el, "ms_per_frame": 1e3 * el / steps / B, "verified": ok,
             "max_abs_depth_diff_m": rep["max_abs_depth_diff_m"],
             "kernels_ms_per_launch": {k: v["avg_ms"] for k, v in kt.items()},
             "success_fraction": float((hist[1] + hist[16]) / max(1, hist.sum())),
         }
+        if near:
+            m["result_types"] = {capi.RESULT_TYPE_NAMES[i]: int(c) for i, c in enumerate(hist) if c}
+        return res, kt, m
+
+    for name, kw in (("c0_dispose", {}),
+                     ("adjust_relative", dict(treshold_depth_mode=1, treshold_depth_local_mode=1,
+                                              treshold_depth_local_valuetype=1)),
+                     ("adjust_absolute", dict(treshold_depth_mode=1, treshold_depth_local_mode=1,
+                                              treshold_depth_local_valuetype=0))):
+        res, kt, out["modes"][name] = run_mode(kw, False)
         if name == "c0_dispose":
             db = [design_bytes_project(res.clouds_h[u], cam, T, res.planes_h[u][1]) for u in range(2)]
             pb = float(np.mean([d["bytes"] for d in db])) * B
@@ -653,7 +662,19 @@ def config3_leg(cam, T, device, B, steps=8):
             out["roofline_project"] = {"design_bytes_per_launch": pb, "kernel_ms": pms,
                                        "frac": pb / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS if pms > 0 else None}
         res.close()
-    out["verified"] = all(m["verified"] for m in out["modes"].values())
+    # Uniformly random features almost never see a neighbour on a 16-ring cloud (rings ~25 px apart, window 9 px high): the
+    # workload above is what BASELINE specifies, but it mostly measures the classification.  Second variant: the same
+    # clouds with the features scattered around the image positions of the returns, so that every path behind the
+    # neighbour search runs (collinear triangles, planarity / orthogonality rejections, thresholds, road fallback).
+    out["near_returns"] = {"workload": "the same clouds, 5000 features per frame within a few pixels of LiDAR returns",
+                           "modes": {}}
+    for name, kw in (("c0_dispose", {}),
+                     ("adjust_relative", dict(treshold_depth_mode=1, treshold_depth_local_mode=1,
+                                              treshold_depth_local_valuetype=1))):
+        res, kt, out["near_returns"]["modes"][name] = run_mode(kw, True)
+        res.close()
+    out["near_returns"]["verified"] = all(m["verified"] for m in out["near_returns"]["modes"].values())
+    out["verified"] = all(m["verified"] for m in out["modes"].values()) and out["near_returns"]["verified"]
     return out
 
 

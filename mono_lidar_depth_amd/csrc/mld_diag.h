@@ -74,6 +74,21 @@ struct Stamps {
 #define MLD_DIAG_KEY(load, tag, cell) (load)
 #endif
 
+// -DMLD_DIAG_NO_TAIL: the lane-per-feature kernel without corner selection + tail (wrong results): what those stages
+// cost in TIME, i.e. the most a deferred, dense execution of them could return
+#ifdef MLD_DIAG_NO_TAIL
+#define MLD_DIAG_SKIP_TAIL() \
+    do {                     \
+        if (live) {          \
+            mytype = MLD_TriangleNotPlanar; \
+            mydepth = -1.0;  \
+        }                    \
+        return;              \
+    } while (0)
+#else
+#define MLD_DIAG_SKIP_TAIL()
+#endif
+
 namespace ransac {
 #ifdef MLD_DIAG_RS_PHASES
 // diagnostic build only: time per phase of k_rs_batch (100 MHz ticks of thread 0, collected in LDS, summed over the

@@ -1939,6 +1939,7 @@ __device__ __forceinline__ void main_hist(const Calib& c, const SlotDesc& s, uin
 __device__ __forceinline__ void main_tail(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, const int ks_in,
                                           bool live, const double minZ, const double maxZ, const double myu,
                                           const double myv, int& mytype, double& mydepth, bool& overflow ST_ARG) {
+    MLD_DIAG_SKIP_TAIL();
     int ks = live ? ks_in : 0;
     double r[kRecFields];
 #pragma unroll

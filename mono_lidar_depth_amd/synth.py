@@ -105,6 +105,28 @@ def make_features(n: int, seed: int = 0, integer: bool = False, width: int = KIT
     return np.ascontiguousarray(uv, dtype=np.float64)
 
 
+def make_features_near_points(cloud: np.ndarray, n: int, seed: int = 0, jitter_u: float = 3.0, jitter_v: float = 2.0,
+                              width: int = KITTI_W, height: int = KITTI_H) -> np.ndarray:
+    """[F, 2] float64 features scattered around the image positions of visible LiDAR returns (uniform jitter of a few
+    pixels): with a sparse scanner (VLP-16: rings ~25 px apart, search window 9 px high) uniformly random features almost
+    never see a neighbour, these always do - the variant of BASELINE config 3 that exercises the paths behind the
+    neighbour search (collinear triangles, planarity / orthogonality rejections, thresholds, road fallback)."""
+    rng = np.random.default_rng(88000 + seed)
+    xyz = cloud[:, :3].astype(np.float64)
+    cam = xyz @ T_CAM_LIDAR[:, :3].T + T_CAM_LIDAR[:, 3]
+    with np.errstate(all="ignore"):
+        u = cam[:, 0] / cam[:, 2] * KITTI_F + KITTI_CU
+        v = cam[:, 1] / cam[:, 2] * KITTI_F + KITTI_CV
+        vis = np.nonzero((cam[:, 2] > 0.5) & (u > 0) & (u < width) & (v > 0) & (v < height))[0]
+    if vis.size == 0:
+        return make_features(n, seed, width=width, height=height)
+    pick = rng.choice(vis, n, replace=True)
+    uv = np.stack([u[pick] + rng.uniform(-jitter_u, jitter_u, n), v[pick] + rng.uniform(-jitter_v, jitter_v, n)], axis=1)
+    uv[:, 0] = np.clip(uv[:, 0], 0.0, width - 1e-6)
+    uv[:, 1] = np.clip(uv[:, 1], 0.0, height - 1e-6)
+    return np.ascontiguousarray(uv, dtype=np.float64)
+
+
 def make_ground_plane(cloud: np.ndarray, subsample: int = 0, seed: int = 0):
     """Analytic plane of the scene in the lidar frame (0,0,1,1.73) + inliers |z + 1.73| < 0.3."""
     z = cloud[:, 2]
