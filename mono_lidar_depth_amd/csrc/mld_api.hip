@@ -1413,7 +1413,7 @@ static int semantic_plane_launch(mld_ctx* ctx, Slot& s, const unsigned char* img
 }
 
 // scratch of the semantic estimator (allocated on first use; may synchronise then)
-static int semantic_plane_scratch(mld_ctx* ctx, Slot& s) {
+static int semantic_plane_scratch(mld_ctx* ctx, Slot& s, long long n) {
     using namespace ransac;
     int rc = MLD_OK;
     if (!ctx->sem_res) {
@@ -1424,7 +1424,7 @@ static int semantic_plane_scratch(mld_ctx* ctx, Slot& s) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     // per 64 points: the group's moment sums (40 bytes) and one 64-bit word of the inlier mask
-    const size_t groups = (size_t)((s.d.n + 63) / 64);
+    const size_t groups = (size_t)((n + 63) / 64);
     if ((rc = grow(ctx, ctx->sem_groups, ctx->sem_groups_cap, groups * sizeof(GroupSums)))) return rc;
     return grow(ctx, s.mask_buf, s.mask_words, groups * 2);
 }
@@ -1435,7 +1435,7 @@ static int semantic_plane_core(mld_ctx* ctx, Slot& s, const unsigned char* img_d
     using namespace ransac;
     int rc = MLD_OK;
     if (s.d.n < 3) return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");  // (:224-227)
-    if ((rc = semantic_plane_scratch(ctx, s))) return rc;
+    if ((rc = semantic_plane_scratch(ctx, s, s.d.n))) return rc;
     if ((rc = semantic_plane_launch(ctx, s, img_dev, rows, cols, row_stride, labels, n_labels, inlier_threshold, ctx->stream)))
         return rc;
     SemResult res;
@@ -1735,8 +1735,7 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
     }
     size_t img_bytes = 0;
     if (kind == FramePlane::SEMANTIC) {
-        s.d.n = n;  // (the scratch is sized by the cloud)
-        if ((rc = semantic_plane_scratch(ctx, s))) return rc;
+        if ((rc = semantic_plane_scratch(ctx, s, n))) return rc;  // (sized by the cloud that is about to arrive)
         img_bytes = (size_t)rq->rows * (size_t)rq->row_stride_bytes;
         if ((rc = grow(ctx, ctx->sem_img, ctx->sem_img_cap, img_bytes))) return rc;
     }
