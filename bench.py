@@ -187,7 +187,7 @@ def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
         return SemanticPlane(imgs[i % len(imgs)], labels, thr)
 
     def run(kind):
-        ts = []
+        ts, host = [], []
         last = None
         for it in range(n_frames + 10):
             i = it % len(clouds) if kind != "semantic" else it % len(imgs)
@@ -195,8 +195,12 @@ def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
             t0 = time.perf_counter()
             d, t = est.CalculateDepth(clouds[i], uvs[i], gp)
             ts.append(time.perf_counter() - t0)
+            host.append(est.frameTiming())  # (host-clock phases of the un-instrumented call)
             last = (it, i, d, t)
         ts = np.array(ts[10:]) * 1e3
+        host_keys = ("pre_us", "copycall_us", "api_us", "wait_us", "total_us")
+        host_med = {k: float(np.median([h[k] for h in host[10:]])) for k in host_keys}
+        host_med["wrapper_us"] = float(np.median(ts) * 1e3 - host_med["total_us"])  # Python mirror around the C call
         # phase breakdown: the same call with the phase events on
         est.timingEnable(True)
         ph = []
@@ -209,7 +213,7 @@ def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
         out = {"frames": int(n_frames), "ms_per_frame_median": float(np.median(ts)),
                "ms_per_frame_p99": float(np.percentile(ts, 99)),
                "associations_per_s": float(uvs[0].shape[0] / np.median(ts) * 1e3),
-               "breakdown_us_median": breakdown}
+               "breakdown_us_median": breakdown, "host_us_median": host_med}
         if kind != "supplied":  # the last frame against the oracle with the restatement's plane for the same request
             it, i, d, t = last
             ref = oracle.OracleDepthEstimator(P, cam.as_struct(), T)
@@ -227,9 +231,12 @@ def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
         "path": "host pointers, one frame per call: setInputCloud (H2D 2.1 MB) + ground plane (inlier list H2D) + "
                 "CalculateDepth (uv H2D, kernels, depth/type D2H, sync)",
         **sup,
-        "breakdown_keys": "h2d = cloud copy, plane = plane estimation kernels, kernels = projection + feature kernel, d2h = "
-                          "result copy (hipEvents on the context's stream); api = host time to enqueue, wait = host time in "
-                          "the final synchronise, total = host wall time; gpu = first to last event",
+        "breakdown_keys": "breakdown_us_median (instrumented pass: hipEvents on the context's stream cost the call tens of "
+                          "microseconds): h2d = cloud copy, plane = plane estimation kernels, kernels = projection + feature "
+                          "kernel, d2h = result hand-over, gpu = first to last event.  host_us_median (the un-instrumented "
+                          "calls of the median above): pre = host time before the cloud copy is submitted, copycall = host "
+                          "time inside the cloud's hipMemcpyAsync (pageable source), api = entry to last enqueue, wait = "
+                          "final synchronise, total = the C call, wrapper = the Python mirror around it",
     }
     if P.do_use_ransac_plane:
         res["estimated"] = {

@@ -346,9 +346,10 @@ int mld_calculate_depth_frame_estimate(mld_ctx* ctx, int slot, const void* pts_h
                                        const mld_plane_request* plane, const double* uv_host, int64_t F,
                                        double* depth_out_host, int32_t* type_out_host, mld_plane_result* plane_out);
 /*
- * Where the time of the LAST one-frame call (mld_calculate_depth_frame / _frame_estimate) went, when timing is enabled
- * (mld_timing_enable; the hipEvents that bracket the phases cost a few microseconds themselves, so the un-instrumented
- * call is a little faster than their sum).  out_us[8]:
+ * Where the time of the LAST one-frame call (mld_calculate_depth_frame / _frame_estimate) went.  The host-clock entries
+ * ([4]-[6], [8], [9]) are always filled; the GPU phases ([0]-[3], [7]) only when timing is enabled (mld_timing_enable: the
+ * hipEvents that bracket the phases cost the call tens of microseconds, so the un-instrumented call is faster than their
+ * sum) and are 0 otherwise.  out_us[10]:
  *   [0] h2d      cloud copy on the context's stream (the small inputs travel beside it on a side stream)
  *   [1] plane    plane estimation kernels (0 for a supplied plane)
  *   [2] kernels  projection + feature kernel(s)
@@ -357,8 +358,10 @@ int mld_calculate_depth_frame_estimate(mld_ctx* ctx, int slot, const void* pts_h
  *   [5] wait     host time blocked in the final synchronise
  *   [6] total    host wall time of the call
  *   [7] gpu      first event -> last event on the stream ([0]+[1]+[2]+[3] plus the gaps between them)
+ *   [8] pre      host time before the cloud copy is submitted (validation, staging of the small inputs, side-stream work)
+ *   [9] copycall host time inside the cloud's hipMemcpyAsync (a pageable source blocks until it is staged)
  */
-int mld_frame_timing(mld_ctx* ctx, double out_us[8]);
+int mld_frame_timing(mld_ctx* ctx, double out_us[10]);
 /* All slots [0, n_slots) in ONE launch set (host arrays of device pointers / counts). */
 int mld_calculate_depths_device(mld_ctx* ctx, int n_slots, const double* const* uv_dev, const int64_t* F,
                                 double* const* depth_out_dev, int32_t* const* type_out_dev);

@@ -8,10 +8,14 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <ctime>
+#include <functional>
 #include <limits>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mld.h"
@@ -62,6 +66,59 @@ struct TimedLaunch {
 };
 
 }  // namespace
+
+// Helper thread of the one-frame calls (mld_calculate_depth_frame*): while the calling thread sits in the cloud's
+// hipMemcpyAsync - a pageable source blocks it for the whole 2.1 MB - the helper stages the small inputs (features,
+// inlier list, label image) and queues their DMA, the mask build and the bitmap clear on the side stream.  Done by the
+// caller itself that work (25-30 us of host time) used to delay the START of the cloud copy.  One job at a time; the
+// thread sleeps on a condition variable between frames and is created by the first one-frame call of a context.
+struct FrameHelper {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int(std::string&)> job;
+    bool pending = false, quit = false;
+    int rc = 0;
+    std::string err;
+    void run() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return pending || quit; });
+            if (quit) return;
+            std::function<int(std::string&)> j = std::move(job);
+            lk.unlock();
+            std::string e;
+            const int r = j(e);
+            lk.lock();
+            rc = r;
+            err = std::move(e);
+            pending = false;
+            cv.notify_all();
+        }
+    }
+    void submit(std::function<int(std::string&)> j) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = std::move(j);
+            pending = true;
+        }
+        cv.notify_all();
+    }
+    int wait(std::string& e) {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !pending; });
+        e = err;
+        return rc;
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
 
 // The projection stream two paired contexts share (mld_pair_contexts).  Either context may be destroyed first.
 struct ProjShare {
@@ -142,15 +199,17 @@ struct mld_ctx {
     size_t fr_cap = 0;
     unsigned char* fr_host_dev = nullptr;  // the pinned block as the kernels address it (results are written there directly)
     bool fr_zero_copy = true;              // false (test build: MLD_FRAME_COPY=1): results through device memory + a D2H copy
+    bool fr_helper_on = true;              // false (test build: MLD_FRAME_HELPER=0): the calling thread queues the side-stream work
     hipEvent_t fr_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // phase marks of a timed one-frame call
-    double fr_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};                           // mld_frame_timing
+    double fr_us[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                    // mld_frame_timing
     // batched ground-plane estimation (mld_set_clouds_estimate_planes_device)
     uint32_t* rsb_masks = nullptr;   // inlier bitmasks of all slots, contiguous
     size_t rsb_mask_words = 0;       // per slot
     PlaneDev* rsb_planes = nullptr;  // one per slot
     uint32_t* rsb_seeds = nullptr;
     hipStream_t side = nullptr;  // the plane's inlier mask is built here while the cloud is still in flight
-    hipEvent_t side_done = nullptr;
+    hipEvent_t side_done = nullptr, side_start = nullptr;
+    FrameHelper* helper = nullptr;  // stages and queues the side-stream work of a one-frame call beside the cloud copy
     hipEvent_t order_ev = nullptr;  // mld_order_after
     // mld_pair_contexts: the batched projections of two contexts share ONE stream (back to back, no cross-stream
     // hand-over between them); each context's feature kernels stay on its own stream, joined by two events per batch
@@ -368,6 +427,8 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     //   MLD_FRAME_COPY=1       one-frame calls return their results through device memory and a D2H copy (A/B of the
     //                          direct stores into the pinned block)
     if (const char* e = std::getenv("MLD_FRAME_COPY")) ctx->fr_zero_copy = e[0] != '1';
+    //   MLD_FRAME_HELPER=0     one-frame calls without the helper thread (A/B)
+    if (const char* e = std::getenv("MLD_FRAME_HELPER")) ctx->fr_helper_on = e[0] != '0';
     if (const char* e = std::getenv("MLD_K1MAX")) c.k1max = std::min(std::max(std::atoi(e), 8), kK1MaxLimit);
     if (const char* e = std::getenv("MLD_KMAIN")) c.kMain = std::min(std::max(std::atoi(e), 8), c.k1max);
 #endif
@@ -920,8 +981,13 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->rsb_seeds) (void)hipFree(ctx->rsb_seeds);
     if (ctx->fr_host) (void)hipHostFree(ctx->fr_host);
     if (ctx->fr_dev) (void)hipFree(ctx->fr_dev);
+    if (ctx->helper) {
+        ctx->helper->stop();
+        delete ctx->helper;
+    }
     for (hipEvent_t e : ctx->fr_ev)
         if (e) (void)hipEventDestroy(e);
+    if (ctx->side_start) (void)hipEventDestroy(ctx->side_start);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->side_done) (void)hipEventDestroy(ctx->side_done);
     if (ctx->order_ev) (void)hipEventDestroy(ctx->order_ev);
@@ -1729,6 +1795,11 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
     }
+    if (!ctx->side_start) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_start, hipEventDisableTiming));
+    if (!ctx->helper && ctx->fr_helper_on) {
+        ctx->helper = new FrameHelper();
+        ctx->helper->th = std::thread([h = ctx->helper] { h->run(); });
+    }
     if (estimate && !ctx->rsb_planes) {
         HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_planes, ctx->slots.size() * sizeof(PlaneDev)));
         HIP_TRY(ctx, hipMalloc((void**)&ctx->rsb_seeds, ctx->slots.size() * sizeof(uint32_t)));
@@ -1743,31 +1814,76 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
     const bool timed = ctx->timing;
     if (timed && !ctx->fr_ev[0])
         for (int i = 0; i < 5; i++) HIP_TRY(ctx, hipEventCreate(&ctx->fr_ev[i]));
-    // The small inputs go first, on the side stream: their DMA and the mask build run while the cloud is in flight.
-    // (The side stream starts after whatever is already queued on the context's stream: an earlier asynchronous call
-    // on this slot may still read the mask buffer and the staging block that are rewritten here.)
-    HIP_TRY(ctx, hipEventRecord(ctx->side_done, ctx->stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->side_done, 0));
-    if (n_inl) std::memcpy(ctx->fr_host, fp.inliers, n_inl * sizeof(int32_t));
-    if (F) std::memcpy(ctx->fr_host + off_uv, uv_host, (size_t)F * 2 * sizeof(double));
-    if (off_depth) HIP_TRY(ctx, hipMemcpyAsync(ctx->fr_dev, ctx->fr_host, off_depth, hipMemcpyHostToDevice, ctx->side));
-    if (kind == FramePlane::SEMANTIC)
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->sem_img, rq->label_image, img_bytes, hipMemcpyHostToDevice, ctx->side));
-    if (kind == FramePlane::SUPPLIED || kind == FramePlane::RANSAC) {
-        HIP_TRY(ctx, hipMemsetAsync(s.mask_buf, 0, (words < 1 ? 1 : words) * sizeof(uint32_t), ctx->side));
-        if (n_inl) {
-            hipLaunchKernelGGL(k_build_mask, dim3((unsigned)((n_inl + 255) / 256)), dim3(256), 0, ctx->side,
-                               reinterpret_cast<const int32_t*>(ctx->fr_dev), (long long)n_inl, (long long)n, s.mask_buf);
-            HIP_TRY(ctx, hipGetLastError());
+    // The small inputs travel on the side stream: their DMA, the mask build and the bitmap clear run while the cloud is
+    // in flight.  (The side stream starts after whatever is already queued on the context's stream: an earlier
+    // asynchronous call on this slot may still read the mask buffer and the staging block that are rewritten here.)
+    // Staging and queueing them is the helper thread's job, so that THIS thread can submit the cloud copy at once.
+    HIP_TRY(ctx, hipEventRecord(ctx->side_start, ctx->stream));
+    const int device = ctx->device;
+    unsigned char* const fr_host = ctx->fr_host;
+    unsigned char* const fr_dev = ctx->fr_dev;
+    unsigned char* const sem_img = ctx->sem_img;
+    uint32_t* const mask_buf = s.mask_buf;
+    uint32_t* const bitmap = s.d.bitmap;
+    const size_t bitmap_bytes = ctx->bitmap_words * sizeof(uint32_t);
+    hipStream_t side = ctx->side;
+    hipEvent_t ev_start = ctx->side_start, ev_done = ctx->side_done;
+    const int32_t* const inl_src = fp.inliers;
+    const uint8_t* const img_src = kind == FramePlane::SEMANTIC ? rq->label_image : nullptr;
+    const bool clear_mask = kind == FramePlane::SUPPLIED || kind == FramePlane::RANSAC;
+    auto side_work = [=](std::string& err) -> int {
+        auto bad = [&](hipError_t e, const char* what) {
+            err = std::string(what) + ": " + hipGetErrorString(e);
+            return (int)MLD_ERR_HIP;
+        };
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return bad(e, "hipSetDevice");
+        if ((e = hipStreamWaitEvent(side, ev_start, 0)) != hipSuccess) return bad(e, "hipStreamWaitEvent(side)");
+        if (n_inl) std::memcpy(fr_host, inl_src, n_inl * sizeof(int32_t));
+        if (F) std::memcpy(fr_host + off_uv, uv_host, (size_t)F * 2 * sizeof(double));
+        if (off_depth && (e = hipMemcpyAsync(fr_dev, fr_host, off_depth, hipMemcpyHostToDevice, side)) != hipSuccess)
+            return bad(e, "hipMemcpyAsync(features)");
+        if (img_src && (e = hipMemcpyAsync(sem_img, img_src, img_bytes, hipMemcpyHostToDevice, side)) != hipSuccess)
+            return bad(e, "hipMemcpyAsync(label image)");
+        if (clear_mask) {
+            if ((e = hipMemsetAsync(mask_buf, 0, (words < 1 ? 1 : words) * sizeof(uint32_t), side)) != hipSuccess)
+                return bad(e, "hipMemsetAsync(mask)");
+            if (n_inl) {
+                hipLaunchKernelGGL(k_build_mask, dim3((unsigned)((n_inl + 255) / 256)), dim3(256), 0, side,
+                                   reinterpret_cast<const int32_t*>(fr_dev), (long long)n_inl, (long long)n, mask_buf);
+                if ((e = hipGetLastError()) != hipSuccess) return bad(e, "k_build_mask");
+            }
         }
-    }
-    // (the slot's occupancy bitmap is cleared there as well: off the cloud copy's critical path)
-    if ((rc = begin_cloud(ctx, s, s.cloud_buf, n, stride_bytes, true, ctx->side))) return rc;
-    HIP_TRY(ctx, hipEventRecord(ctx->side_done, ctx->side));
+        // (the slot's occupancy bitmap is cleared there as well: off the cloud copy's critical path)
+        if ((e = hipMemsetAsync(bitmap, 0, bitmap_bytes, side)) != hipSuccess) return bad(e, "hipMemsetAsync(bitmap)");
+        if ((e = hipEventRecord(ev_done, side)) != hipSuccess) return bad(e, "hipEventRecord(side)");
+        return (int)MLD_OK;
+    };
+    // (never return while the helper still reads the caller's arrays)
+    struct HelperGuard {
+        FrameHelper* h;
+        ~HelperGuard() {
+            std::string ignored;
+            if (h) (void)h->wait(ignored);
+        }
+    } helper_guard{ctx->helper};
+    int side_rc = MLD_OK;
+    std::string side_err;
+    if (ctx->helper)
+        ctx->helper->submit(side_work);
+    else
+        side_rc = side_work(side_err);  // (no helper thread: the caller queues the side-stream work itself, ahead of the copy)
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->fr_ev[0], ctx->stream));
+    const double t_copy0 = now_us();
     // The cloud, straight from the caller's memory (measured: the runtime's own staging of a pageable source moves
     // 2.1 MB in 51 us, as fast as from pinned memory; copying through a pinned buffer of ours in pieces was slower).
-    if (bytes) HIP_TRY(ctx, hipMemcpyAsync(s.cloud_buf, pts_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipError_t e_copy = hipSuccess;
+    if (bytes) e_copy = hipMemcpyAsync(s.cloud_buf, pts_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    const double t_copy1 = now_us();
+    if (ctx->helper) side_rc = ctx->helper->wait(side_err);
+    HIP_TRY(ctx, e_copy);
+    if (side_rc) return fail(ctx, side_rc, side_err);
+    if ((rc = begin_cloud(ctx, s, s.cloud_buf, n, stride_bytes, false))) return rc;  // (bitmap cleared on the side stream)
     if (timed) HIP_TRY(ctx, hipEventRecord(ctx->fr_ev[1], ctx->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
     PlaneDev* pd_copy = reinterpret_cast<PlaneDev*>(out_base + off_plane);
@@ -1817,15 +1933,22 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
         if (e != hipSuccess) {
             ctx->err = std::string("mld_calculate_depth_frame: ") + hipGetErrorString(e);
             rc = MLD_ERR_HIP;
-        } else if (timed) {
-            float ms[4] = {0, 0, 0, 0}, all = 0;
-            for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&ms[i], ctx->fr_ev[i], ctx->fr_ev[i + 1]);
-            (void)hipEventElapsedTime(&all, ctx->fr_ev[0], ctx->fr_ev[4]);
-            for (int i = 0; i < 4; i++) ctx->fr_us[i] = 1e3 * (double)ms[i];
+        } else {
+            // host clock: always (a few clock reads); GPU phases only when the events were recorded
             ctx->fr_us[4] = t_enq - t_entry;
             ctx->fr_us[5] = t_done - t_enq;
             ctx->fr_us[6] = t_done - t_entry;  // (up to here: the copies into the caller's arrays follow)
-            ctx->fr_us[7] = 1e3 * (double)all;
+            ctx->fr_us[8] = t_copy0 - t_entry;
+            ctx->fr_us[9] = t_copy1 - t_copy0;
+            for (int i = 0; i < 4; i++) ctx->fr_us[i] = 0.0;
+            ctx->fr_us[7] = 0.0;
+            if (timed) {
+                float ms[4] = {0, 0, 0, 0}, all = 0;
+                for (int i = 0; i < 4; i++) (void)hipEventElapsedTime(&ms[i], ctx->fr_ev[i], ctx->fr_ev[i + 1]);
+                (void)hipEventElapsedTime(&all, ctx->fr_ev[0], ctx->fr_ev[4]);
+                for (int i = 0; i < 4; i++) ctx->fr_us[i] = 1e3 * (double)ms[i];
+                ctx->fr_us[7] = 1e3 * (double)all;
+            }
         }
     }
     // the slot must not keep pointers into the staging block (it is reused by the next call)
@@ -1887,9 +2010,9 @@ int mld_calculate_depth_frame_estimate(mld_ctx* ctx, int slot, const void* pts_h
     return frame_call(ctx, slot, pts_host, n, stride_bytes, fp, uv_host, F, depth_out_host, type_out_host, plane_out);
 }
 
-int mld_frame_timing(mld_ctx* ctx, double out_us[8]) {
+int mld_frame_timing(mld_ctx* ctx, double out_us[10]) {
     if (!ctx || !out_us) return MLD_ERR_INVALID_ARG;
-    for (int i = 0; i < 8; i++) out_us[i] = ctx->fr_us[i];
+    for (int i = 0; i < 10; i++) out_us[i] = ctx->fr_us[i];
     return MLD_OK;
 }
 

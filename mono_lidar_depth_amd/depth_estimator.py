@@ -746,10 +746,11 @@ class DepthEstimator:
 
     # ------------------------------------------------------------------ measurement hooks
     def frameTiming(self) -> dict:
-        """Phases of the last one-frame call in microseconds (mld_frame_timing; needs timingEnable(True))."""
-        out = (C.c_double * 8)()
+        """Phases of the last one-frame call in microseconds (mld_frame_timing): host-clock entries always, the GPU
+        phases (h2d / plane / kernels / d2h / gpu) only with timingEnable(True)."""
+        out = (C.c_double * 10)()
         self._check(self._lib.mld_frame_timing(self._ctx, out))
-        keys = ("h2d_us", "plane_us", "kernels_us", "d2h_us", "api_us", "wait_us", "total_us", "gpu_us")
+        keys = ("h2d_us", "plane_us", "kernels_us", "d2h_us", "api_us", "wait_us", "total_us", "gpu_us", "pre_us", "copycall_us")
         return {k: float(v) for k, v in zip(keys, out)}
 
     def timingEnable(self, on: bool = True):
