@@ -332,7 +332,10 @@ __global__ __launch_bounds__(kPartials) void k_rs_refine(const float* __restrict
 // candidate count of every group in LDS; the pos-th candidate of the stratified sample is then found by a binary search
 // over per-1024-point prefix sums, a walk over the sixteen group counts of that chunk and a bit select in its mask.
 // ------------------------------------------------------------------------------------------------
-constexpr int kRsThreads = 1024;
+#ifndef MLD_RS_THREADS
+#define MLD_RS_THREADS 1024
+#endif
+constexpr int kRsThreads = MLD_RS_THREADS;
 constexpr int kRsRound = kRsThreads / kWave;  // hypotheses evaluated per round
 constexpr int kRsPerThread = (kSample + kRsThreads - 1) / kRsThreads;  // sample points per thread
 constexpr int kRsEpoch = kRsThreads;  // draws whose models are set up together (after a slot's first 64)
