@@ -186,7 +186,7 @@ def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
             return RansacPlane(seed=it + 1)
         return SemanticPlane(imgs[i % len(imgs)], labels, thr)
 
-    def run(kind):
+    def run(kind, clouds=clouds):
         ts, host = [], []
         last = None
         for it in range(n_frames + 10):
@@ -227,6 +227,17 @@ def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
         return out
 
     sup = run("supplied")
+    # the same call with the clouds in PINNED host memory (a caller that allocates its cloud buffers with hipHostMalloc /
+    # hipHostRegister): the copy no longer blocks the calling thread and runs at the DMA rate - informational, the
+    # reference's nodelets hand over pageable memory
+    pinned = None
+    try:
+        import torch
+        pc = [torch.from_numpy(c).pin_memory().numpy() for c in clouds]
+        pinned = run("supplied", pc)
+        del pc
+    except Exception as e:  # noqa: BLE001
+        pinned = {"error": str(e)}
     res = {
         "path": "host pointers, one frame per call: setInputCloud (H2D 2.1 MB) + ground plane (inlier list H2D) + "
                 "CalculateDepth (uv H2D, kernels, depth/type D2H, sync)",
@@ -238,6 +249,7 @@ def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
                           "time inside the cloud's hipMemcpyAsync (pageable source), api = entry to last enqueue, wait = "
                           "final synchronise, total = the C call, wrapper = the Python mirror around it",
     }
+    res["pinned_source"] = pinned
     if P.do_use_ransac_plane:
         res["estimated"] = {
             "path": "the same call with a GroundPlane that is not segmented yet (the reference's production call): plane "
@@ -1181,13 +1193,15 @@ def main():
                      "frame_slots_per_launch": res.est_S, "verified": ok_e, "frames_checked": len(est_frames),
                      "poison_left": poison_e}
     if world == 1:
-        if args.cpu_seconds > 0:
-            cpu = cpu_baseline(P, cam_struct, T, res.clouds_h, res.planes_h, res.uvs_h, args.cpu_seconds)
+        # (the one-frame latency legs first: the CPU baseline keeps sixteen OpenMP threads busy for seconds, and calls
+        # timed right after it are 10 % slower and noisier)
         if args.latency_frames > 0:
             latency = latency_leg(P, cam, T, res.clouds_h, res.planes_h, res.uvs_h, args.latency_frames, gpu_index)
         if args.streaming_batches > 0:
             streaming = streaming_leg(P, cam, T, res.clouds_h, res.planes_h, res.uvs_h, gpu_index, args.streaming_frames,
                                       args.streaming_batches)
+        if args.cpu_seconds > 0:
+            cpu = cpu_baseline(P, cam_struct, T, res.clouds_h, res.planes_h, res.uvs_h, args.cpu_seconds)
     clouds_kept = None  # noqa: F841
     res.close()
     del res
