@@ -485,6 +485,8 @@ struct ProjectionScope {
 // clouds of different sizes share it, so the size enabled so far is kept per device (it only ever grows).
 int enable_rs_batch_lds(mld_ctx* ctx, size_t lds) {
     static size_t enabled[64] = {};
+    static std::mutex mtx;  // (contexts of one device may be driven from different host threads)
+    std::lock_guard<std::mutex> lk(mtx);
     size_t& cur = enabled[ctx->device & 63];
     if (lds <= cur) return MLD_OK;
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(ransac::k_rs_batch),

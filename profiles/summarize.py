@@ -96,6 +96,25 @@ if stats_l:
     except Exception as e:  # noqa: BLE001
         lines += ["", f"(latency legs not parsed: {e})"]
     lines.append("")
+    try:
+        bl = json.loads(open(f"{src}/bench_latency.json").read().strip().splitlines()[-1])["latency"]
+        lines += ["Without the tracer (same box, same session; `bench.py --latency-frames 200`, 200 calls per leg) - the numbers of "
+                  "record for the one-frame calls:", "",
+                  "| leg | median us | p99 us | host phases of the un-instrumented call (median us) | GPU phases of the instrumented pass (median us) |",
+                  "|---|---|---|---|---|"]
+        legs = [("supplied plane (`mld_calculate_depth_frame`)", bl), ("supplied plane, cloud in pinned host memory", bl.get("pinned_source") or {}),
+                ("plane estimated in the call, RANSAC (`mld_calculate_depth_frame_estimate`)", bl["estimated"]["ransac"]),
+                ("plane estimated in the call, semantic label image", bl["estimated"]["semantic"])]
+        for name, leg in legs:
+            if "ms_per_frame_median" not in leg:
+                continue
+            hp = ", ".join(f"{k[:-3]} {v:.1f}" for k, v in (leg.get("host_us_median") or {}).items())
+            gp = ", ".join(f"{k[:-3]} {v:.1f}" for k, v in (leg.get("breakdown_us_median") or {}).items()
+                           if k in ("h2d_us", "plane_us", "kernels_us", "d2h_us", "gpu_us"))
+            lines.append(f"| {name} | {leg['ms_per_frame_median'] * 1e3:.1f} | {leg['ms_per_frame_p99'] * 1e3:.1f} | {hp} | {gp} |")
+        lines.append("")
+    except Exception as e:  # noqa: BLE001
+        lines += [f"(un-traced latency legs not parsed: {e})", ""]
 lines += ["## PMC (per launch, mean over launches)", "",
           "FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half the bytes of a wide (16 B/lane) "
           "coalesced read (MI355X_MICROARCH.md §HBM): `hbm_read_corrected` doubles it for k_project_scatter "
