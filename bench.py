@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--slots", type=int, default=0,
                     help="frame slots of the context (0 = frames-per-step); a step runs frames-per-step/slots launch sets")
     ap.add_argument("--no-estimated", action="store_true", help="skip the plane-estimated leg")
+    ap.add_argument("--est-schedule", choices=["halves", "alternate"], default="halves",
+                    help="plane-estimated leg with two contexts: every context takes half of a step's frames, side by side "
+                         "(halves), or whole steps alternate as in the supplied-plane schedule (alternate)")
     ap.add_argument("--no-exclusive", action="store_true",
                     help="skip the pass that times each kernel alone (profiling: keeps the kernel statistics of a trace "
                          "to the launches of the timed schedule)")
@@ -459,6 +462,20 @@ class Resident:
         the GroundPlane handed to setInputCloud is not segmented yet) instead of supplied."""
         import ctypes as C
         todo = self.batches
+        if self.whole and len(self.ests) > 1 and getattr(self, "est_schedule", "halves") == "alternate":
+            # whole steps in turn, as run_step: the next context's estimation + projection released by the end of this one's
+            nb = len(self.batches)
+            e, b = self.batches[self.k % nb]
+            nxt = self.batches[(self.k + 1) % nb][0]
+            n = b["n"]
+            if "seeds" not in b:
+                b["seeds"] = (C.c_uint32 * n)(*range(1, n + 1))
+            e._check(e._lib.mld_set_clouds_estimate_planes_device(e._ctx, n, b["cloud_ptrs"], b["cloud_n"], b["stride"],
+                                                                  b["seeds"]))
+            nxt.orderAfter(e)
+            e._check(e._lib.mld_calculate_depths_device(e._ctx, n, b["uv_ptrs"], b["F"], b["depth_ptrs"], b["type_ptrs"]))
+            self.k += 1
+            return
         if self.whole and len(self.ests) > 1:
             # (k_rs_batch - a 1024-thread block and 150 KB of LDS per frame - fits neither beside the feature kernels nor
             # beside a projection, so alternating whole steps gains nothing here: every context takes its share of the
@@ -1168,29 +1185,36 @@ def main():
         # the reference's default call: the plane of every frame estimated on the GPU (seeded RANSAC, batched, no host
         # round trip) instead of supplied; checked against the restatement's estimate for three frames
         from oracle import oracle
-        for e in res.ests:
-            e.setSharedGpu(False)
+        res.est_schedule = args.est_schedule
+        alt = args.est_schedule == "alternate" and res.whole and len(res.ests) > 1
+        if alt:
+            res.est_S = res.S
+        else:
+            for e in res.ests:
+                e.setSharedGpu(False)
         loops_e, kt_e = timed_resident(res, max(2, args.steps // 2), 2, timing, 2, estimated=True)
         el_e = loops_e[0]
+        est_set = ((res.k - 1) % len(res.batches)) if alt else 0  # output set of the last step of this leg
         for e in res.ests:
             e.setSharedGpu(res.shared_mode if len(res.ests) > 1 else 0)
         ok_e = True
         # sixteen frames, one of every distinct cloud of the batch (frame 14 is the one whose draws are mostly skipped)
         est_frames = sorted({min(B - 1, k * max(1, B // 16) + (k % U)) for k in range(16)} | {min(14, B - 1), B - 1})
-        poison_e = res.poison_left(sets=[0])  # (this leg writes every frame into the first output set)
+        poison_e = res.poison_left(sets=[est_set])  # (halves: every frame goes into the first output set)
         ok_e = poison_e["type_minus77"] == 0
         for fr in est_frames:
             ref = oracle.OracleDepthEstimator(P, cam_struct, T)
             ref.set_cloud(res.clouds_h[fr % U])
             ref.estimate_ground_plane((fr % res.est_S) + 1)
             d0, t0 = ref.calculate_depth(res.uvs_h[fr], 8)
-            dg, tg = res.all_depth[fr].cpu().numpy(), res.all_type[fr].cpu().numpy()
+            dg, tg = res.out_depth[est_set][fr].cpu().numpy(), res.out_type[est_set][fr].cpu().numpy()
             ok_e = ok_e and bool(np.array_equal(tg, t0) and np.allclose(dg, d0, rtol=0, atol=1e-4, equal_nan=True))
         n_e = max(2, args.steps // 2)
         estimated = {"plane": "estimated", "value": B * F * n_e / el_e, "ms_per_step": 1e3 * el_e / n_e,
                      "kernels_ms_per_launch": {k: v["avg_ms"] for k, v in kt_e.items()},
                      "ransac_us_per_frame": 1e3 * kt_e.get("k_rs_batch", {}).get("avg_ms", 0.0) / res.est_S,
-                     "frame_slots_per_launch": res.est_S, "verified": ok_e, "frames_checked": len(est_frames),
+                     "frame_slots_per_launch": res.est_S, "schedule": args.est_schedule, "verified": ok_e,
+                     "frames_checked": len(est_frames),
                      "poison_left": poison_e}
     if world == 1:
         # (the one-frame latency legs first: the CPU baseline keeps sixteen OpenMP threads busy for seconds, and calls

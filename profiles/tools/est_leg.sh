@@ -9,7 +9,7 @@ print('$2 $1', 'step', round(d['ms_per_step'],4), 'estimated', round(e['ms_per_s
 }
 LIBS=${@:--}
 for r in 1 2; do
-for extra in "" "--contexts 1"; do
+for extra in "" "--est-schedule alternate" "--contexts 1"; do
   for lib in $LIBS; do
     if [ "$lib" = "-" ]; then unset MLD_HIP_LIBRARY; else export MLD_HIP_LIBRARY=$PWD/profiles/tools/libs/$lib.so; fi
     run "$extra" "$lib"
