@@ -220,3 +220,35 @@ def test_large_cloud_with_the_pass_through_takes_the_per_slot_estimator():
     c0, inl0 = ref.estimate_ground_plane(4)
     assert np.array_equal(gp.getModelCoeffs(), c0) and np.array_equal(gp.getInlinersIndex(), inl0)
     assert_depth_parity(d, t, *ref.calculate_depth(uv))
+
+
+@pytest.mark.parametrize("switch", ["MLD_FRAME_HELPER=0", "MLD_FRAME_COPY=1"])
+def test_one_frame_call_variants_of_the_test_build(switch, monkeypatch):
+    """The A/B switches of the measurement build (no helper thread: the caller queues the side-stream work itself;
+    results through device memory and a D2H copy instead of direct stores into the pinned block) give the same results."""
+    name, value = switch.split("=")
+    monkeypatch.setenv(name, value)
+    monkeypatch.setattr(capi, "_lib", capi.load_ab())
+    P = capi.params_c0()
+    cloud = synth.make_cloud(synth.HDL64_KITTI, seed=17, frame=3)
+    uv = synth.make_features(1500, seed=17)
+    ref = make_oracle(P)
+    ref.set_cloud(cloud)
+    est = make_estimator(P)
+    # supplied plane
+    plane = synth.make_ground_plane(cloud)
+    ref.set_ground_plane(*plane)
+    d, t = est.CalculateDepth(cloud, uv, GroundPlane(*plane))
+    assert_depth_parity(d, t, *ref.calculate_depth(uv))
+    # plane estimated inside the call, both estimators
+    gp = RansacPlane(seed=9)
+    d, t = est.CalculateDepth(cloud, uv, gp)
+    c0, inl0 = ref.estimate_ground_plane(9)
+    assert np.array_equal(gp.getModelCoeffs(), c0) and np.array_equal(gp.getInlinersIndex(), inl0)
+    assert_depth_parity(d, t, *ref.calculate_depth(uv))
+    img = synth.make_label_image(cloud)
+    sp = SemanticPlane(img, LABELS, 0.1)
+    d, t = est.CalculateDepth(cloud, uv, sp)
+    c1, inl1 = ref.estimate_semantic_plane(img, LABELS, 0.1)
+    assert np.array_equal(sp.getModelCoeffs(), c1) and sp.n_inliers == inl1.size
+    assert_depth_parity(d, t, *ref.calculate_depth(uv))
