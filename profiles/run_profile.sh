@@ -19,7 +19,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_e -- python3 
 # the one-frame-per-call legs (supplied plane, RANSAC and semantic plane estimated inside the call): kernels of a frame
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_l -- python3 $REPO/bench.py --steps 2 --warmup 1 --repeats 1 --min-timed-seconds 0 --frames-per-step 64 --verify-slots 4 --cpu-seconds 0 --latency-frames 100 --streaming-batches 0 --config-frames 0 --no-estimated --no-exclusive > $OUT/bench_trace_l.json 2> $OUT/trace_l.log
 # the same legs WITHOUT the tracer (the numbers of record for the one-frame calls: rocprofv3 costs them 15-30 us)
-python3 $REPO/bench.py --steps 2 --warmup 1 --repeats 1 --min-timed-seconds 0 --frames-per-step 64 --verify-slots 4 --cpu-seconds 0 --latency-frames 200 --streaming-batches 0 --config-frames 0 --no-estimated --no-exclusive > $OUT/bench_latency.json 2> $OUT/latency.log
+python3 $REPO/bench.py --steps 2 --warmup 1 --repeats 1 --min-timed-seconds 0 --frames-per-step 64 --verify-slots 4 --cpu-seconds 8 --latency-frames 200 --streaming-batches 24 --config-frames 0 --no-estimated --no-exclusive > $OUT/bench_latency.json 2> $OUT/latency.log
 # counters: rocprofv3 serialises the kernels in these passes, so they are collected on the one-context schedule
 PMCARGS="--contexts 1 --steps 4 --warmup 1 --repeats 1 $COMMON --no-kernel-timing --no-estimated"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log

@@ -97,7 +97,16 @@ if stats_l:
         lines += ["", f"(latency legs not parsed: {e})"]
     lines.append("")
     try:
-        bl = json.loads(open(f"{src}/bench_latency.json").read().strip().splitlines()[-1])["latency"]
+        bfull = json.loads(open(f"{src}/bench_latency.json").read().strip().splitlines()[-1])
+        bl = bfull["latency"]
+        st, cb = bfull.get("streaming"), bfull.get("cpu_baseline")
+        if st:
+            lines += [f"PCIe-inclusive throughput (`streaming`: {st['frames_per_batch']}-frame batches from pinned host memory, double-buffered, "
+                      f"results copied back): {st['frames_per_s'] / 1e3:.1f} k frames/s = {st['associations_per_s'] / 1e6:.1f} M associations/s, "
+                      f"{st['h2d_GBps']:.1f} GB/s host to device.", ""]
+        if cb:
+            lines += [f"`cpu_baseline` (the restated reference path on this host, kind `{cb['kind']}`, {cb['cores']} threads): "
+                      f"{cb['value'] / 1e6:.2f} M associations/s, {cb['ms_per_frame']:.2f} ms per frame (stage A {cb['stage_a_ms']:.2f} ms serial).", ""]
         lines += ["Without the tracer (same box, same session; `bench.py --latency-frames 200`, 200 calls per leg) - the numbers of "
                   "record for the one-frame calls:", "",
                   "| leg | median us | p99 us | host phases of the un-instrumented call (median us) | GPU phases of the instrumented pass (median us) |",
