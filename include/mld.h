@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MLD_ABI_VERSION 6
+#define MLD_ABI_VERSION 7
 
 typedef enum mld_status {
     MLD_OK = 0,
@@ -391,6 +391,22 @@ int mld_tracklets_depth(mld_ctx* ctx, int slot_cur, int slot_last, const float* 
                         const float* u_old, const float* v_old, const uint8_t* is_new, int64_t n_tracks,
                         float* d_cur_out, float* d_last_out, int32_t* type_cur_out, int32_t* type_last_out,
                         int64_t* n_new_host);
+/*
+ * TrackletDepthModule::process (tracklet_depth_module.cpp:261-396) for ONE frame held in host memory as a single call -
+ * the ROS callback's whole GPU side: setInputCloud of the new cloud on `slot_cur` with its ground plane (`plane`: not
+ * segmented yet, estimated on the GPU inside the call as in mld_calculate_depth_frame_estimate - what the reference's
+ * process() does every frame; or plane == NULL and coeffs / inliers: a segmented plane; both NULL: no plane), the
+ * feature marshalling, both CalculateDepth calls (the previous frame from its resident `slot_last`, -1: none) and the
+ * float32 scatter of mld_tracklets_depth.  One asynchronous chain, one synchronisation; track arrays and results travel in
+ * one pinned block each way.  Arrays and outputs as mld_tracklets_depth.  A failed plane estimation
+ * (GroundPlane::ExceptionPclInvalid) returns MLD_ERR_CLOUD_TOO_SMALL with d_cur_out = -1 and d_last_out answered from
+ * the previous frame, as the reference's two try blocks do (:318-347).
+ */
+int mld_tracklets_frame(mld_ctx* ctx, int slot_cur, int slot_last, const void* pts_host, int64_t n, int stride_bytes,
+                        const mld_plane_request* plane, const float coeffs[4], const int32_t* inlier_idx_host,
+                        int64_t n_inliers, const float* u_new, const float* v_new, const float* u_old, const float* v_old,
+                        const uint8_t* is_new, int64_t n_tracks, float* d_cur_out, float* d_last_out, int32_t* type_cur_out,
+                        int32_t* type_last_out, int64_t* n_new_host, mld_plane_result* plane_out);
 /*
  * The tracklet layer at batch size: the current frames of n_seq independent SEQUENCES in one launch set
  * (TrackletDepthModule::process, tracklet_depth_module.cpp:261-396, once per sequence).  The context's frame slots are

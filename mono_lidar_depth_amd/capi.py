@@ -12,7 +12,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libmld_hip.so"
 
-MLD_ABI_VERSION = 6  # include/mld.h
+MLD_ABI_VERSION = 7  # include/mld.h
 MLD_OK = 0
 MLD_ERR_INVALID_ARG = -1
 MLD_ERR_NOT_INITIALIZED = -2
@@ -178,6 +178,9 @@ _SIGNATURES = [
      [C.c_void_p] * 4 + [_P(C.c_int64)]),
     ("mld_tracklets_depth", C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_int64] +
      [C.c_void_p] * 4 + [_P(C.c_int64)]),
+    ("mld_tracklets_frame", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int, _P(MldPlaneRequest),
+                                      _P(C.c_float), C.c_void_p, C.c_int64] + [C.c_void_p] * 5 + [C.c_int64] +
+     [C.c_void_p] * 4 + [_P(C.c_int64), _P(MldPlaneResult)]),
     ("mld_set_clouds_planes_range_device", C.c_int, [C.c_void_p, C.c_int, C.c_int, _P(C.c_void_p), _P(C.c_int64), C.c_int,
                                                      _P(C.c_float), _P(C.c_void_p)]),
     ("mld_tracklets_depths_device", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [_P(C.c_void_p)] * 5 +

@@ -1705,6 +1705,17 @@ struct FramePlane {
     int64_t n_inliers = 0;
     const mld_plane_request* req = nullptr;  // RANSAC / SEMANTIC
 };
+// The feature side of a one-frame call given as tracklets (TrackletDepthModule::process): gather -> depths of the newest
+// features on the frame being uploaded, of the NEW tracks' previous features on the resident previous frame -> scatter.
+struct FrameTracks {
+    int slot_last = -1;
+    const float *u_new = nullptr, *v_new = nullptr, *u_old = nullptr, *v_old = nullptr;
+    const uint8_t* is_new = nullptr;
+    int64_t n = 0;
+    float *d_cur_out = nullptr, *d_last_out = nullptr;
+    int32_t *type_cur_out = nullptr, *type_last_out = nullptr;
+    int64_t* n_new_out = nullptr;
+};
 double now_us() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -1712,14 +1723,26 @@ double now_us() {
 }
 }  // namespace
 
+static int ensure_tracklet_scratch(mld_ctx* ctx, size_t n);
+
 static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, int stride_bytes, const FramePlane& fp,
                       const double* uv_host, int64_t F, double* depth_out_host, int32_t* type_out_host,
-                      mld_plane_result* plane_out) {
+                      mld_plane_result* plane_out, const FrameTracks* trk = nullptr) {
     using namespace ransac;
     const double t_entry = now_us();
     int rc = check_slot(ctx, slot);
     if (rc) return rc;
     if ((rc = bind_device(ctx))) return rc;
+    const int64_t nt = trk ? trk->n : 0;
+    if (trk) {
+        if (trk->slot_last >= 0 && (rc = check_slot(ctx, trk->slot_last))) return rc;
+        if (trk->slot_last == slot) return fail(ctx, MLD_ERR_INVALID_ARG, "slot_last must differ from slot_cur");
+        if (nt < 0 || nt > 0x7FFFFFFFLL) return fail(ctx, MLD_ERR_INVALID_ARG, "bad track count");
+        if (nt > 0 && (!trk->u_new || !trk->v_new || !trk->u_old || !trk->v_old || !trk->is_new || !trk->d_cur_out || !trk->d_last_out))
+            return fail(ctx, MLD_ERR_INVALID_ARG, "null tracklet array");
+        if (trk->slot_last >= 0 && (rc = precheck_calc(ctx, ctx->slots[trk->slot_last], nt))) return rc;
+        if (ctx->P.set_all_depths_to_zero) return fail(ctx, MLD_ERR_UNSUPPORTED_MODE, "set_all_depths_to_zero: use mld_tracklets_depth");
+    }
     if (n < 0 || (!pts_host && n > 0)) return fail(ctx, MLD_ERR_INVALID_ARG, "bad cloud");
     if (stride_bytes != 16 && stride_bytes != 32) return fail(ctx, MLD_ERR_INVALID_ARG, "stride_bytes must be 16 or 32");
     if (n > kMaxPoints) return fail(ctx, MLD_ERR_CAPACITY, "cloud larger than 8 388 607 points");
@@ -1730,6 +1753,12 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
     if (!P.do_use_ransac_plane && kind != FramePlane::NONE) kind = FramePlane::NONE;  // the plane is ignored (:274)
     if (kind == FramePlane::SUPPLIED && (fp.n_inliers < 0 || (!fp.inliers && fp.n_inliers > 0)))
         return fail(ctx, MLD_ERR_INVALID_ARG, "bad inlier list");
+    // RansacPlane.cpp:44-50 / :224-227: fewer than three points cannot carry a plane - the reference throws out of
+    // setInputCloud before anything else happens.  With tracklets the previous frame's features are still answered
+    // (tracklet_depth_module.cpp:318-347): the frame runs without a plane and the call reports the failure at the end.
+    const bool too_small = (kind == FramePlane::RANSAC || kind == FramePlane::SEMANTIC) && n < 3;
+    if (too_small && !trk) return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");
+    if (too_small) kind = FramePlane::NONE;
     const bool estimate = kind == FramePlane::RANSAC || kind == FramePlane::SEMANTIC;
     const mld_plane_request* rq = fp.req;
     if (kind == FramePlane::SEMANTIC &&
@@ -1738,9 +1767,6 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
         return fail(ctx, MLD_ERR_INVALID_ARG, "bad label image / label set");
     const int n_draws = P.ransac_plane_max_iterations + 1;
     if (kind == FramePlane::RANSAC && n_draws < 1) return fail(ctx, MLD_ERR_INVALID_ARG, "ransac_plane_max_iterations must be >= 0");
-    // RansacPlane.cpp:44-50 / :224-227: fewer than three points cannot carry a plane - the reference throws out of
-    // setInputCloud before anything else happens
-    if (estimate && n < 3) return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");
     Slot& s = ctx->slots[slot];
     // RANSAC with the z pass-through on a cloud too large for the one-block kernel's LDS: the per-slot estimator
     // (it synchronises once before the feature kernels)
@@ -1766,10 +1792,16 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
         }
     }
     const size_t n_inl = kind == FramePlane::SUPPLIED ? (size_t)fp.n_inliers : 0;
+    // staging block: [inlier list | inputs] travel to the device in one DMA, [outputs | plane] come back
+    //   features: inputs uv (2 F doubles), outputs depth (F doubles) + type (F ints)
+    //   tracklets: inputs u_new, v_new, u_old, v_old (floats) + is_new (bytes), outputs d_cur, d_last (floats) + type_cur,
+    //              type_last (ints) + the number of new tracks
     const size_t off_uv = (n_inl * sizeof(int32_t) + 15) & ~(size_t)15;
-    const size_t off_depth = off_uv + (size_t)F * 2 * sizeof(double);
-    const size_t off_type = off_depth + (size_t)F * sizeof(double);
-    const size_t off_plane = (off_type + (size_t)F * sizeof(int32_t) + 15) & ~(size_t)15;
+    const size_t in_bytes = trk ? (((size_t)nt * 17 + 15) & ~(size_t)15) : (size_t)F * 2 * sizeof(double);
+    const size_t off_depth = off_uv + in_bytes;
+    const size_t off_type = off_depth + (size_t)F * sizeof(double);  // (features only)
+    const size_t out_bytes = trk ? (size_t)nt * 16 + 16 : (size_t)F * (sizeof(double) + sizeof(int32_t));
+    const size_t off_plane = (off_depth + out_bytes + 15) & ~(size_t)15;
     const size_t total = off_plane + sizeof(PlaneDev) + 16;
     if (total > ctx->fr_cap) {
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1792,7 +1824,11 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
     // inlier bitmask of the slot; the one-block RANSAC also keeps its 64-bit pass-through group masks there (even word count)
     const size_t words = kind == FramePlane::RANSAC ? (((size_t)((n + 31) / 32) + 2) & ~(size_t)1) : (size_t)((n + 31) / 32);
     if (kind != FramePlane::NONE && (rc = grow(ctx, s.mask_buf, s.mask_words, words))) return rc;
-    if ((rc = ensure_queues(ctx, s, F))) return rc;
+    if ((rc = ensure_queues(ctx, s, trk ? nt : F))) return rc;
+    if (trk) {
+        if ((rc = ensure_tracklet_scratch(ctx, (size_t)nt))) return rc;
+        if (trk->slot_last >= 0 && (rc = ensure_queues(ctx, ctx->slots[trk->slot_last], nt))) return rc;
+    }
     if (!ctx->side) {
         HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming));
@@ -1833,6 +1869,7 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
     const int32_t* const inl_src = fp.inliers;
     const uint8_t* const img_src = kind == FramePlane::SEMANTIC ? rq->label_image : nullptr;
     const bool clear_mask = kind == FramePlane::SUPPLIED || kind == FramePlane::RANSAC;
+    const FrameTracks tk = trk ? *trk : FrameTracks{};
     auto side_work = [=](std::string& err) -> int {
         auto bad = [&](hipError_t e, const char* what) {
             err = std::string(what) + ": " + hipGetErrorString(e);
@@ -1843,6 +1880,12 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
         if ((e = hipStreamWaitEvent(side, ev_start, 0)) != hipSuccess) return bad(e, "hipStreamWaitEvent(side)");
         if (n_inl) std::memcpy(fr_host, inl_src, n_inl * sizeof(int32_t));
         if (F) std::memcpy(fr_host + off_uv, uv_host, (size_t)F * 2 * sizeof(double));
+        if (nt) {
+            unsigned char* q = fr_host + off_uv;
+            const float* src[4] = {tk.u_new, tk.v_new, tk.u_old, tk.v_old};
+            for (int a = 0; a < 4; a++) std::memcpy(q + (size_t)a * (size_t)nt * 4, src[a], (size_t)nt * 4);
+            std::memcpy(q + (size_t)nt * 16, tk.is_new, (size_t)nt);
+        }
         if (off_depth && (e = hipMemcpyAsync(fr_dev, fr_host, off_depth, hipMemcpyHostToDevice, side)) != hipSuccess)
             return bad(e, "hipMemcpyAsync(features)");
         if (img_src && (e = hipMemcpyAsync(sem_img, img_src, img_bytes, hipMemcpyHostToDevice, side)) != hipSuccess)
@@ -1921,13 +1964,42 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
     if ((rc = launch_project(ctx, 1, n, true, slot))) return rc;
     double* d_depth = reinterpret_cast<double*>(out_base + off_depth);
     int32_t* d_type = reinterpret_cast<int32_t*>(out_base + off_type);
-    if (F > 0) rc = calc_one(ctx, slot, reinterpret_cast<const double*>(ctx->fr_dev + off_uv), F, d_depth, d_type);
+    if (F > 0) rc = calc_one(ctx, slot, reinterpret_cast<const double*>(ctx->fr_dev + off_uv), F, d_depth, d_type, nullptr, false);
+    if (trk && nt > 0) {
+        // TrackletDepthModule::process (tracklet_depth_module.cpp:23-169) on the frame just projected: marshal the
+        // features, both CalculateDepth calls (the previous frame from its resident slot), float32 scatter
+        const float* in = reinterpret_cast<const float*>(ctx->fr_dev + off_uv);
+        float* o_cur = reinterpret_cast<float*>(out_base + off_depth);
+        float* o_last = o_cur + nt;
+        int32_t* o_tc = reinterpret_cast<int32_t*>(o_last + nt);
+        int32_t* o_tl = o_tc + nt;
+        long long* o_nn = reinterpret_cast<long long*>(o_tl + nt);
+        const int slot_last = trk->slot_last;
+        hipLaunchKernelGGL(k_tracklet_gather, dim3(1), dim3(kTrkBlock), 0, ctx->stream, in, in + nt, in + 2 * nt, in + 3 * nt,
+                           reinterpret_cast<const uint8_t*>(in + 4 * nt), (long long)nt, ctx->trk_uv_cur, ctx->trk_uv_last,
+                           ctx->trk_rank, ctx->trk_n_new);
+        HIP_TRY(ctx, hipGetLastError());
+        rc = calc_one(ctx, slot, ctx->trk_uv_cur, nt, ctx->trk_depth_cur, ctx->trk_type_cur, nullptr, false);
+        if (rc == MLD_OK && slot_last >= 0) {
+            Slot& sl = ctx->slots[slot_last];
+            sl.d.F_dev = ctx->trk_n_new;  // the number of new tracks is only known on the device
+            rc = calc_one(ctx, slot_last, ctx->trk_uv_last, nt, ctx->trk_depth_last, ctx->trk_type_last, nullptr, false);
+            sl.d.F_dev = nullptr;
+        }
+        if (rc == MLD_OK) {
+            hipLaunchKernelGGL(k_tracklet_scatter, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, ctx->stream,
+                               ctx->trk_depth_cur, ctx->trk_type_cur, ctx->trk_depth_last, ctx->trk_type_last, ctx->trk_rank,
+                               (long long)nt, slot_last >= 0 ? 1 : 0, o_cur, o_last, o_tc, o_tl,
+                               (const long long*)ctx->trk_n_new, o_nn);
+            if (hipGetLastError() != hipSuccess) rc = fail(ctx, MLD_ERR_HIP, "k_tracklet_scatter");
+        }
+    }
     if (rc == MLD_OK) {
         hipError_t e = hipSuccess;
         if (timed) e = hipEventRecord(ctx->fr_ev[3], ctx->stream);
-        const size_t out_bytes = (estimate ? off_plane + sizeof(PlaneDev) : off_type + (size_t)F * sizeof(int32_t)) - off_depth;
-        if (e == hipSuccess && out_bytes && !ctx->fr_zero_copy)
-            e = hipMemcpyAsync(ctx->fr_host + off_depth, d_depth, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+        const size_t back_bytes = (estimate ? off_plane + sizeof(PlaneDev) : off_depth + out_bytes) - off_depth;
+        if (e == hipSuccess && back_bytes && !ctx->fr_zero_copy)
+            e = hipMemcpyAsync(ctx->fr_host + off_depth, d_depth, back_bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess && timed) e = hipEventRecord(ctx->fr_ev[4], ctx->stream);
         const double t_enq = now_us();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1959,6 +2031,28 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
     s.d.type = nullptr;
     s.d.F = 0;
     if (rc) return rc;
+    // tracklets: float32 depths back to the tracks (d_last / type_last are defined for the new tracks only)
+    auto deliver_tracks = [&](bool cur_valid) {
+        if (!trk || nt == 0) {
+            if (trk && trk->n_new_out) *trk->n_new_out = 0;
+            return;
+        }
+        const float* o_cur = reinterpret_cast<const float*>(ctx->fr_host + off_depth);
+        const float* o_last = o_cur + nt;
+        const int32_t* o_tc = reinterpret_cast<const int32_t*>(o_last + nt);
+        const int32_t* o_tl = o_tc + nt;
+        int64_t nn = 0;
+        for (int64_t i = 0; i < nt; i++) {
+            trk->d_cur_out[i] = cur_valid ? o_cur[i] : -1.0f;
+            if (trk->type_cur_out) trk->type_cur_out[i] = cur_valid ? o_tc[i] : (int32_t)MLD_Unspecified;
+            if (trk->is_new[i]) {
+                trk->d_last_out[i] = o_last[i];
+                if (trk->type_last_out) trk->type_last_out[i] = o_tl[i];
+                nn++;
+            }
+        }
+        if (trk->n_new_out) *trk->n_new_out = nn;
+    };
     if (estimate) {
         PlaneDev h;
         std::memcpy(&h, ctx->fr_host + off_plane, sizeof(PlaneDev));
@@ -1971,6 +2065,9 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
         if (h.status != 0) {  // GroundPlane::ExceptionPclInvalid: the reference never gets to the feature loop
             clear_plane(s);
             s.plane_decided = false;
+            // (tracklets: the previous frame's features are still answered, the current ones are invalid -
+            // tracklet_depth_module.cpp:320-347)
+            deliver_tracks(false);
             return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");
         }
         // host-side copy of what the kernels read from the slot's PlaneDev (for the getters)
@@ -1984,7 +2081,48 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
         std::memcpy(depth_out_host, ctx->fr_host + off_depth, (size_t)F * sizeof(double));
         if (type_out_host) std::memcpy(type_out_host, ctx->fr_host + off_type, (size_t)F * sizeof(int32_t));
     }
+    if (too_small) {  // (tracklets only: see above)
+        if (plane_out) *plane_out = mld_plane_result{{0.f, 0.f, 0.f, 0.f}, 0, 1, 0};
+        s.plane_decided = false;
+        deliver_tracks(false);
+        return fail(ctx, MLD_ERR_CLOUD_TOO_SMALL, "In GroundPlane: Input pointcloud is invalid");
+    }
+    deliver_tracks(true);
     return MLD_OK;
+}
+
+int mld_tracklets_frame(mld_ctx* ctx, int slot_cur, int slot_last, const void* pts_host, int64_t n, int stride_bytes,
+                        const mld_plane_request* plane, const float coeffs[4], const int32_t* inlier_idx_host,
+                        int64_t n_inliers, const float* u_new, const float* v_new, const float* u_old, const float* v_old,
+                        const uint8_t* is_new, int64_t n_tracks, float* d_cur_out, float* d_last_out, int32_t* type_cur_out,
+                        int32_t* type_last_out, int64_t* n_new_host, mld_plane_result* plane_out) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    FramePlane fp;
+    if (plane) {
+        if (plane->kind != MLD_PLANE_RANSAC && plane->kind != MLD_PLANE_SEMANTIC)
+            return fail(ctx, MLD_ERR_INVALID_ARG, "mld_plane_request: kind must be MLD_PLANE_RANSAC or MLD_PLANE_SEMANTIC");
+        fp.kind = plane->kind == MLD_PLANE_RANSAC ? FramePlane::RANSAC : FramePlane::SEMANTIC;
+        fp.req = plane;
+    } else if (coeffs) {
+        fp.kind = FramePlane::SUPPLIED;
+        fp.coeffs = coeffs;
+        fp.inliers = inlier_idx_host;
+        fp.n_inliers = n_inliers;
+    }
+    FrameTracks tk;
+    tk.slot_last = slot_last;
+    tk.u_new = u_new;
+    tk.v_new = v_new;
+    tk.u_old = u_old;
+    tk.v_old = v_old;
+    tk.is_new = is_new;
+    tk.n = n_tracks;
+    tk.d_cur_out = d_cur_out;
+    tk.d_last_out = d_last_out;
+    tk.type_cur_out = type_cur_out;
+    tk.type_last_out = type_last_out;
+    tk.n_new_out = n_new_host;
+    return frame_call(ctx, slot_cur, pts_host, n, stride_bytes, fp, nullptr, 0, nullptr, nullptr, plane_out, &tk);
 }
 
 int mld_calculate_depth_frame(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, int stride_bytes,

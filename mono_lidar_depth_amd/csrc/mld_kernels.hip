@@ -2668,8 +2668,10 @@ __global__ __launch_bounds__(kTrkBlock) void k_tracklet_gather(const float* __re
 __global__ void k_tracklet_scatter(const double* __restrict__ depth_cur, const int32_t* __restrict__ type_cur,
                                    const double* __restrict__ depth_last, const int32_t* __restrict__ type_last,
                                    const int32_t* __restrict__ rank, long long n, int have_last, float* d_cur_out,
-                                   float* d_last_out, int32_t* type_cur_out, int32_t* type_last_out) {
+                                   float* d_last_out, int32_t* type_cur_out, int32_t* type_last_out,
+                                   const long long* n_new_dev = nullptr, long long* n_new_out = nullptr) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && n_new_out) *n_new_out = *n_new_dev;  // (one-frame call: the count travels with the depths)
     if (i >= n) return;
     d_cur_out[i] = (float)depth_cur[i];
     if (type_cur_out) type_cur_out[i] = type_cur[i];

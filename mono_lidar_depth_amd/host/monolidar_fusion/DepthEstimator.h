@@ -340,6 +340,72 @@ public:
         }
     }
 
+    // TrackletDepthModule::process's GPU side as ONE C call (mld_tracklets_frame): setInputCloud(cloud, groundPlane) on
+    // slot_cur - the plane estimated inside the call when it is not segmented yet, as the reference does every frame
+    // (tracklet_depth_module.cpp:269-284) -, the feature marshalling, both CalculateDepth calls (previous frame from its
+    // resident slot_last, -1: none) and the float32 scatter.  Throws GroundPlane::ExceptionPclInvalid when the estimation
+    // fails; d_last is answered even then (the reference's two try blocks, :318-347), d_cur is -1.
+    void trackletsFrame(const Cloud::ConstPtr& cloud, GroundPlane::Ptr& groundPlane, int slot_cur, int slot_last,
+                        const float* u_new, const float* v_new, const float* u_old, const float* v_old, const uint8_t* is_new,
+                        int64_t n_tracks, float* d_cur, float* d_last) {
+        if (!_isInitialized) throw "call of 'setInputCloud' without 'initialize'";
+        flushLazyPlane(slot_cur);
+        const bool road = _parameters->do_use_ransac_plane;
+        if (road && groundPlane == nullptr) groundPlane = std::make_shared<RansacPlane>(_parameters);
+        mld_plane_request rq{};
+        const mld_plane_request* prq = nullptr;
+        const float* coeffs = nullptr;
+        const int32_t* inl = nullptr;
+        int64_t n_inl = 0;
+        RansacPlane* rp = road ? dynamic_cast<RansacPlane*>(groundPlane.get()) : nullptr;
+        static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
+        if (road && !groundPlane->isSegmented()) {
+            if (!rp) {  // a foreign GroundPlane subclass estimates itself on the CPU
+                groundPlane->CalculateInliersPlane(cloud, _parameters->ransac_plane_min_z, _parameters->ransac_plane_max_z);
+            } else {
+                rq.kind = MLD_PLANE_RANSAC;
+                rq.seed = rp->seed;
+                if (auto* sp = dynamic_cast<SemanticPlane*>(rp)) {
+                    rq.kind = MLD_PLANE_SEMANTIC;
+                    rq.label_image = sp->image().data();
+                    rq.rows = sp->rows();
+                    rq.cols = sp->cols();
+                    rq.row_stride_bytes = sp->cols();
+                    rq.ground_labels = reinterpret_cast<const int32_t*>(sp->labels().data());
+                    rq.n_labels = (int)sp->labels().size();
+                    rq.inlier_threshold = sp->inlierThreshold();
+                }
+                prq = &rq;
+            }
+        }
+        if (road && !prq) {
+            coeffs = groundPlane->getModelCoeffs().data();
+            inl = reinterpret_cast<const int32_t*>(groundPlane->getInlinersIndex().data());
+            n_inl = (int64_t)groundPlane->getInlinersIndex().size();
+        }
+        mld_plane_result pr{};
+        const int rc = mld_tracklets_frame(_ctx, slot_cur, slot_last, cloud->points.data(), (int64_t)cloud->points.size(),
+                                           (int)sizeof(PointXYZI), prq, coeffs, inl, n_inl, u_new, v_new, u_old, v_old, is_new,
+                                           n_tracks, d_cur, d_last, nullptr, nullptr, nullptr, &pr);
+        noteCloud(cloud);
+        check(rc);
+        if (prq) {
+            mld_ctx* ctx = _ctx;
+            std::shared_ptr<bool> alive = _alive;
+            const int64_t n_in = pr.n_inliers;
+            rp->assignLazy({pr.coeffs[0], pr.coeffs[1], pr.coeffs[2], pr.coeffs[3]}, n_in, [ctx, slot_cur, alive, n_in](std::vector<int>& out) {
+                if (!*alive) throw std::runtime_error("GroundPlane: the DepthEstimator that holds this plane's inliers is gone");
+                out.resize((size_t)n_in);
+                int64_t k = 0;
+                if (mld_get_ground_plane_inliers(ctx, slot_cur, reinterpret_cast<int32_t*>(out.data()), n_in, &k) != MLD_OK)
+                    throw std::runtime_error(std::string("GroundPlane: ") + mld_last_error(ctx));
+                out.resize((size_t)k);
+            });
+            if ((size_t)slot_cur < _lazyPlane.size()) _lazyPlane[(size_t)slot_cur] = groundPlane;
+        }
+        _installedPlane = road ? groundPlane.get() : nullptr;
+    }
+
     std::shared_ptr<DepthEstimatorParameters> getParameters() { return _parameters; }
     std::shared_ptr<CameraPinhole> getCamera() { return _camera; }
     std::array<double, 12> getTransformLidarToCam() { return _transform; }

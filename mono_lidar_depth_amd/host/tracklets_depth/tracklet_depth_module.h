@@ -5,7 +5,8 @@
 // are replaced by the plain structs below (same fields).  What changes underneath: the previous frame is not
 // re-projected for the features of new tracklets (CalculateFeatureDepthsLastFrame re-runs setInputCloud on the old
 // cloud in the reference, :115) — its slot (cloud, pixel map, ground plane) stays resident on the GPU and the two
-// slots ping-pong; both depth calls and the float32 scatter run as one mld_tracklets_depth call.
+// slots ping-pong; upload, ground plane, projection, both depth calls and the float32 scatter of a frame run as ONE
+// mld_tracklets_frame call.
 // Header-only; link with -lmld_hip.
 #pragma once
 
@@ -107,26 +108,15 @@ public:
         const int slot_cur = _slotCur, slot_last = _haveLast ? 1 - _slotCur : -1;
         bool cur_ok = true;
         try {
-            _depthEstimator.setInputCloud(cloud_in, gp, slot_cur);  // the only projection of this frame
+            // the frame's whole GPU side is ONE C call: upload + ground plane (estimated inside the call when it is not
+            // segmented yet) + the only projection of this frame + both depth calls + scatter
+            _depthEstimator.trackletsFrame(cloud_in, gp, slot_cur, slot_last, u_new.data(), v_new.data(), u_old.data(),
+                                           v_old.data(), is_new.data(), n, d_cur.data(), d_last.data());
         } catch (const Mono_Lidar::GroundPlane::ExceptionPclInvalid&) {
-            // :337-347  current frame continues with invalid depths, plane and cloud are forgotten
+            // :337-347  current frame continues with invalid depths (the call has left -1 there and answered the previous
+            // frame's features), plane and cloud are forgotten
             cur_ok = false;
             gp = nullptr;
-        }
-        if (n > 0) {
-            if (cur_ok) {
-                check(mld_tracklets_depth(_depthEstimator.ctx(), slot_cur, slot_last, u_new.data(), v_new.data(),
-                                          u_old.data(), v_old.data(), is_new.data(), n, d_cur.data(), d_last.data(), nullptr,
-                                          nullptr, nullptr));
-            } else if (slot_last >= 0) {
-                // the previous frame's features are still answered (:320-332); the current slot gets "no plane" so that
-                // the call is well formed, and its depths are discarded
-                check(mld_set_ground_plane(_depthEstimator.ctx(), slot_cur, nullptr, nullptr, 0));
-                check(mld_tracklets_depth(_depthEstimator.ctx(), slot_cur, slot_last, u_new.data(), v_new.data(),
-                                          u_old.data(), v_old.data(), is_new.data(), n, d_cur.data(), d_last.data(), nullptr,
-                                          nullptr, nullptr));
-                std::fill(d_cur.begin(), d_cur.end(), -1.f);
-            }
         }
         groundPlaneLast_ = gp;
         // SaveFeatureDepths consumes the last-frame depths compacted over the new tracklets (index j, :143-147)

@@ -18,7 +18,8 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 
 from . import capi
-from .depth_estimator import CameraPinhole, DepthEstimator, GroundPlane, SemanticPlane, _is_torch_cuda
+from .depth_estimator import (NO_PLANE, CameraPinhole, DepthEstimator, ExceptionPclInvalid, GroundPlane, RansacPlane,
+                              SemanticPlane, _is_torch_cuda)
 
 
 class TrackletDepthModule:
@@ -30,6 +31,7 @@ class TrackletDepthModule:
         self._slot_cur = 0
         self._have_last = False  # _cloud_last_frame != nullptr
         self._keep_history = keep_history
+        self.one_call = True  # process() = one C call (mld_tracklets_frame); False: setInputCloud + mld_tracklets_depth
         # _trackletMap: id -> list of (u, v, depth), newest first (feature_tracking::Tracklet::push_front)
         self._tracklet_map: Dict[int, List[Tuple[int, int, float]]] = {}
 
@@ -61,16 +63,20 @@ class TrackletDepthModule:
         t_abi = time.perf_counter()
         if img is not None:
             ground_plane = SemanticPlane(img, (6, 7, 8, 9), est.getParameters().ransac_plane_refinement_treshold)
-        est.setInputCloud(cloud, ground_plane, slot=slot_cur)  # the only projection of this frame
         arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in (u_new, v_new, u_old, v_old)]
         d_cur = np.empty(n, dtype=np.float32)
         d_last = np.full(n, np.nan, dtype=np.float32)
         t_cur = np.empty(n, dtype=np.int32)
         t_last = np.zeros(n, dtype=np.int32)
         n_new = C.c_int64(0)
-        est._check(lib.mld_tracklets_depth(est._ctx, slot_cur, slot_last, *[a.ctypes.data for a in arrs],
-                                           is_new.ctypes.data, n, d_cur.ctypes.data, d_last.ctypes.data,
-                                           t_cur.ctypes.data, t_last.ctypes.data, C.byref(n_new)))
+        if self.one_call and not _is_torch_cuda(cloud) and self._frame_call(cloud, ground_plane, slot_cur, slot_last, arrs,
+                                                                            is_new, n, d_cur, d_last, t_cur, t_last, n_new):
+            pass  # the whole GPU side of process() was ONE C call (mld_tracklets_frame)
+        else:
+            est.setInputCloud(cloud, ground_plane, slot=slot_cur)  # the only projection of this frame
+            est._check(lib.mld_tracklets_depth(est._ctx, slot_cur, slot_last, *[a.ctypes.data for a in arrs],
+                                               is_new.ctypes.data, n, d_cur.ctypes.data, d_last.ctypes.data,
+                                               t_cur.ctypes.data, t_last.ctypes.data, C.byref(n_new)))
         self.last_types = (t_cur, t_last)
         self.last_abi_seconds = time.perf_counter() - t_abi  # C-ABI calls only (copies, kernels, synchronise)
         # SaveFeatureDepths (:119-169) + TidyUpTracklets (:171-193)
@@ -91,6 +97,61 @@ class TrackletDepthModule:
         self._have_last = True
         self._slot_cur = 1 - slot_cur
         return d_cur, d_last, is_new.astype(bool)
+
+    def _frame_call(self, cloud, gp, slot_cur, slot_last, arrs, is_new, n, d_cur, d_last, t_cur, t_last, n_new) -> bool:
+        """The GPU side of process() as one C call: upload, ground plane (estimated inside the call when it is not
+        segmented yet - what the reference does every frame, tracklet_depth_module.cpp:269-284), projection, feature
+        marshalling, both CalculateDepth calls, scatter.  False: not applicable (device inputs)."""
+        est, lib = self._est, self._est._lib
+        road = bool(est.getParameters().do_use_ransac_plane)
+        if road and gp is None:
+            gp = RansacPlane()
+        ptr, npts, stride, keep = est._cloud_view(cloud)
+        req = None
+        coeffs = inl = None
+        n_inl = 0
+        hold = None
+        if road and gp is not NO_PLANE:
+            if isinstance(gp, RansacPlane) and not gp.isSegmented():
+                req = capi.MldPlaneRequest()
+                req.kind, req.seed = capi.MLD_PLANE_RANSAC, gp.seed & 0xFFFFFFFF
+                if isinstance(gp, SemanticPlane):
+                    if _is_torch_cuda(gp.img):
+                        return False
+                    im = np.ascontiguousarray(gp.img, dtype=np.uint8)
+                    lab = np.ascontiguousarray(gp.groundplane_label, dtype=np.int32)
+                    hold = (im, lab)
+                    req.kind = capi.MLD_PLANE_SEMANTIC
+                    req.label_image, req.rows, req.cols, req.row_stride_bytes = im.ctypes.data, im.shape[0], im.shape[1], im.strides[0]
+                    req.ground_labels, req.n_labels, req.inlier_threshold = lab.ctypes.data, lab.size, gp.inlier_threshold
+            else:
+                if not isinstance(gp, GroundPlane) or _is_torch_cuda(gp.inliers):
+                    return False
+                ii = gp.getInlinersIndex()
+                if ii is None:
+                    return False
+                inl = np.ascontiguousarray(ii, dtype=np.int32)
+                coeffs = (C.c_float * 4)(*[float(x) for x in gp.coeffs])
+                n_inl = int(inl.size)
+        res = capi.MldPlaneResult()
+        rc = lib.mld_tracklets_frame(est._ctx, slot_cur, slot_last, ptr, npts, stride, C.byref(req) if req is not None else None,
+                                     coeffs, inl.ctypes.data if inl is not None else None, n_inl,
+                                     *[a.ctypes.data for a in arrs], is_new.ctypes.data, n, d_cur.ctypes.data,
+                                     d_last.ctypes.data, t_cur.ctypes.data, t_last.ctypes.data, C.byref(n_new), C.byref(res))
+        del hold, keep
+        if rc == capi.MLD_ERR_CLOUD_TOO_SMALL:
+            # the reference's process() catches ExceptionPclInvalid per frame (:318-347): the previous frame's features
+            # are answered, the current frame continues with invalid depths, cloud and plane are forgotten
+            raise ExceptionPclInvalid(rc, "In GroundPlane: Input pointcloud is invalid")
+        est._check(rc)
+        if req is not None:
+            gp.coeffs = np.array(list(res.coeffs), dtype=np.float32)
+            gp.inliers = None
+            gp.n_inliers = int(res.n_inliers)
+            gp.iterations = int(res.iterations)
+            gp._segmented = True
+            gp._owner = (est, slot_cur)
+        return True
 
     def tracklet(self, track_id: int):
         return list(self._tracklet_map[track_id])
