@@ -253,6 +253,39 @@ def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
                           "final synchronise, total = the C call, wrapper = the Python mirror around it",
     }
     res["pinned_source"] = pinned
+    # TrackletDepthModule::process (tracklet_depth_module.cpp:261-396), the ROS callback itself: a new cloud, a fresh
+    # SemanticPlane from the frame's label image and 2000 tracks (10 % new: their previous features are answered on the
+    # resident previous frame) per call.  C-ABI time only (the Python mirror's tracklet bookkeeping is not the product):
+    # ONE call (mld_tracklets_frame) against the route it replaces (setInputCloud + mld_tracklets_depth: two calls, two
+    # synchronisations, nine small copies).
+    if P.do_use_ransac_plane:
+        from mono_lidar_depth_amd import TrackletDepthModule
+        rng = np.random.default_rng(11)
+        n_tr = uvs[0].shape[0]
+        proc = {}
+        for name, one in (("one_call", True), ("two_calls", False)):
+            mod = TrackletDepthModule(P, cam, T, device=device, keep_history=False)
+            mod.one_call = one
+            ids = np.arange(n_tr, dtype=np.int64)
+            nxt = n_tr
+            ts = []
+            for it in range(min(n_frames, 120) + 10):
+                i = it % len(imgs)
+                fresh = rng.choice(n_tr, n_tr // 10, replace=False)  # a tenth of the tracks are replaced by new ones
+                ids = ids.copy()
+                ids[fresh] = np.arange(nxt, nxt + fresh.size)
+                nxt += fresh.size
+                u0 = uvs[i][:, 0].astype(np.float32)
+                v0 = uvs[i][:, 1].astype(np.float32)
+                mod.process(clouds[i], ids, u0, v0, u0 + 1.0, v0 + 1.0, None, img=imgs[i])
+                ts.append(mod.last_abi_seconds)
+            ts = np.array(ts[10:]) * 1e3
+            proc[name] = {"ms_per_frame_median": float(np.median(ts)), "ms_per_frame_p99": float(np.percentile(ts, 99)),
+                          "frames": int(ts.size)}
+            mod.estimator.close()
+        proc["path"] = ("TrackletDepthModule::process per frame: host cloud + fresh SemanticPlane (label image) + "
+                        f"{n_tr} tracks, 10 % new; C-ABI calls only")
+        res["process"] = proc
     if P.do_use_ransac_plane:
         res["estimated"] = {
             "path": "the same call with a GroundPlane that is not segmented yet (the reference's production call): plane "

@@ -1870,6 +1870,10 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
     const uint8_t* const img_src = kind == FramePlane::SEMANTIC ? rq->label_image : nullptr;
     const bool clear_mask = kind == FramePlane::SUPPLIED || kind == FramePlane::RANSAC;
     const FrameTracks tk = trk ? *trk : FrameTracks{};
+    double* const trk_uv_cur = ctx->trk_uv_cur;
+    double* const trk_uv_last = ctx->trk_uv_last;
+    int32_t* const trk_rank = ctx->trk_rank;
+    long long* const trk_n_new = ctx->trk_n_new;
     auto side_work = [=](std::string& err) -> int {
         auto bad = [&](hipError_t e, const char* what) {
             err = std::string(what) + ": " + hipGetErrorString(e);
@@ -1888,6 +1892,13 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
         }
         if (off_depth && (e = hipMemcpyAsync(fr_dev, fr_host, off_depth, hipMemcpyHostToDevice, side)) != hipSuccess)
             return bad(e, "hipMemcpyAsync(features)");
+        if (nt) {  // ExractNewTrackletFrames + the features' truncation to integer pixels, off the critical path
+            const float* in = reinterpret_cast<const float*>(fr_dev + off_uv);
+            hipLaunchKernelGGL(k_tracklet_gather, dim3(1), dim3(kTrkBlock), 0, side, in, in + nt, in + 2 * nt, in + 3 * nt,
+                               reinterpret_cast<const uint8_t*>(in + 4 * nt), (long long)nt, trk_uv_cur, trk_uv_last, trk_rank,
+                               trk_n_new);
+            if ((e = hipGetLastError()) != hipSuccess) return bad(e, "k_tracklet_gather");
+        }
         if (img_src && (e = hipMemcpyAsync(sem_img, img_src, img_bytes, hipMemcpyHostToDevice, side)) != hipSuccess)
             return bad(e, "hipMemcpyAsync(label image)");
         if (clear_mask) {
@@ -1968,17 +1979,13 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
     if (trk && nt > 0) {
         // TrackletDepthModule::process (tracklet_depth_module.cpp:23-169) on the frame just projected: marshal the
         // features, both CalculateDepth calls (the previous frame from its resident slot), float32 scatter
-        const float* in = reinterpret_cast<const float*>(ctx->fr_dev + off_uv);
         float* o_cur = reinterpret_cast<float*>(out_base + off_depth);
         float* o_last = o_cur + nt;
         int32_t* o_tc = reinterpret_cast<int32_t*>(o_last + nt);
         int32_t* o_tl = o_tc + nt;
         long long* o_nn = reinterpret_cast<long long*>(o_tl + nt);
         const int slot_last = trk->slot_last;
-        hipLaunchKernelGGL(k_tracklet_gather, dim3(1), dim3(kTrkBlock), 0, ctx->stream, in, in + nt, in + 2 * nt, in + 3 * nt,
-                           reinterpret_cast<const uint8_t*>(in + 4 * nt), (long long)nt, ctx->trk_uv_cur, ctx->trk_uv_last,
-                           ctx->trk_rank, ctx->trk_n_new);
-        HIP_TRY(ctx, hipGetLastError());
+        // (the feature marshalling - k_tracklet_gather - ran on the side stream, beside the cloud copy)
         rc = calc_one(ctx, slot, ctx->trk_uv_cur, nt, ctx->trk_depth_cur, ctx->trk_type_cur, nullptr, false);
         if (rc == MLD_OK && slot_last >= 0) {
             Slot& sl = ctx->slots[slot_last];
