@@ -285,6 +285,7 @@ def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
             mod.estimator.close()
         proc["path"] = ("TrackletDepthModule::process per frame: host cloud + fresh SemanticPlane (label image) + "
                         f"{n_tr} tracks, 10 % new; C-ABI calls only")
+        proc["tracks"] = n_tr
         res["process"] = proc
     if P.do_use_ransac_plane:
         res["estimated"] = {

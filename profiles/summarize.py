@@ -122,6 +122,13 @@ if stats_l:
                            if k in ("h2d_us", "plane_us", "kernels_us", "d2h_us", "gpu_us"))
             lines.append(f"| {name} | {leg['ms_per_frame_median'] * 1e3:.1f} | {leg['ms_per_frame_p99'] * 1e3:.1f} | {hp} | {gp} |")
         lines.append("")
+        pr = bl.get("process")
+        if pr:
+            lines += ["`latency.process` - `TrackletDepthModule.process` per frame (host cloud, fresh un-segmented SemanticPlane, "
+                      f"{pr.get('tracks', 2000)} tracks), time inside the C-ABI per frame: one call (`mld_tracklets_frame`) median "
+                      f"{pr['one_call']['ms_per_frame_median'] * 1e3:.1f} us / p99 {pr['one_call']['ms_per_frame_p99'] * 1e3:.1f} us; "
+                      f"three calls (set cloud, estimate plane, tracklet depths) median {pr['two_calls']['ms_per_frame_median'] * 1e3:.1f} us / "
+                      f"p99 {pr['two_calls']['ms_per_frame_p99'] * 1e3:.1f} us.", ""]
     except Exception as e:  # noqa: BLE001
         lines += [f"(un-traced latency legs not parsed: {e})", ""]
 lines += ["## PMC (per launch, mean over launches)", "",
