@@ -60,6 +60,9 @@ def parse_args():
     ap.add_argument("--shared-mode", type=int, default=1,
                     help="mld_set_shared_gpu argument of the alternating contexts: 1 = on; + 256 * n = n feature-kernel "
                          "wavefronts per CU instead of 8")
+    ap.add_argument("--handover", choices=("classify", "projection"), default="classify",
+                    help="two contexts: the next context's projection is released behind this context's classification "
+                         "kernel (mld_order_after_classify; default) or at the end of its projection (mld_order_after)")
     ap.add_argument("--pair", action="store_true",
                     help="two contexts: run both contexts' projections on one shared stream (mld_pair_contexts) instead of "
                          "handing the projection over with mld_order_after (one event across streams).  Measured: the "
@@ -398,6 +401,7 @@ class Resident:
         dev = torch.device("cuda", device)
         self.P, self.cam, self.T, self.B, self.F = P, cam, T, B, F
         self.shared_mode = shared_mode
+        self.handover = "classify"
         self.clouds_h = [synth.make_cloud(scanner, seed=seq, frame=f) for f in range(U)]
         self.planes_h = [synth.make_ground_plane(c) for c in self.clouds_h]
         if near_points:  # features around the image positions of the frame's own returns (config 3, second variant)
@@ -471,11 +475,11 @@ class Resident:
         nb = len(self.batches)
         if self.whole:
             e, b = self.batches[self.k % nb]
-            e.runBatchBeside(b, self.batches[(self.k + 1) % nb][0])
+            e.runBatchBeside(b, self.batches[(self.k + 1) % nb][0], self.handover)
             self.k += 1
             return
         for i, (e, b) in enumerate(self.batches):
-            e.runBatchBeside(b, self.batches[(i + 1) % nb][0])
+            e.runBatchBeside(b, self.batches[(i + 1) % nb][0], self.handover)
 
     def last_context(self):
         """The context whose slots hold the most recent launch set."""
@@ -1026,6 +1030,7 @@ def main():
     seq = sharding.assign_sequences(world, world)[rank][0]  # one sequence per rank (config 4 layout)
     res = Resident(P, cam, T, synth.HDL64, B, U, F, seq, gpu_index, slots=args.slots, contexts=args.contexts,
                    shared_mode=args.shared_mode, pair=args.pair)
+    res.handover = args.handover
     S, N = res.S, res.N
 
     def barrier():
@@ -1301,8 +1306,11 @@ def main():
             "contexts": args.contexts,
             "schedule": (("consecutive steps alternate between the contexts" if args.slots <= 0 else
                           "the launch sets of a step alternate between the contexts") +
-                         ": the projection of one runs beside the feature kernels of the other"
+                         ": the projection of one runs beside the feature kernels of the other" +
+                         (" (released behind the classification kernel: mld_order_after_classify)"
+                          if args.handover == "classify" and not args.pair else "")
                          if args.contexts > 1 else "one stream, one kernel at a time"),
+            "handover": args.handover if args.contexts > 1 and not args.pair else None,
             "features_per_frame": F,
             "points_per_frame": N,
             "sequences": world,

@@ -171,6 +171,7 @@ int mld_synchronize(mld_ctx* ctx);
  * parallel part (DepthEstimator.cpp:156-217 vs :455).  Schedule per batch, contexts taken round-robin:
  *     mld_set_clouds_*_device(ctx_k, ...);      projection of batch i on context k
  *     mld_order_after(ctx_next, ctx_k);          the NEXT context's projection starts when this one is done ...
+ *       (or mld_order_after_classify: ... when this context's classification kernel is done)
  *     mld_calculate_depths_device(ctx_k, ...);   ... i.e. beside these feature kernels
  *
  * mld_order_after: everything submitted to `ctx` from now on starts after everything submitted to `other` so far has
@@ -182,6 +183,15 @@ int mld_synchronize(mld_ctx* ctx);
  *   lane-per-feature kernel per CU in that mode (0 = the default, 8): fewer leave more of every CU to the projection.
  */
 int mld_order_after(mld_ctx* ctx, mld_ctx* other);
+/*
+ * mld_order_after_classify: the same hand-over, but `ctx` is released behind the classification kernel of `other`'s NEXT
+ *   mld_calculate_depth(s)_device call instead of at once: the classification (one 1024-thread block and 63 KB of LDS per
+ *   frame, 40 us per 1024 frames) then has the GPU to itself instead of competing with 131 072 projection blocks for wave
+ *   slots, and the projection of `ctx` still runs beside the long feature kernels (measured: k_classify 70-90 -> 44 us,
+ *   the step 0.5-1.5 % shorter and steadier; LAB.md 4.17).  Nothing waits if `other` never issues that call; a pending
+ *   hand-over ends with either context.  Purely a scheduling hint: the contexts share no data.
+ */
+int mld_order_after_classify(mld_ctx* ctx, mld_ctx* other);
 /*
  * mld_pair_contexts(a, b): the batched setInputCloud entry points (mld_set_clouds_*_device) of BOTH contexts run their
  *   projection on one stream created here (owned by `a`), back to back in call order, while each context's feature

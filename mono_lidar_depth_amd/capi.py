@@ -142,6 +142,7 @@ _SIGNATURES = [
     ("mld_get_stream", C.c_void_p, [C.c_void_p]),
     ("mld_synchronize", C.c_int, [C.c_void_p]),
     ("mld_order_after", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("mld_order_after_classify", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mld_pair_contexts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mld_set_shared_gpu", C.c_int, [C.c_void_p, C.c_int]),
     ("mld_set_list_capacity", C.c_int, [C.c_void_p, C.c_int, C.c_int]),

@@ -211,6 +211,8 @@ struct mld_ctx {
     hipEvent_t side_done = nullptr, side_start = nullptr;
     FrameHelper* helper = nullptr;  // stages and queues the side-stream work of a one-frame call beside the cloud copy
     hipEvent_t order_ev = nullptr;  // mld_order_after
+    mld_ctx* release_waiter = nullptr;  // mld_order_after_classify: released behind this context's next k_classify
+    mld_ctx* waiting_on = nullptr;      //   (back pointer: either context may be destroyed first)
     // mld_pair_contexts: the batched projections of two contexts share ONE stream (back to back, no cross-stream
     // hand-over between them); each context's feature kernels stay on its own stream, joined by two events per batch
     hipStream_t proj_stream = nullptr;  // nullptr: projections run on `stream`
@@ -674,6 +676,15 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         hipLaunchKernelGGL(kc, dim3((unsigned)ns), dim3(kClsThreads), ctx->lds_classify, ctx->stream, ctx->d_slots, one,
                            use_single, calib, ctx->bm_ncol, ctx->bm_ncolp);
     }
+    // mld_order_after_classify: the waiting context is released here - behind the classification (which wants every
+    // CU's wave slots and LDS for 40 us), ahead of the long feature kernels
+    if (ctx->release_waiter) {
+        mld_ctx* w = ctx->release_waiter;
+        ctx->release_waiter = nullptr;
+        w->waiting_on = nullptr;
+        HIP_TRY(ctx, hipEventRecord(w->order_ev, ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(w->stream, w->order_ev, 0));
+    }
     if (calib.threadPath) {
         ScopedTimer tm(ctx, 1);
         auto kf = calib.roadMode ? mld::k_feature_fused<1> : mld::k_feature_fused<0>;
@@ -987,6 +998,9 @@ void mld_destroy(mld_ctx* ctx) {
         ctx->helper->stop();
         delete ctx->helper;
     }
+    // a pending mld_order_after_classify hand-over dies with either of its contexts
+    if (ctx->waiting_on && ctx->waiting_on->release_waiter == ctx) ctx->waiting_on->release_waiter = nullptr;
+    if (ctx->release_waiter) ctx->release_waiter->waiting_on = nullptr;
     for (hipEvent_t e : ctx->fr_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->side_start) (void)hipEventDestroy(ctx->side_start);
@@ -1083,6 +1097,20 @@ int mld_order_after(mld_ctx* ctx, mld_ctx* other) {
     if (!ctx->order_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
     HIP_TRY(ctx, hipEventRecord(ctx->order_ev, other->stream));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->order_ev, 0));
+    return MLD_OK;
+}
+
+int mld_order_after_classify(mld_ctx* ctx, mld_ctx* other) {
+    if (!ctx || !other) return MLD_ERR_INVALID_ARG;
+    if (ctx == other) return MLD_OK;
+    if (ctx->device != other->device) return fail(ctx, MLD_ERR_INVALID_ARG, "contexts live on different devices");
+    int rc = bind_device(ctx);
+    if (rc) return rc;
+    if (!ctx->order_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->order_ev, hipEventDisableTiming));
+    if (ctx->waiting_on && ctx->waiting_on->release_waiter == ctx) ctx->waiting_on->release_waiter = nullptr;
+    if (other->release_waiter) other->release_waiter->waiting_on = nullptr;
+    other->release_waiter = ctx;  // (the event is recorded, and waited for, when `other` queues its next feature kernels)
+    ctx->waiting_on = other;
     return MLD_OK;
 }
 

@@ -245,6 +245,12 @@ class DepthEstimator:
         finished (device-side; mld_order_after)."""
         self._check(self._lib.mld_order_after(self._ctx, other._ctx))
 
+    def orderAfterClassify(self, other: "DepthEstimator"):
+        """The same hand-over, released behind the classification kernel of `other`'s next batched CalculateDepth call
+        (mld_order_after_classify): that kernel then has the GPU to itself, this context's projection still runs beside
+        `other`'s feature kernels."""
+        self._check(self._lib.mld_order_after_classify(self._ctx, other._ctx))
+
     def setListCapacity(self, wide: int, narrow: int):
         """Neighbour-list capacities of the lane-per-feature kernel (mld_set_list_capacity): 32 / 24 by default, 48 / 24
         for dense (128-beam) clouds."""
@@ -370,22 +376,26 @@ class DepthEstimator:
         self._check(lib.mld_set_clouds_planes_device(ctx, n, b["cloud_ptrs"], b["cloud_n"], b["stride"],
                                                      b["coeffs"].ctypes.data_as(C.POINTER(C.c_float)), b["mask_ptrs"]))
 
-    def featuresBatchBeside(self, b, nxt: "DepthEstimator"):
+    def featuresBatchBeside(self, b, nxt: "DepthEstimator", handover: str = "classify"):
         """CalculateDepth of a prepared batch whose projection is already queued; the NEXT context's projection is
-        released first (unless `nxt` is this context's pair partner: their projections are in call order on the shared
-        stream; any other context - three or more in rotation - still needs the hand-over)."""
+        released behind this batch's classification kernel (`handover="classify"`, mld_order_after_classify) or at once
+        (`"projection"`, mld_order_after) - unless `nxt` is this context's pair partner: their projections are in call
+        order on the shared stream; any other context - three or more in rotation - still needs the hand-over."""
         if nxt is not self and getattr(self, "_pair", None) is not nxt:
-            nxt.orderAfter(self)
+            if handover == "classify":
+                nxt.orderAfterClassify(self)
+            else:
+                nxt.orderAfter(self)
         self._check(self._lib.mld_calculate_depths_device(self._ctx, b["n"], b["uv_ptrs"], b["F"], b["depth_ptrs"],
                                                           b["type_ptrs"]))
 
-    def runBatchBeside(self, b, nxt: "DepthEstimator"):
+    def runBatchBeside(self, b, nxt: "DepthEstimator", handover: str = "classify"):
         """`runBatch` for two (or more) contexts used in turn: context `nxt`, which will take the next batch, is released
         as soon as THIS batch's projection has finished, so that its projection runs beside this batch's feature kernels
         (HBM-bound work beside gather-bound work: include/mld.h "Two contexts").  Call `setSharedGpu()` on both contexts
         once."""
         self.projectBatch(b)
-        self.featuresBatchBeside(b, nxt)
+        self.featuresBatchBeside(b, nxt, handover)
 
     def estimateGroundPlane(self, slot: int = 0, seed: int = 0):
         """RansacPlane::CalculateInliersPlane on the GPU for the slot's cloud; installs the plane.

@@ -337,9 +337,9 @@ def test_batch_with_empty_and_ragged_slots():
         assert_depth_parity(t_depth[b].cpu().numpy(), t_type[b].cpu().numpy(), d0, t0)
 
 
-@pytest.mark.parametrize("paired", [False, True])
-def test_two_contexts_alternating_on_one_gpu(paired):
-    """Two contexts used in turn (mld_order_after or mld_pair_contexts, + mld_set_shared_gpu; include/mld.h "Two
+@pytest.mark.parametrize("paired,handover", [(False, "classify"), (False, "projection"), (True, "classify")])
+def test_two_contexts_alternating_on_one_gpu(paired, handover):
+    """Two contexts used in turn (mld_order_after[_classify] or mld_pair_contexts, + mld_set_shared_gpu; include/mld.h "Two
     contexts"): the projection of one runs beside the feature kernels of the other.  Every launch set of four rounds
     equals the oracle, whichever context computed it, and the shared-GPU mode (more LDS per block of the lane-per-feature
     kernel) changes nothing.  Paired: both contexts' projections on one stream; the same slots are re-projected while
@@ -373,7 +373,7 @@ def test_two_contexts_alternating_on_one_gpu(paired):
         sets.append((e, batch, clouds, planes, uvs, d, t))
     torch.cuda.synchronize()
     for r, (e, batch, *_rest) in enumerate(sets):
-        e.runBatchBeside(batch, ests[(r + 1) % 2])
+        e.runBatchBeside(batch, ests[(r + 1) % 2], handover)
     for e in ests:
         e.synchronize()
     for e, batch, clouds, planes, uvs, d, t in sets:
@@ -384,6 +384,12 @@ def test_two_contexts_alternating_on_one_gpu(paired):
     lib = ests[0]._lib
     assert lib.mld_order_after(ests[0]._ctx, None) == capi.MLD_ERR_INVALID_ARG
     assert lib.mld_order_after(ests[0]._ctx, ests[0]._ctx) == capi.MLD_OK
+    assert lib.mld_order_after_classify(ests[0]._ctx, None) == capi.MLD_ERR_INVALID_ARG
+    assert lib.mld_order_after_classify(None, ests[0]._ctx) == capi.MLD_ERR_INVALID_ARG
+    assert lib.mld_order_after_classify(ests[0]._ctx, ests[0]._ctx) == capi.MLD_OK
+    # a pending hand-over (the other context never issues its feature kernels) ends with either context
+    assert lib.mld_order_after_classify(ests[0]._ctx, ests[1]._ctx) == capi.MLD_OK
+    assert lib.mld_order_after_classify(ests[1]._ctx, ests[0]._ctx) == capi.MLD_OK
     assert lib.mld_pair_contexts(ests[0]._ctx, None) == capi.MLD_ERR_INVALID_ARG
     assert lib.mld_pair_contexts(ests[0]._ctx, ests[0]._ctx) == capi.MLD_ERR_INVALID_ARG
     if paired:
