@@ -622,14 +622,25 @@ int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int sl
     if (max_n <= 0) return MLD_OK;
     const int per_block = kProjThreads * kProjPerThread;
     int per_slot = (int)((max_n + per_block - 1) / per_block);
+#ifdef MLD_AB_SWITCHES
+    //   MLD_DIAG_PROJ_FRACTION=p   diagnostic (WRONG results): batches project only the first p percent of every cloud -
+    //                              how the two-context step would answer to a faster projection
+    if (!single)
+        if (const char* e = std::getenv("MLD_DIAG_PROJ_FRACTION")) per_slot = std::max(1, per_slot * std::atoi(e) / 100);
+#endif
+    // (clouds on 16-byte boundaries - every allocator's - take the instantiation without the scalar-load alternative)
+    bool aligned = true;
+    for (int i = slot; i < slot + (single ? 1 : n_slots); i++)
+        aligned = aligned && (((uintptr_t)ctx->slots[i].d.cloud) & 15) == 0;
+    auto kp = aligned ? mld::k_project_scatter<true> : mld::k_project_scatter<false>;
     ScopedTimer tm(ctx, 0, st);
     if (single) {
-        hipLaunchKernelGGL(k_project_scatter, dim3(per_slot), dim3(kProjThreads), 0, st, ctx->d_slots,
-                           ctx->slots[slot].d, 1, ctx->calib, 1, per_slot, 0u);
+        hipLaunchKernelGGL(kp, dim3(per_slot), dim3(kProjThreads), 0, st, ctx->d_slots, ctx->slots[slot].d, 1, ctx->calib, 1,
+                           per_slot, 0u);
     } else {
         // (batch: the slots [slot, slot + n_slots))
-        hipLaunchKernelGGL(k_project_scatter, dim3((unsigned)per_slot * n_slots), dim3(kProjThreads), ctx->proj_lds, st,
-                           ctx->d_slots + slot, SlotDesc{}, 0, ctx->calib, n_slots, per_slot, common_tag(ctx, n_slots, slot));
+        hipLaunchKernelGGL(kp, dim3((unsigned)per_slot * n_slots), dim3(kProjThreads), ctx->proj_lds, st, ctx->d_slots + slot,
+                           SlotDesc{}, 0, ctx->calib, n_slots, per_slot, common_tag(ctx, n_slots, slot));
     }
     HIP_TRY(ctx, hipGetLastError());
     return MLD_OK;

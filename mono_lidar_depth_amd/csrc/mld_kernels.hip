@@ -185,6 +185,11 @@ constexpr int kProjPerThread = MLD_PROJ_PER_THREAD;
 #else
 #define MLD_PROJ_ATTR
 #endif
+// ALIGNED16: every cloud of the launch starts on a 16-byte boundary (the host checks): the kernel then holds ONE load
+// sequence, and a point's load is waited for where the point is first used.  (With both sequences in one kernel their
+// results meet in register copies behind the loads, i.e. every load of the thread is waited for before the first
+// point is touched.)
+template <bool ALIGNED16>
 __global__ __launch_bounds__(kProjThreads) MLD_PROJ_ATTR void k_project_scatter(const SlotDesc* __restrict__ slots, SlotDesc single,
                                                                   int use_single, Calib c, int n_slots, int per_slot,
                                                                   uint32_t tag_all) {
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(kProjThreads) MLD_PROJ_ATTR void k_project_scatter(
     const unsigned char* cl = s.cloud;
     float fx[kProjPerThread], fy[kProjPerThread], fz[kProjPerThread];
     // every lane loads a valid point (index clamped to the cloud); lanes beyond the end are masked out of the result
-    if ((((size_t)s.cloud) & 15) == 0) {
+    if (ALIGNED16 || (((size_t)s.cloud) & 15) == 0) {
 #pragma unroll
         for (int r = 0; r < kProjPerThread; r++) {
             const int i = min(base + r * kProjThreads, n - 1);
@@ -263,6 +268,9 @@ __global__ __launch_bounds__(kProjThreads) MLD_PROJ_ATTR void k_project_scatter(
     asm volatile("" : "+v"(t3), "+v"(t7), "+v"(t11));
 #pragma unroll
     for (int r = 0; r < kProjPerThread; r++) {
+#ifdef MLD_PROJ_SCHED_BARRIER  // measurement builds: nothing moves across the points of a thread (LAB.md 4.19)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         int w = -1 - (int)threadIdx.x;  // occupancy-bitmap word of the point (or a unique negative value)
         uint32_t bits = 0u;             // its bit
         const int i = base + r * kProjThreads;
