@@ -396,3 +396,47 @@ def test_two_contexts_alternating_on_one_gpu(paired, handover):
         assert lib.mld_pair_contexts(ests[0]._ctx, ests[1]._ctx) == capi.MLD_ERR_INVALID_ARG  # already paired
     ests[1].close()  # the borrower of the projection stream first
     ests[0].close()
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_clouds_off_16_byte_boundaries(mixed):
+    """Device clouds that start 4 bytes past a 16-byte boundary (a view into a larger buffer): the projection takes its
+    scalar-load instantiation (`k_project_scatter<false>`; the 16-byte one is chosen only when every cloud of the launch
+    is aligned).  `mixed`: aligned and unaligned clouds in one launch set.  Same results as the oracle either way."""
+    import torch
+    P = capi.params_c0()
+    B, F = 10, 600
+    dev = torch.device("cuda:0")
+    est = make_estimator(P, max_frames=B)
+    clouds = [synth.make_cloud(synth.HDL64_KITTI, seed=70 + b, frame=b) for b in range(B)]
+    planes = [synth.make_ground_plane(c) for c in clouds]
+    uvs = [synth.make_features(F, seed=80 + b) for b in range(B)]
+    t_clouds, keep = [], []
+    for b, c in enumerate(clouds):
+        off = 0 if (mixed and b % 2 == 0) else 1
+        buf = torch.zeros(c.size + 4, dtype=torch.float32, device=dev)
+        assert buf.data_ptr() % 16 == 0
+        view = buf[off:off + c.size].view(c.shape)
+        view.copy_(torch.from_numpy(c))
+        assert (view.data_ptr() % 16 == 0) == (off == 0)
+        keep.append(buf)
+        t_clouds.append(view)
+    t_uvs = [torch.from_numpy(u).to(dev) for u in uvs]
+    t_inl = [torch.from_numpy(p[1]).to(dev) for p in planes]
+    t_depth = [torch.full((F,), 7.0, dtype=torch.float64, device=dev) for _ in range(B)]
+    t_type = [torch.full((F,), -7, dtype=torch.int32, device=dev) for _ in range(B)]
+    torch.cuda.synchronize()
+    est.setInputClouds(t_clouds, 16)
+    for b in range(B):
+        est.setGroundPlane(GroundPlane(planes[b][0], t_inl[b]), slot=b)
+    est.CalculateDepths(t_uvs, t_depth, t_type)
+    est.synchronize()
+    for b in range(B):
+        _, (d0, t0) = run_oracle(P, clouds[b], uvs[b], planes[b])
+        assert_depth_parity(t_depth[b].cpu().numpy(), t_type[b].cpu().numpy(), d0, t0)
+    # one frame at a time on an unaligned cloud (single-slot launch)
+    est1 = make_estimator(P)
+    est1.setInputCloud(t_clouds[1], GroundPlane(planes[1][0], t_inl[1]))
+    d1, t1 = est1.CalculateDepth(t_uvs[1])
+    _, (d0, t0) = run_oracle(P, clouds[1], uvs[1], planes[1])
+    assert_depth_parity(d1.cpu().numpy(), t1.cpu().numpy(), d0, t0)
