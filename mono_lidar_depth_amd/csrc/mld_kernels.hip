@@ -51,31 +51,58 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
     hi = __builtin_amdgcn_readlane(hi, lane);
     return __hiloint2double(hi, lo);
 }
+// Wavefront max / min as DPP reductions: four row shifts, two row broadcasts, one v_readlane - six dependent VALU steps
+// and no LDS (the __shfl_xor butterfly is six dependent ds_bpermute round trips, ~100 cycles each, through the same LDS
+// pipe the lists of the feature kernels live in).  A lane without a valid DPP source keeps its own value (old = v), so
+// no identity element is needed.  For wave-uniform control flow with all 64 lanes active (every caller: one-wave blocks);
+// the result is uniform (lane 63's).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_self(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_self_f64(double v) {
+    const int lo = dpp_self<CTRL, ROW_MASK>(__double2loint(v)), hi = dpp_self<CTRL, ROW_MASK>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+#define MLD_DPP_REDUCE(OP, MOV)                       \
+    v = OP(v, MOV<0x111, 0xf>(v)); /* row_shr:1 */    \
+    v = OP(v, MOV<0x112, 0xf>(v)); /* row_shr:2 */    \
+    v = OP(v, MOV<0x114, 0xf>(v)); /* row_shr:4 */    \
+    v = OP(v, MOV<0x118, 0xf>(v)); /* row_shr:8 */    \
+    v = OP(v, MOV<0x142, 0xa>(v)); /* row_bcast:15 */ \
+    v = OP(v, MOV<0x143, 0xc>(v)); /* row_bcast:31 */
 __device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+    MLD_DPP_REDUCE(fmax, dpp_self_f64)
+    return readlane_f64(v, 63);
 }
 __device__ __forceinline__ double wave_min_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-    return v;
+    MLD_DPP_REDUCE(fmin, dpp_self_f64)
+    return readlane_f64(v, 63);
 }
+// Sum with the same steps (a lane without a source adds +0.0).  Its association - prefix sums along the rows, then the
+// rows' totals - is neither the reference's sequential one nor a butterfly's; the callers are the road estimator and
+// the PCA of the wave-cooperative kernel, which answer to the 1e-4 m tolerance, not to bit equality.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_zero_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_add(double a, double b) { return a + b; }
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    MLD_DPP_REDUCE(dpp_add, dpp_zero_f64)
+    return readlane_f64(v, 63);
 }
 __device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
+    MLD_DPP_REDUCE(max, dpp_self)
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
+    MLD_DPP_REDUCE(min, dpp_self)
+    return __builtin_amdgcn_readlane(v, 63);
 }
+#undef MLD_DPP_REDUCE
 
 // blockIdx -> (slot, block-within-slot).  Slots are taken in groups of 8 whose blocks are interleaved, so that all
 // blocks of one slot are congruent mod 8, i.e. land on the same XCD under round-robin dispatch: the slot's map and
