@@ -1599,7 +1599,8 @@ __device__ __forceinline__ void enqueue_features(int32_t* queue, int32_t* count,
 // The road fallback once the wide-window list (k2 entries, original point indices in the low 24 bits) is in `lst`.
 template <int ROAD_MODE>
 __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, bool cand,
-                                                const int k2, const double myu, const double myv, int& mytype,
+                                                const int k2, const uint32_t list_states, const double myu,
+                                                const double myv, int& mytype,
                                                 double& mydepth, bool& overflow ST_ARG) {
     const int roadMode = ROAD_MODE >= 0 ? ROAD_MODE : c.roadMode;
     const int resultOld = mytype;
@@ -1614,7 +1615,6 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
     }
     // CalculateDepthSegmentationPlane (DepthEstimator.cpp:782-900) + first M-estimator pass, serial order
     const int n2 = cand ? k2 : 0;
-    const int n2max = uniform(wave_max_i32(n2));
     bool far = false;
     int kk = 0;
     double zmn = 1.7976931348623157e308, zmx = -1.7976931348623157e308;
@@ -1658,24 +1658,25 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
     // general loop below.
     bool by_state = false;
     if (s.mask_in_key) {
-        bool unsure = false;
-        for (int e = 0; e < n2max; e++) {
-            const uint32_t st = (e < n2) ? ((LST(min(e, c.k1max - 1)) >> kEntStateShift) & 3u) : 0u;
-            far = far || (st == kPtFar);
-            unsure = unsure || (st == kPtUnsure);
-        }
-        by_state = !wave_any(unsure);
+        // (what the scan saw in the lane's keys: scan_window_flagged)
+        far = n2 > 0 && (list_states & 1u);
+        by_state = !wave_any(n2 > 0 && (list_states & 2u));
         if (!by_state) far = false;
     }
     if (by_state) {
         const int n2f = far ? 0 : n2;  // :591 a far point in the window: the feature keeps the main path's result
         const int n2fmax = uniform(wave_max_i32(n2f));
-        for (int e = 0; e < n2fmax; e++) {
-            const uint32_t ent = (e < n2f) ? LST(min(e, c.k1max - 1)) : 0u;
-            if (((ent >> kEntStateShift) & 3u) == kPtInlier) {
-                LST(kk) = ent & kIdxMask;  // kk <= e: entries not yet read are never overwritten
-                kk++;
-            }
+        // four independent LDS reads per step; kk <= e: entries not yet read are never overwritten
+        for (int e = 0; e < n2fmax; e += 4) {
+            uint32_t ent[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) ent[q] = (e + q < n2f) ? LST(min(e + q, c.k1max - 1)) : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (((ent[q] >> kEntStateShift) & 3u) == kPtInlier) {
+                    LST(kk) = ent[q] & kIdxMask;
+                    kk++;
+                }
         }
         const int ni = (cand && !far && kk >= 3) ? kk : 0;
         const int nimax = uniform(wave_max_i32(ni));
@@ -1688,6 +1689,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
                 if (e0 + q < ni) add_inlier(raw_point(c, rp[q]));
         }
     } else {
+    const int n2max = uniform(wave_max_i32(n2));
     for (int e0 = 0; e0 < n2max; e0 += kRoadBatch) {
         RawP rp[kRoadBatch];
         uint32_t ids[kRoadBatch], mw[kRoadBatch];
@@ -1833,6 +1835,12 @@ __device__ __forceinline__ void main_hist(const Calib& c, const SlotDesc& s, uin
             double q = fabs(value / c.binW);
             bmin = (int)((lim < q) ? lim : q);  // bin index is monotone in d: the smallest d gives the first bin
         }
+        // bins (relative to the first one, one byte each) of the first kZc entries: packed in registers, 0xFF beyond
+        // the list's end (never a bin the scan below asks for); the entries behind them carry theirs in the list
+        constexpr int kRelWords = (kZc + 3) / 4;
+        uint32_t relw[kRelWords];
+#pragma unroll
+        for (int t = 0; t < kRelWords; t++) relw[t] = 0xFFFFFFFFu;
 #pragma unroll
         for (int q = 0; q < kZc; q++) {
             double d = (999. < zc[q]) ? 999. : zc[q];
@@ -1840,8 +1848,9 @@ __device__ __forceinline__ void main_hist(const Calib& c, const SlotDesc& s, uin
             double qq = fabs(value / c.binW);
             int bi = (int)((lim < qq) ? lim : qq);
             int rel = bi - bmin;
-            rel = rel > 255 ? 255 : rel;
-            if (q < ks) LST(q) = (LST(q) & kIdxMask) | ((uint32_t)rel << kIdxBits);
+            rel = rel > 255 ? 255 : rel;  // (the scan below never asks for bin 255: 0xFF doubles as "no entry")
+            const uint32_t byte = (q < ks) ? (uint32_t)rel : 0xFFu;
+            relw[q >> 2] = (relw[q >> 2] & ~(0xFFu << (8 * (q & 3)))) | (byte << (8 * (q & 3)));
         }
         for (int e0 = kZc; e0 < kmax; e0 += kBatch) {
             RawP rp[kBatch];
@@ -1873,9 +1882,20 @@ __device__ __forceinline__ void main_hist(const Calib& c, const SlotDesc& s, uin
                 } else {
                     int last = binValue;
                     int cnt = 0;
-                    // four independent LDS reads per step (wave-uniform bound) instead of one dependent read
-                    // per entry
-                    for (int e = 0; e < kmax; e += 4) {
+                    // the first kZc entries: bytes equal to irel, counted in the packed registers (a zero byte of
+                    // x ^ irel-in-every-byte; exact zero-byte mask, one population count per word)
+                    {
+                        const uint32_t rep = (uint32_t)irel * 0x01010101u;
+#pragma unroll
+                        for (int t = 0; t < kRelWords; t++) {
+                            const uint32_t y = relw[t] ^ rep;
+                            const uint32_t nz = ((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu;
+                            cnt += __popc(~nz);
+                        }
+                    }
+                    // the rest, if any lane's list is longer: four independent LDS reads per step (wave-uniform
+                    // bound) instead of one dependent read per entry
+                    for (int e = kZc; e < kmax; e += 4) {
                         uint32_t vv[4];
 #pragma unroll
                         for (int q = 0; q < 4; q++) vv[q] = LST(min(e + q, c.k1max - 1));
@@ -1906,7 +1926,7 @@ __device__ __forceinline__ void main_hist(const Calib& c, const SlotDesc& s, uin
 #pragma unroll
         for (int q = 0; q < kZc; q++) {
             const uint32_t packed = (q < ks) ? LST(q) : 0u;
-            const int rel = (int)(packed >> kIdxBits);
+            const int rel = (int)((relw[q >> 2] >> (8 * (q & 3))) & 0xFFu);
             const double z = zc[q];
             const double d = (999. < z) ? 999. : z;
             const bool keep = (q < ks) && !hfail && (rel >= binMaxRel - 1) && (rel <= binMaxRel + 1) &&
@@ -2400,9 +2420,12 @@ constexpr int kKeyBatchF = MLD_KEY_BATCH_F;  // map keys fetched per round trip 
 // bit 31 set for the cells that also lie inside the narrow window (xn0, yn0, nxn, nyn).  The lane's list ends up
 // holding ORIGINAL POINT INDICES (low 24 bits) | flag.  Returns the entry count (may exceed c.k1max: overflow), the
 // number of flagged entries in kflag.
+// While the keys are in registers the scan also writes the narrow list `nl` (the flagged entries' point indices, same
+// order, at most c.kMain of them) and gathers what the road fallback wants to know about the lane's list before it
+// touches a point: states = bit 0 "a far point", bit 1 "an unsure point" (k_project_scatter's plane states).
 __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDesc& s, int x0, int y0, int nx, int ny,
-                                                   int xn0, int yn0, int nxn, int nyn, uint32_t* lst, int lane,
-                                                   int& kflag ST_ARG) {
+                                                   int xn0, int yn0, int nxn, int nyn, uint32_t* lst, uint32_t* nl,
+                                                   int lane, int& kflag, uint32_t& states ST_ARG) {
     const int nymax = uniform(wave_max_i32(ny));
     const auto* bm = GPTR(uint32_t, s.bitmap);
     // windows are at most 32 cells wide here (k_classify routes wider ones to the wave kernel): 32-bit row masks
@@ -2490,6 +2513,8 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDes
     const int kk = k <= c.k1max ? k : 0;
     const int kmax = uniform(wave_max_i32(kk));
     const auto* mp = GPTR(uint32_t, s.map);
+    int kn = 0;
+    uint32_t st_any = 0u;
     for (int e0 = 0; e0 < kmax; e0 += kKeyBatchF) {
         uint32_t cell[kKeyBatchF], key[kKeyBatchF];
 #pragma unroll
@@ -2498,10 +2523,19 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDes
         for (int q = 0; q < kKeyBatchF; q++) key[q] = (e0 + q < kk) ? MLD_DIAG_KEY(mp[cell[q] & 0x7FFFFFFFu], s.tag, cell[q]) : 0u;
 #pragma unroll
         for (int q = 0; q < kKeyBatchF; q++)
-            if (e0 + q < kk) LST(e0 + q) = key_index(key[q]) | ((key[q] & 3u) << kEntStateShift) | (cell[q] & kEntNarrow);
+            if (e0 + q < kk) {
+                const uint32_t idx = key_index(key[q]), st = key[q] & 3u;
+                LST(e0 + q) = idx | (st << kEntStateShift) | (cell[q] & kEntNarrow);
+                st_any |= (st == kPtFar ? 1u : 0u) | (st == kPtUnsure ? 2u : 0u);
+                if ((cell[q] & kEntNarrow) && kn < c.kMain) {
+                    nl[kn * kWave + lane] = idx;
+                    kn++;
+                }
+            }
     }
     ST_MARK(4);
     kflag = kf;
+    states = st_any;
     return k;
 }
 
@@ -2567,23 +2601,12 @@ __global__ __launch_bounds__(kWave, MLD_FUSED_WAVES) MLD_FUSED_ATTR void k_featu
             ny = nyn;
         }
         int k1 = 0;
-        const int k2 = scan_window_flagged(c, s, x0, y0, nx, ny, xn0, yn0, nxn, nyn, lst, lane, k1 ST_PASS);
+        uint32_t list_states = 0u;
+        const int k2 = scan_window_flagged(c, s, x0, y0, nx, ny, xn0, yn0, nxn, nyn, lst, nl, lane, k1, list_states ST_PASS);
         // (k_classify keeps windows wider than 32 cells out of the live queue)
         bool overflow = active && (k2 > c.k1max || k1 > c.kMain);
         int ovf_code = -1;
-        // narrow list = the flagged entries, same order
-        {
-            const int n2 = (active && !overflow) ? k2 : 0;
-            const int n2max = uniform(wave_max_i32(n2));
-            int kk = 0;
-            for (int e = 0; e < n2max; e++) {
-                const uint32_t v = LST(min(e, c.k1max - 1));
-                if (e < n2 && (v >> 31)) {
-                    nl[kk * kWave + lane] = v & kIdxMask;
-                    kk++;
-                }
-            }
-        }
+        // (the narrow list - the flagged entries, same order - was written by the scan)
         ST_MARK(5);
         int mytype = MLD_Unspecified;
         double mydepth = -1.0;
@@ -2611,7 +2634,7 @@ __global__ __launch_bounds__(kWave, MLD_FUSED_WAVES) MLD_FUSED_ATTR void k_featu
         if (__any(cand)) {
             const int resultOld = mytype;
             bool ovf2 = false;
-            road_after_scan<ROAD_MODE>(c, s, lst, lane, cand, k2, myu, myv, mytype, mydepth, ovf2 ST_PASS);
+            road_after_scan<ROAD_MODE>(c, s, lst, lane, cand, k2, list_states, myu, myv, mytype, mydepth, ovf2 ST_PASS);
             if (ovf2) {  // only the road part is redone by the wave kernel
                 overflow = true;
                 ovf_code = resultOld;
