@@ -184,8 +184,9 @@ int mld_synchronize(mld_ctx* ctx);
  */
 int mld_order_after(mld_ctx* ctx, mld_ctx* other);
 /*
- * mld_order_after_classify: the same hand-over, but `ctx` is released behind the classification kernel of `other`'s NEXT
- *   mld_calculate_depth(s)_device call instead of at once: the classification (one 1024-thread block and 63 KB of LDS per
+ * mld_order_after_classify: the same hand-over, but it is `ctx`'s next PROJECTION KERNEL (and what follows it) that waits -
+ *   the bitmap fill and descriptor upload queued ahead of that kernel do not -, and it is released behind the
+ *   classification kernel of `other`'s NEXT mld_calculate_depth(s)_device call instead of at once: the classification (one 1024-thread block and 63 KB of LDS per
  *   frame, 40 us per 1024 frames) then has the GPU to itself instead of competing with 131 072 projection blocks for wave
  *   slots, and the projection of `ctx` still runs beside the long feature kernels (measured: k_classify 70-90 -> 44 us,
  *   the step 0.5-1.5 % shorter and steadier; LAB.md 4.17).  Nothing waits if `other` never issues that call; a pending

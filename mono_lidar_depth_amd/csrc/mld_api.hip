@@ -213,6 +213,7 @@ struct mld_ctx {
     hipEvent_t order_ev = nullptr;  // mld_order_after
     mld_ctx* release_waiter = nullptr;  // mld_order_after_classify: released behind this context's next k_classify
     mld_ctx* waiting_on = nullptr;      //   (back pointer: either context may be destroyed first)
+    bool order_wait_pending = false;    //   order_ev is recorded; the next projection launch of this context waits for it
     // mld_pair_contexts: the batched projections of two contexts share ONE stream (back to back, no cross-stream
     // hand-over between them); each context's feature kernels stay on its own stream, joined by two events per batch
     hipStream_t proj_stream = nullptr;  // nullptr: projections run on `stream`
@@ -633,6 +634,10 @@ int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int sl
     for (int i = slot; i < slot + (single ? 1 : n_slots); i++)
         aligned = aligned && (((uintptr_t)ctx->slots[i].d.cloud) & 15) == 0;
     auto kp = aligned ? mld::k_project_scatter<true> : mld::k_project_scatter<false>;
+    if (ctx->order_wait_pending) {  // mld_order_after_classify
+        ctx->order_wait_pending = false;
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->order_ev, 0));
+    }
     ScopedTimer tm(ctx, 0, st);
     if (single) {
         hipLaunchKernelGGL(kp, dim3(per_slot), dim3(kProjThreads), 0, st, ctx->d_slots, ctx->slots[slot].d, 1, ctx->calib, 1,
@@ -693,8 +698,11 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         mld_ctx* w = ctx->release_waiter;
         ctx->release_waiter = nullptr;
         w->waiting_on = nullptr;
+        // The waiting context inserts the wait right in front of its next projection KERNEL (launch_project): what it
+        // queues ahead of that kernel - the batch's bitmap fill, descriptor upload, a map clear on tag wrap - does not
+        // wait and is out of the way when the projection is released.
         HIP_TRY(ctx, hipEventRecord(w->order_ev, ctx->stream));
-        HIP_TRY(ctx, hipStreamWaitEvent(w->stream, w->order_ev, 0));
+        w->order_wait_pending = true;
     }
     if (calib.threadPath) {
         ScopedTimer tm(ctx, 1);

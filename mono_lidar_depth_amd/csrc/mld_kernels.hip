@@ -223,7 +223,10 @@ __global__ __launch_bounds__(kProjThreads) MLD_PROJ_ATTR void k_project_scatter(
     // Raised issue priority: beside another context's feature kernels (long f64 sequences, always ready to issue)
     // the few instructions a projection wave needs between its loads and its atomics would otherwise wait their
     // turn; measured side by side 0.843 -> 0.815 ms per 1024 frames, alone no difference.
-    __builtin_amdgcn_s_setprio(3);
+#ifndef MLD_PROJ_PRIO
+#define MLD_PROJ_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(MLD_PROJ_PRIO);
     int slot, j;
     decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
     SlotDesc s = use_single ? single : slots[slot];  // block-uniform: scalar loads, field by field
