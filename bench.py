@@ -1203,7 +1203,26 @@ def main():
         counter_bytes = sum(float(tj[k]["hbm_bytes_per_launch"]) for k in
                             ("k_project_scatter", "k_classify", "k_feature_fused", "k_feature_wave") if k in tj) * scale * sets_per_step
     compulsory = 16.0 * N * B
+    # HBM time of the step: the streamed bytes (projection, classification) at the rate the projection reaches alone, plus
+    # the feature kernel's fetches from memory - random 64-byte lines - at the random-line rate of the device
+    # (profiles/tools/randgather.hip, same session as the counters).  A pure device-to-device copy beside one context slows
+    # its feature kernel exactly as the other context's projection does (profiles/tools/interference.py, LAB.md 4.25):
+    # memory, not wave slots or registers, is what the two contexts share.
+    hbm_busy = None
+    try:
+        if tj:
+            scale = float(S) / float(tj["frames_per_launch"]) * sets_per_step
+            stream_rate = float(tj["k_project_scatter"]["hbm_bytes_per_launch"]) / float(tj["k_project_scatter"]["launch_s"])
+            streamed = (float(tj["k_project_scatter"]["hbm_bytes_per_launch"]) + float(tj["k_classify"]["hbm_bytes_per_launch"])) * scale
+            lines = float(tj["k_feature_fused"]["tcc_ea_rdreq"]) * scale
+            line_rate = float(tj["gather_ceilings"]["hbm_Glines_s"]) * 1e9
+            busy_s = streamed / stream_rate + lines / line_rate
+            hbm_busy = {"streamed_bytes": streamed, "stream_rate_GBps": stream_rate / 1e9, "random_lines": lines,
+                        "random_line_rate_Glines_s": line_rate / 1e9, "busy_ms": 1e3 * busy_s, "frac_of_step": busy_s / step_s}
+    except (KeyError, TypeError, ZeroDivisionError):
+        hbm_busy = None
     roofline["whole_step"] = {
+        "hbm_busy": hbm_busy,
         "counter_bytes": counter_bytes,
         "compulsory_bytes": compulsory,
         "step_ms": 1e3 * step_s,

@@ -63,6 +63,9 @@ def test_bench_single_rank_line_is_physical():
     ws = r["whole_step"]
     assert ws["compulsory_bytes"] == 16.0 * 131072 * 32 and 0.0 < ws["compulsory_frac_of_peak"] < 1.0
     assert ws["counter_bytes"] > ws["compulsory_bytes"] * 0.9 and 0.0 < ws["frac_of_peak"] < 1.0
+    # HBM time of the step from the committed counters: streamed bytes at the projection's own rate + random lines
+    hb = ws["hbm_busy"]
+    assert hb["streamed_bytes"] > ws["compulsory_bytes"] and hb["random_lines"] > 0 and 0.0 < hb["frac_of_step"] < 1.5
     assert out["timed_loops"]["repeats"] >= 2 and out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
 
 
