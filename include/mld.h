@@ -165,9 +165,9 @@ int mld_synchronize(mld_ctx* ctx);
 
 /*
  * Two (or more) contexts on one GPU, used alternately ("double buffering"; DESIGN.md §4 "Batches").
- * The projection kernel streams the clouds from HBM and leaves most of a CU's issue slots idle; the feature kernels are
- * the opposite (gather- and issue-bound, ~10 % of the HBM bandwidth).  Run beside each other they finish sooner than
- * one after the other -- the reference has no counterpart: its stage A is serial and its feature loop is the only
+ * The projection kernel streams the clouds from HBM; the feature kernels wait for scattered fetches and move a tenth of
+ * the bytes.  Run beside each other they finish sooner than one after the other (HBM busy 0.8 of the step instead of
+ * 0.6) -- the reference has no counterpart: its stage A is serial and its feature loop is the only
  * parallel part (DepthEstimator.cpp:156-217 vs :455).  Schedule per batch, contexts taken round-robin:
  *     mld_set_clouds_*_device(ctx_k, ...);      projection of batch i on context k
  *     mld_order_after(ctx_next, ctx_k);          the NEXT context's projection starts when this one is done ...
@@ -178,16 +178,16 @@ int mld_synchronize(mld_ctx* ctx);
  *   finished (one event; no host synchronisation).  Both contexts must live on the same device.
  * mld_set_shared_gpu(ctx, 1): the lane-per-feature kernel of `ctx` keeps to two wavefronts per SIMD (it requests more
  *   LDS per block), which leaves registers for the other context's projection wavefronts on every CU.  A context that
- *   has the GPU to itself is ~7 % slower in this mode; the alternating pair is ~18 % faster (bench.py default:
- *   0.78 instead of 0.95 ms per 1024 frames of config 2).  `shared`: bit 0 = on; bits 8..15 = wavefronts of the
+ *   has the GPU to itself is ~7 % slower in this mode; the alternating pair is ~20 % faster (bench.py default:
+ *   0.71 instead of 0.91 ms per 1024 frames of config 2).  `shared`: bit 0 = on; bits 8..15 = wavefronts of the
  *   lane-per-feature kernel per CU in that mode (0 = the default, 8): fewer leave more of every CU to the projection.
  */
 int mld_order_after(mld_ctx* ctx, mld_ctx* other);
 /*
  * mld_order_after_classify: the same hand-over, but it is `ctx`'s next PROJECTION KERNEL (and what follows it) that waits -
  *   the bitmap fill and descriptor upload queued ahead of that kernel do not -, and it is released behind the
- *   classification kernel of `other`'s NEXT mld_calculate_depth(s)_device call instead of at once: the classification (one 1024-thread block and 63 KB of LDS per
- *   frame, 40 us per 1024 frames) then has the GPU to itself instead of competing with 131 072 projection blocks for wave
+ *   classification kernel of `other`'s NEXT mld_calculate_depth(s)_device call instead of at once: the classification
+ *   (one 1024-thread block and 63 KB of LDS per frame, 40 us per 1024 frames) then has the GPU to itself instead of competing with 131 072 projection blocks for wave
  *   slots, and the projection of `ctx` still runs beside the long feature kernels (measured: k_classify 70-90 -> 44 us,
  *   the step 0.5-1.5 % shorter and steadier; LAB.md 4.17).  Nothing waits if `other` never issues that call; a pending
  *   hand-over ends with either context.  Purely a scheduling hint: the contexts share no data.
