@@ -213,7 +213,13 @@ struct mld_ctx {
     hipEvent_t order_ev = nullptr;  // mld_order_after
     mld_ctx* release_waiter = nullptr;  // mld_order_after_classify: released behind this context's next k_classify
     mld_ctx* waiting_on = nullptr;      //   (back pointer: either context may be destroyed first)
-    bool order_wait_pending = false;    //   order_ev is recorded; the next projection launch of this context waits for it
+    bool order_wait_pending = false;
+    uint32_t* cls_done = nullptr;       //   gate hand-over: k_classify blocks of this context that have finished (device)
+    uint32_t cls_target = 0;            //   ... and how many there will be once everything queued so far has run
+    const uint32_t* gate_counter = nullptr;  // the counter / value this context's next projection waits for (k_gate)
+    uint32_t gate_target = 0;
+    bool gate_mode = true;              //   hand over through k_gate (a polling wavefront) instead of a cross-stream event
+    mld_ctx* gate_waiter = nullptr;     //   the context whose pending gate reads cls_done (either may be destroyed first)    //   order_ev is recorded; the next projection launch of this context waits for it
     // mld_pair_contexts: the batched projections of two contexts share ONE stream (back to back, no cross-stream
     // hand-over between them); each context's feature kernels stay on its own stream, joined by two events per batch
     hipStream_t proj_stream = nullptr;  // nullptr: projections run on `stream`
@@ -427,6 +433,8 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     if (const char* e = std::getenv("MLD_FORCE_THREAD_PATH")) ctx->force_thread_path = e[0] == '1';
     //   MLD_PROJ_LDS=bytes     occupancy experiments: the batched projection asks for that much (unused) LDS per block
     if (const char* e = std::getenv("MLD_PROJ_LDS")) ctx->proj_lds = (size_t)std::atoll(e);
+    //   MLD_GATE=0             mld_order_after_classify hands over through a cross-stream event instead of k_gate (A/B)
+    if (const char* e = std::getenv("MLD_GATE")) ctx->gate_mode = e[0] != '0';
     //   MLD_FRAME_COPY=1       one-frame calls return their results through device memory and a D2H copy (A/B of the
     //                          direct stores into the pinned block)
     if (const char* e = std::getenv("MLD_FRAME_COPY")) ctx->fr_zero_copy = e[0] != '1';
@@ -636,7 +644,14 @@ int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int sl
     auto kp = aligned ? mld::k_project_scatter<true> : mld::k_project_scatter<false>;
     if (ctx->order_wait_pending) {  // mld_order_after_classify
         ctx->order_wait_pending = false;
-        HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->order_ev, 0));
+        if (ctx->gate_counter) {
+            hipLaunchKernelGGL(mld::k_gate, dim3(1), dim3(kWave), 0, st, ctx->gate_counter, ctx->gate_target, 100000);
+            ctx->gate_counter = nullptr;
+            if (ctx->waiting_on && ctx->waiting_on->gate_waiter == ctx) ctx->waiting_on->gate_waiter = nullptr;
+            ctx->waiting_on = nullptr;
+        } else {
+            HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->order_ev, 0));
+        }
     }
     ScopedTimer tm(ctx, 0, st);
     if (single) {
@@ -689,8 +704,24 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         ScopedTimer ts(ctx, 5);
         auto kc = ctx->classify_staged ? mld::k_classify<true, kClsThreads, kClsKeep>
                                        : mld::k_classify<false, kClsThreads, kClsKeep>;
+        const bool gate = ctx->gate_mode && ctx->release_waiter && !single;
+        if (gate && !ctx->cls_done) {
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->cls_done, sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->cls_done, 0, sizeof(uint32_t), ctx->stream));
+        }
         hipLaunchKernelGGL(kc, dim3((unsigned)ns), dim3(kClsThreads), ctx->lds_classify, ctx->stream, ctx->d_slots, one,
-                           use_single, calib, ctx->bm_ncol, ctx->bm_ncolp);
+                           use_single, calib, ctx->bm_ncol, ctx->bm_ncolp, gate ? ctx->cls_done : (uint32_t*)nullptr);
+        if (gate) {
+            mld_ctx* w = ctx->release_waiter;
+            ctx->release_waiter = nullptr;
+            w->waiting_on = nullptr;
+            ctx->cls_target += (uint32_t)ns;
+            w->gate_counter = ctx->cls_done;
+            w->gate_target = ctx->cls_target;
+            w->order_wait_pending = true;
+            w->waiting_on = ctx;
+            ctx->gate_waiter = w;
+        }
     }
     // mld_order_after_classify: the waiting context is released here - behind the classification (which wants every
     // CU's wave slots and LDS for 40 us), ahead of the long feature kernels
@@ -1019,7 +1050,14 @@ void mld_destroy(mld_ctx* ctx) {
     }
     // a pending mld_order_after_classify hand-over dies with either of its contexts
     if (ctx->waiting_on && ctx->waiting_on->release_waiter == ctx) ctx->waiting_on->release_waiter = nullptr;
+    if (ctx->waiting_on && ctx->waiting_on->gate_waiter == ctx) ctx->waiting_on->gate_waiter = nullptr;
     if (ctx->release_waiter) ctx->release_waiter->waiting_on = nullptr;
+    if (ctx->gate_waiter) {  // (its gate would poll a counter that is about to be freed)
+        ctx->gate_waiter->gate_counter = nullptr;
+        ctx->gate_waiter->order_wait_pending = false;
+        ctx->gate_waiter->waiting_on = nullptr;
+    }
+    if (ctx->cls_done) (void)hipFree(ctx->cls_done);
     for (hipEvent_t e : ctx->fr_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->side_start) (void)hipEventDestroy(ctx->side_start);
