@@ -440,3 +440,47 @@ def test_clouds_off_16_byte_boundaries(mixed):
     d1, t1 = est1.CalculateDepth(t_uvs[1])
     _, (d0, t0) = run_oracle(P, clouds[1], uvs[1], planes[1])
     assert_depth_parity(d1.cpu().numpy(), t1.cpu().numpy(), d0, t0)
+
+
+@pytest.mark.parametrize("destroy_first", ["released", "releasing"])
+def test_pending_gate_survives_either_context_going_first(destroy_first):
+    """mld_order_after_classify hands over through a polling wavefront queued in front of the released context's NEXT
+    projection.  Here that projection never comes: the classification has run (the gate's counter and target are set on
+    the released context) and one of the two contexts is destroyed - the other must neither poll freed memory nor keep a
+    pointer to the dead context (it goes on to compute a correct batch)."""
+    import torch
+    P = capi.params_c0()
+    S, F = 4, 300
+    dev = torch.device("cuda:0")
+    a, b = make_estimator(P, max_frames=S, max_features=F), make_estimator(P, max_frames=S, max_features=F)
+
+    def batch(e, seed):
+        clouds = [synth.make_cloud(synth.HDL64_KITTI, seed=seed, frame=i) for i in range(S)]
+        planes = [synth.make_ground_plane(c) for c in clouds]
+        uvs = [synth.make_features(F, seed=seed + i) for i in range(S)]
+        d = [torch.empty(F, dtype=torch.float64, device=dev) for _ in range(S)]
+        t = [torch.empty(F, dtype=torch.int32, device=dev) for _ in range(S)]
+        masks = []
+        for p, c in zip(planes, clouds):
+            m = np.zeros((c.shape[0] + 31) // 32, dtype=np.uint32)
+            np.bitwise_or.at(m, p[1] >> 5, (np.uint32(1) << (p[1] & 31).astype(np.uint32)))
+            masks.append(torch.from_numpy(m.view(np.int32)).to(dev))
+        pb = e.prepareBatch([torch.from_numpy(c).to(dev) for c in clouds], [torch.from_numpy(u).to(dev) for u in uvs], d, t,
+                            np.stack([p[0] for p in planes]), masks)
+        return pb, clouds, planes, uvs, d, t
+
+    ba = batch(a, 500)
+    torch.cuda.synchronize()
+    a.runBatchBeside(ba[0], b)   # b is released behind a's classification: the gate is now pending on b
+    a.synchronize()
+    survivor = a if destroy_first == "released" else b
+    (b if destroy_first == "released" else a).close()
+    bs = batch(survivor, 600)
+    torch.cuda.synchronize()
+    survivor.runBatch(bs[0])     # (b: its pending gate must have been dropped with a's counter)
+    survivor.synchronize()
+    _, clouds, planes, uvs, d, t = bs
+    for i in range(S):
+        _, (d0, t0) = run_oracle(P, clouds[i], uvs[i], planes[i])
+        assert_depth_parity(d[i].cpu().numpy(), t[i].cpu().numpy(), d0, t0)
+    survivor.close()
