@@ -192,7 +192,7 @@ int mld_order_after(mld_ctx* ctx, mld_ctx* other);
  *   the step 0.5-1.5 % shorter and steadier; LAB.md 4.17).  The release itself is a one-wavefront kernel (k_gate) queued
  *   in front of the projection that polls a counter of finished classification blocks - 2-3 us from the last block to the
  *   projection's start instead of the ~15 us of a cross-stream event (LAB.md 4.28); its polling is bounded (it gives up
- *   after ~0.1 s), because nothing depends on it: purely a scheduling hint, the contexts share no data.  Nothing waits if
+ *   after 100 000 polls, a fraction of a second), because nothing depends on it: purely a scheduling hint, the contexts share no data.  Nothing waits if
  *   `other` never issues that call; a pending hand-over ends with either context.
  */
 int mld_order_after_classify(mld_ctx* ctx, mld_ctx* other);
