@@ -219,6 +219,7 @@ struct mld_ctx {
     const uint32_t* gate_counter = nullptr;  // the counter / value this context's next projection waits for (k_gate)
     uint32_t gate_target = 0;
     bool gate_mode = true;              //   hand over through k_gate (a polling wavefront) instead of a cross-stream event
+    mld_ctx* gate_src = nullptr;        //   the context whose cls_done this context's pending gate reads (its gate_waiter is this one)
     mld_ctx* gate_waiter = nullptr;     //   the context whose pending gate reads cls_done (either may be destroyed first)    //   order_ev is recorded; the next projection launch of this context waits for it
     // mld_pair_contexts: the batched projections of two contexts share ONE stream (back to back, no cross-stream
     // hand-over between them); each context's feature kernels stay on its own stream, joined by two events per batch
@@ -647,8 +648,9 @@ int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int sl
         if (ctx->gate_counter) {
             hipLaunchKernelGGL(mld::k_gate, dim3(1), dim3(kWave), 0, st, ctx->gate_counter, ctx->gate_target, 100000);
             ctx->gate_counter = nullptr;
-            if (ctx->waiting_on && ctx->waiting_on->gate_waiter == ctx) ctx->waiting_on->gate_waiter = nullptr;
-            ctx->waiting_on = nullptr;
+            // (the gate's source, not `waiting_on`: the context may have been re-armed behind another one since)
+            if (ctx->gate_src && ctx->gate_src->gate_waiter == ctx) ctx->gate_src->gate_waiter = nullptr;
+            ctx->gate_src = nullptr;
         } else {
             HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->order_ev, 0));
         }
@@ -716,10 +718,17 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
             ctx->release_waiter = nullptr;
             w->waiting_on = nullptr;
             ctx->cls_target += (uint32_t)ns;
+            // an earlier gate that was never consumed: of `w` on another context, or of another context on this one
+            if (w->gate_src && w->gate_src != ctx && w->gate_src->gate_waiter == w) w->gate_src->gate_waiter = nullptr;
+            if (ctx->gate_waiter && ctx->gate_waiter != w) {
+                ctx->gate_waiter->gate_counter = nullptr;
+                ctx->gate_waiter->order_wait_pending = false;
+                ctx->gate_waiter->gate_src = nullptr;
+            }
             w->gate_counter = ctx->cls_done;
             w->gate_target = ctx->cls_target;
             w->order_wait_pending = true;
-            w->waiting_on = ctx;
+            w->gate_src = ctx;
             ctx->gate_waiter = w;
         }
     }
@@ -733,6 +742,10 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         // queues ahead of that kernel - the batch's bitmap fill, descriptor upload, a map clear on tag wrap - does not
         // wait and is out of the way when the projection is released.
         HIP_TRY(ctx, hipEventRecord(w->order_ev, ctx->stream));
+        // (a stale, unconsumed gate must not be polled instead of this event)
+        if (w->gate_src && w->gate_src->gate_waiter == w) w->gate_src->gate_waiter = nullptr;
+        w->gate_src = nullptr;
+        w->gate_counter = nullptr;
         w->order_wait_pending = true;
     }
     if (calib.threadPath) {
@@ -1050,12 +1063,12 @@ void mld_destroy(mld_ctx* ctx) {
     }
     // a pending mld_order_after_classify hand-over dies with either of its contexts
     if (ctx->waiting_on && ctx->waiting_on->release_waiter == ctx) ctx->waiting_on->release_waiter = nullptr;
-    if (ctx->waiting_on && ctx->waiting_on->gate_waiter == ctx) ctx->waiting_on->gate_waiter = nullptr;
+    if (ctx->gate_src && ctx->gate_src->gate_waiter == ctx) ctx->gate_src->gate_waiter = nullptr;
     if (ctx->release_waiter) ctx->release_waiter->waiting_on = nullptr;
     if (ctx->gate_waiter) {  // (its gate would poll a counter that is about to be freed)
         ctx->gate_waiter->gate_counter = nullptr;
         ctx->gate_waiter->order_wait_pending = false;
-        ctx->gate_waiter->waiting_on = nullptr;
+        ctx->gate_waiter->gate_src = nullptr;
     }
     if (ctx->cls_done) (void)hipFree(ctx->cls_done);
     for (hipEvent_t e : ctx->fr_ev)
@@ -1863,15 +1876,43 @@ static int frame_call(mld_ctx* ctx, int slot, const void* pts_host, int64_t n, i
         const size_t n_chunks = (size_t)((n + 1023) / 1024);
         rs_lds = lds_fixed + (pass ? (n_chunks + 1) * sizeof(int) + 16 * n_chunks + 16 : 0);
         if (rs_lds > 158 * 1024) {
-            float co[4];
+            float co[4] = {0.f, 0.f, 0.f, 0.f};
             int64_t ni = 0;
             if ((rc = mld_set_cloud(ctx, slot, pts_host, n, stride_bytes))) return rc;
-            if ((rc = mld_estimate_ground_plane(ctx, slot, rq->seed, co, &ni))) return rc;
+            const int rc_est = mld_estimate_ground_plane(ctx, slot, rq->seed, co, &ni);
+            if (rc_est && (rc_est != MLD_ERR_CLOUD_TOO_SMALL || !trk)) return rc_est;
             if (plane_out) {
-                for (int t = 0; t < 4; t++) plane_out->coeffs[t] = co[t];
-                plane_out->n_inliers = ni;
-                plane_out->status = 0;
+                for (int t = 0; t < 4; t++) plane_out->coeffs[t] = rc_est ? 0.f : co[t];
+                plane_out->n_inliers = rc_est ? 0 : ni;
+                plane_out->status = rc_est ? 1 : 0;
                 plane_out->iterations = 0;
+            }
+            if (trk) {
+                // the tracklet side of the call on the same route: both CalculateDepth calls + scatter.  A failed
+                // estimation (GroundPlane::ExceptionPclInvalid; the estimator has cleared the slot's plane) still answers
+                // the previous frame's features and invalidates the current ones (tracklet_depth_module.cpp:318-347),
+                // as the one-chain path below does.
+                const std::string why = ctx->err;
+                if (rc_est) clear_plane(s);  // this frame runs without a plane ("decided": the feature calls accept it)
+                struct Undecide {  // ... and the slot forgets it afterwards, as the reference forgets cloud and plane
+                    Slot& s;
+                    bool on;
+                    ~Undecide() {
+                        if (on) s.plane_decided = false;
+                    }
+                } undecide{s, rc_est != 0};
+                if ((rc = mld_tracklets_depth(ctx, slot, trk->slot_last, trk->u_new, trk->v_new, trk->u_old, trk->v_old,
+                                              trk->is_new, nt, trk->d_cur_out, trk->d_last_out, trk->type_cur_out,
+                                              trk->type_last_out, trk->n_new_out)))
+                    return rc;
+                if (rc_est) {
+                    for (int64_t i = 0; i < nt; i++) {
+                        trk->d_cur_out[i] = -1.0f;
+                        if (trk->type_cur_out) trk->type_cur_out[i] = (int32_t)MLD_Unspecified;
+                    }
+                    return fail(ctx, rc_est, why);
+                }
+                return MLD_OK;
             }
             return F > 0 ? mld_calculate_depth(ctx, slot, uv_host, F, depth_out_host, type_out_host) : MLD_OK;
         }

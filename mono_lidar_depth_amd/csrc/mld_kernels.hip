@@ -65,7 +65,21 @@ __device__ __forceinline__ double dpp_self_f64(double v) {
     const int lo = dpp_self<CTRL, ROW_MASK>(__double2loint(v)), hi = dpp_self<CTRL, ROW_MASK>(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "row_bcast:15 / row_bcast:31 (DPP controls 0x142 / 0x143) exist on GFX9 / CDNA only: this library is written for gfx950"
+#endif
+// The reductions read lane 63 after row-wise prefix steps: a partial wave (or a call from divergent control flow) would
+// return a stale register.  The test build (-DMLD_AB_SWITCHES, which the whole GPU parity suite also runs) traps on it.
+#ifdef MLD_AB_SWITCHES
+#define MLD_ASSERT_FULL_WAVE()                                            \
+    do {                                                                  \
+        if (__builtin_amdgcn_read_exec() != ~0ull) __builtin_trap();      \
+    } while (0)
+#else
+#define MLD_ASSERT_FULL_WAVE() do {} while (0)
+#endif
 #define MLD_DPP_REDUCE(OP, MOV)                       \
+    MLD_ASSERT_FULL_WAVE();                           \
     v = OP(v, MOV<0x111, 0xf>(v)); /* row_shr:1 */    \
     v = OP(v, MOV<0x112, 0xf>(v)); /* row_shr:2 */    \
     v = OP(v, MOV<0x114, 0xf>(v)); /* row_shr:4 */    \

@@ -9,7 +9,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
 from mono_lidar_depth_amd import CameraPinhole, DepthEstimator, capi, synth  # noqa: E402
 
 
-def build(B=1024, F=2000, U=16, scanner=None, P=None, seed=0, integer_uv=False):
+def build(B=1024, F=2000, U=16, scanner=None, P=None, seed=0, integer_uv=False, uv_fn=None, list_capacity=None):
     dev = torch.device("cuda:0")
     scanner = scanner or synth.HDL64
     P = P or capi.params_c0()
@@ -35,7 +35,7 @@ def build(B=1024, F=2000, U=16, scanner=None, P=None, seed=0, integer_uv=False):
     for b in range(B):
         all_clouds[b].copy_(du[b % U])
         all_masks[b].copy_(mu[b % U])
-        uv = synth.make_features(F, seed=seed * 100000 + b)
+        uv = uv_fn(F, seed * 100000 + b) if uv_fn else synth.make_features(F, seed=seed * 100000 + b)
         if integer_uv:
             uv = np.floor(uv)
         uvs_h.append(uv)
@@ -45,6 +45,8 @@ def build(B=1024, F=2000, U=16, scanner=None, P=None, seed=0, integer_uv=False):
     est = DepthEstimator(device=0, max_frames=B, max_features=F)
     est.InitConfig(P)
     est.Initialize(cam, synth.T_CAM_LIDAR)
+    if list_capacity:
+        est.setListCapacity(*list_capacity)
     batch = est.prepareBatch([all_clouds[b] for b in range(B)], [all_uvs[b] for b in range(B)],
                              [all_depth[b] for b in range(B)], [all_type[b] for b in range(B)], coeffs,
                              [all_masks[b] for b in range(B)], stride_bytes=16)
