@@ -78,7 +78,7 @@ def parse_args():
     ap.add_argument("--streaming-frames", type=int, default=64, help="frames per batch of the streaming leg")
     ap.add_argument("--config-frames", type=int, default=256,
                     help="resident frames of the config-3 leg / sequence length of the config-5 leg (0 = skip both)")
-    ap.add_argument("--only-config", type=int, default=0, choices=[0, 3, 5],
+    ap.add_argument("--only-config", type=int, default=0, choices=[0, 2, 3, 5],
                     help="run only that BASELINE config's leg and print its object (for per-config rocprofv3 runs)")
     ap.add_argument("--verify-slots", type=int, default=-1,
                     help="frames of the timed batch checked against the oracle: -1 (default) = EVERY frame of every "
@@ -404,7 +404,13 @@ class Resident:
         self.handover = "classify"
         self.clouds_h = [synth.make_cloud(scanner, seed=seq, frame=f) for f in range(U)]
         self.planes_h = [synth.make_ground_plane(c) for c in self.clouds_h]
-        if near_points:  # features around the image positions of the frame's own returns (config 3, second variant)
+        if near_points == "k":  # features whose search window holds >= 6 returns (config 2 at its stated neighbour count)
+            per = (B + U - 1) // U  # one draw per distinct cloud, cut into its frames' feature sets
+            pools = [synth.make_features_k_neighbours(self.clouds_h[u], F * per, seed=seq * 100000 + u, min_neighbours=6,
+                                                      window=(P.pixelarea_search_witdh, P.pixelarea_search_height))
+                     for u in range(U)]
+            self.uvs_h = [np.ascontiguousarray(pools[b % U][(b // U) * F:(b // U + 1) * F]) for b in range(B)]
+        elif near_points:  # features around the image positions of the frame's own returns (config 3, second variant)
             self.uvs_h = [synth.make_features_near_points(self.clouds_h[b % U], F, seed=seq * 100000 + b) for b in range(B)]
         else:
             self.uvs_h = [synth.make_features(F, seed=seq * 100000 + b, integer=integer_uv) for b in range(B)]
@@ -696,6 +702,44 @@ def timed_resident(res, steps, warmup, timing, timing_every, barrier=lambda: Non
     for e in res.ests:
         e.timingEnable(False)
     return loops, kt
+
+
+def config2_k_leg(P, cam, T, device, B, F, steps=20, contexts=2, shared_mode=1):
+    """BASELINE config 2 "at its stated neighbour count" (k = 7): the same 64x2048 clouds, parameters and schedule as the
+    headline, but every feature sits on a LiDAR return whose search window (6 x 9, parameters.yaml:14,17;
+    NeighborFinderPixel.cpp:67-88) holds at least six returns - no feature is settled by the classification alone, every
+    one runs the neighbour gather, the histogram and a plane fit.  (The headline's uniformly random features see 2.3
+    neighbours on average and 42 % of them none.)  Reported beside the headline, never as it; every frame of every
+    output set is checked against the oracle."""
+    from mono_lidar_depth_amd import capi, synth, traffic
+    res = Resident(P, cam, T, synth.HDL64, B, min(16, B), F, 2, device, contexts=contexts, shared_mode=shared_mode,
+                   near_points="k")
+    loops, kt = timed_resident(res, steps, 3, True, 2, repeats=3, min_timed_s=0.3)
+    el = float(np.median(loops))
+    ok, rep = res.verify(-1)
+    hist = np.zeros(capi.MLD_RESULT_TYPE_COUNT, dtype=np.int64)
+    for t_set in res.out_type:
+        hist += res.ests[0].resultHistogram(t_set.reshape(-1))
+    last = res.last_context()
+    stats = [traffic.frame_bytes(P, cam.width, cam.height, res.N, last.getVisibleCount(b), last.getPixelMap(b), res.uvs_h[b],
+                                 res.all_type[b].cpu().numpy()) for b in range(0, B, max(1, B // 4))][:4]
+    out = {
+        "workload": (f"BASELINE config 2 at k = 7: 64x2048 cloud x {F} features/frame on returns whose 6 x 9 search window "
+                     f"holds >= 6 returns, {B} device-resident frames per step, {contexts} contexts alternating"),
+        "value": B * F * steps / el, "unit": "feature-depth associations/s", "ms_per_step": 1e3 * el / steps,
+        "ms_per_frame": 1e3 * el / steps / B, "frames_per_step": B,
+        "k1_mean": float(np.mean([s_["k1_mean"] for s_ in stats])),
+        "k2_mean_fallback": float(np.mean([s_["k2_mean_fallback"] for s_ in stats])),
+        "fallback_features_per_frame": float(np.mean([s_["fallback_features"] for s_ in stats])),
+        "result_types": {capi.RESULT_TYPE_NAMES[i]: int(c) for i, c in enumerate(hist) if c},
+        "success_fraction": float((hist[1] + hist[16]) / max(1, hist.sum())),
+        "dead_features": int(hist[2]),
+        "kernels_ms_per_launch": {k: v["avg_ms"] for k, v in kt.items()},
+        "verified": ok, "frames_checked": rep["frames_checked"], "max_abs_depth_diff_m": rep["max_abs_depth_diff_m"],
+        "poison_left": rep["poison_left"],
+    }
+    res.close()
+    return out
 
 
 def config3_leg(cam, T, device, B, steps=8):
@@ -1015,7 +1059,10 @@ def main():
                         cam_struct.principal_point_y)
 
     if args.only_config:
-        if args.only_config == 3:
+        if args.only_config == 2:
+            leg = config2_k_leg(P, cam, T, gpu_index, args.frames_per_step, args.features, contexts=args.contexts,
+                                shared_mode=args.shared_mode)
+        elif args.only_config == 3:
             leg = config3_leg(cam, T, gpu_index, args.config_frames)
         else:
             leg = config5_leg(cam, T, gpu_index, min(args.config_frames, 200))
@@ -1289,6 +1336,10 @@ def main():
     del res
     torch.cuda.empty_cache()
     if world == 1 and args.config_frames > 0:
+        configs["2"] = {"near_returns": config2_k_leg(P, cam, T, gpu_index, min(B, 1024), F, contexts=args.contexts,
+                                                      shared_mode=args.shared_mode)}
+        configs["2"]["verified"] = configs["2"]["near_returns"]["verified"]
+        torch.cuda.empty_cache()
         configs["3"] = config3_leg(cam, T, gpu_index, args.config_frames)
         configs["5"] = config5_leg(cam, T, gpu_index, min(args.config_frames, 200))
         configs["5"]["batched"] = {str(S5): config5_batched_leg(cam, T, gpu_index, S5) for S5 in (16, 64, 256)}

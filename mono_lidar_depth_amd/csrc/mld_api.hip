@@ -418,7 +418,7 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     ctx->lds_bytes = (size_t)cap * (3 * sizeof(double) + 2 * sizeof(int));
     c.threadPath = 1;
     c.xcdAware = 1;
-    c.splitRoad = 0;
+    c.sortClasses = 4;
     // list capacities of the fused kernel: 32 entries for the scanned (road) window, 24 for the narrow one - 14 KB of
     // LDS per wavefront; longer lists overflow to the wave-cooperative kernel
     c.k1max = 32;
@@ -431,6 +431,8 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     //   MLD_NO_XCD=1           plain block -> slot mapping        MLD_K1MAX / MLD_KMAIN   list capacities
     if (const char* e = std::getenv("MLD_FORCE_WAVE_PATH")) c.threadPath = (e[0] == '1') ? 0 : 1;
     if (const char* e = std::getenv("MLD_NO_XCD")) c.xcdAware = (e[0] == '1') ? 0 : 1;
+    //   MLD_SORT_CLASSES=1     live queue in row order alone (A/B of the count-class order)
+    if (const char* e = std::getenv("MLD_SORT_CLASSES")) c.sortClasses = (e[0] == '4') ? 4 : 1;
     if (const char* e = std::getenv("MLD_FORCE_THREAD_PATH")) ctx->force_thread_path = e[0] == '1';
     //   MLD_PROJ_LDS=bytes     occupancy experiments: the batched projection asks for that much (unused) LDS per block
     if (const char* e = std::getenv("MLD_PROJ_LDS")) ctx->proj_lds = (size_t)std::atoll(e);
@@ -750,7 +752,12 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     }
     if (calib.threadPath) {
         ScopedTimer tm(ctx, 1);
-        auto kf = calib.roadMode ? mld::k_feature_fused<1> : mld::k_feature_fused<0>;
+        // long lists (mld_set_list_capacity beyond the default 32 / 24: dense clouds) take the DENSE instantiation - two
+        // wavefronts per SIMD, which is what their LDS allows anyway, and the registers of the third for the in-register
+        // corner search; never in the shared-GPU mode, whose point is to leave registers to the other context's projection
+        const bool dense = !(ctx->shared_arg & 1) && (calib.k1max > 32 || calib.kMain > 24);
+        auto kf = dense ? (calib.roadMode ? mld::k_feature_fused<1, true> : mld::k_feature_fused<0, true>)
+                        : (calib.roadMode ? mld::k_feature_fused<1, false> : mld::k_feature_fused<0, false>);
         hipLaunchKernelGGL(kf, dim3((unsigned)per_slot * (unsigned)ns), dim3(kWave), ctx->lds_fused + ctx->lds_fused_pad, ctx->stream, ctx->d_slots,
                            one, use_single, calib, ns, per_slot, tag_all);
     }
@@ -957,12 +964,14 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
         if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute(k_classify)");
     }
     if (ctx->lds_fused > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_feature_fused<0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_fused);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_feature_fused<1>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_fused);
-        if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute(k_feature_fused)");
+        const void* fused[] = {reinterpret_cast<const void*>(mld::k_feature_fused<0, false>),
+                               reinterpret_cast<const void*>(mld::k_feature_fused<1, false>),
+                               reinterpret_cast<const void*>(mld::k_feature_fused<0, true>),
+                               reinterpret_cast<const void*>(mld::k_feature_fused<1, true>)};
+        for (const void* f : fused) {
+            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_fused);
+            if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute(k_feature_fused)");
+        }
     }
     ctx->slots.resize(max_frames);
     ctx->h_descs.resize(max_frames);
@@ -1725,7 +1734,6 @@ static int calc_one(mld_ctx* ctx, int slot, const double* uv_dev, int64_t F, dou
         // debug mode: every feature takes the wave-cooperative kernel, which also stores the triangle corners
         Calib dbg = ctx->calib;
         dbg.threadPath = 0;
-        dbg.splitRoad = 0;
         s.d.corners = corners_dev;
         int rc = launch_features(ctx, 1, F, true, slot, &dbg);
         s.d.corners = nullptr;

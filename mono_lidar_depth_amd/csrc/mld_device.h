@@ -65,7 +65,7 @@ struct Calib {
     int bmStride;    // words per 32-pixel column of the occupancy bitmap (word = (x >> 5) * bmStride + y): H + slack
     int k1max;       // thread path: neighbour list capacity per feature (entries in LDS)
     int kMain;       // fused kernel: capacity of the narrow-window list
-    int splitRoad;   // unused (kept for layout stability of diagnostic builds)
+    int sortClasses; // k_classify: 4 = live queue ordered by neighbour-count class, then image row; 1 = by row alone
     int xcdAware;    // 1: blocks of one slot are congruent mod 8 (same XCD under round-robin dispatch)
     int threadPath;  // 1: thread-per-feature fast path with wave-cooperative overflow; 0: wave path only
 };

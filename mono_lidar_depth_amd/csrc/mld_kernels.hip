@@ -1424,6 +1424,17 @@ constexpr int kK2Max = 16;  // longest list the per-thread O(n^2) triangle searc
 #define MLD_TRI_SMALL 8
 #endif
 constexpr int kTriSmall = MLD_TRI_SMALL;
+#ifndef MLD_TRI_MID
+#define MLD_TRI_MID 12
+#endif
+#ifndef MLD_TRI_LARGE
+#define MLD_TRI_LARGE 16
+#endif
+#ifndef MLD_TRI_HUGE
+#define MLD_TRI_HUGE 24
+#endif
+constexpr int kTriMid = MLD_TRI_MID, kTriLarge = MLD_TRI_LARGE, kTriHuge = MLD_TRI_HUGE;  // tiers of the in-register
+                                                                                           // triangle search (DENSE kernel)
 #ifndef MLD_KZC
 #define MLD_KZC 12
 #endif
@@ -2008,6 +2019,7 @@ __device__ __forceinline__ void main_hist(const Calib& c, const SlotDesc& s, uin
 
 // Second half: CalculateDepthSegmented (DepthEstimator.cpp:903-1037) on the segmented list: corner selection (max
 // spanning triangle / first three points / PCA moments), planarity, ray-plane intersection, thresholds.
+template <bool DENSE>
 __device__ __forceinline__ void main_tail(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, const int ks_in,
                                           bool live, const double minZ, const double maxZ, const double myu,
                                           const double myv, int& mytype, double& mydepth, bool& overflow ST_ARG) {
@@ -2018,25 +2030,38 @@ __device__ __forceinline__ void main_tail(const Calib& c, const SlotDesc& s, uin
     for (int t = 0; t < kRecFields; t++) r[t] = 0.0;
     bool pca = false;
     if (!c.usePCA && c.useTriMax) {
-        if (live && ks > kK2Max) {
-            overflow = true;
-            live = false;
-        }
         if (live && ks < 3) {
             mytype = MLD_TriangleNotPlanarInsufficientPoints;
             live = false;
         }
+        // Corner search with the segmented points in REGISTERS, fully unrolled, sized by the longest list of the
+        // wavefront (k_classify orders the queue by neighbour count, so the lists of a wavefront are alike): one memory
+        // round trip for all points and then no load inside the O(n^2) pair loop.  Beyond kTriSmall entries that takes
+        // more registers than three wavefronts per SIMD leave (168): the DENSE instantiation of the kernel (two
+        // wavefronts per SIMD, which is all its LDS allows with long lists anyway) has tiers up to kTriHuge entries; the
+        // other one falls back to the serial loops (triangle_thread: a dependent L1 / L2 round trip per pair, ~500 cycles
+        // each - a dense 128-beam cloud spent 39 % of the kernel there).
         V3 c1, c2, c3;
-        bool ok = triangle_small<kTriSmall>(c, s, ks, live && ks <= kTriSmall, lst, lane, c1, c2, c3);
-        if (__any(live && ks > kTriSmall)) {  // rare: longer segmented lists take the generic serial loops
-            V3 d1, d2, d3;
-            bool ok2 = triangle_thread(c, s, ks, live && ks > kTriSmall, lst, lane, d1, d2, d3);
-            if (ks > kTriSmall) {
-                ok = ok2;
-                c1 = d1;
-                c2 = d2;
-                c3 = d3;
+        bool ok;
+        const int ksmax = uniform(wave_max_i32(live ? ks : 0));
+        if (!DENSE || ksmax <= kTriSmall || ksmax > kTriHuge) {
+            ok = triangle_small<kTriSmall>(c, s, ks, live && ks <= kTriSmall, lst, lane, c1, c2, c3);
+            if (ksmax > kTriSmall) {  // longer segmented lists: the generic serial loops
+                V3 d1, d2, d3;
+                bool ok2 = triangle_thread(c, s, ks, live && ks > kTriSmall, lst, lane, d1, d2, d3);
+                if (ks > kTriSmall) {
+                    ok = ok2;
+                    c1 = d1;
+                    c2 = d2;
+                    c3 = d3;
+                }
             }
+        } else if (ksmax <= kTriMid) {
+            ok = triangle_small<DENSE ? kTriMid : 1>(c, s, ks, live, lst, lane, c1, c2, c3);
+        } else if (ksmax <= kTriLarge) {
+            ok = triangle_small<DENSE ? kTriLarge : 1>(c, s, ks, live, lst, lane, c1, c2, c3);
+        } else {
+            ok = triangle_small<DENSE ? kTriHuge : 1>(c, s, ks, live, lst, lane, c1, c2, c3);
         }
         if (live && !ok) {
             mytype = MLD_TriangleNotPlanarInsufficientPoints;
@@ -2095,13 +2120,14 @@ __device__ __forceinline__ void main_tail(const Calib& c, const SlotDesc& s, uin
     ST_MARK(11);
 }
 
+template <bool DENSE>
 __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane,
                                                 const int k, bool live, const double myu, const double myv,
                                                 int& mytype, double& mydepth, bool& overflow ST_ARG) {
     int ks;
     double minZ, maxZ;
     main_hist(c, s, lst, lane, k, live, mytype, ks, minZ, maxZ ST_PASS);
-    main_tail(c, s, lst, lane, ks, live, minZ, maxZ, myu, myv, mytype, mydepth, overflow ST_PASS);
+    main_tail<DENSE>(c, s, lst, lane, ks, live, minZ, maxZ, myu, myv, mytype, mydepth, overflow ST_PASS);
 }
 
 // Wave-cooperative kernel for the features the thread kernels could not hold (lists longer than their capacities).
@@ -2300,7 +2326,8 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
     __syncthreads();
     const bool road_on = c.useRoad && s.has_plane && s.inlier_mask;
     const auto* uv = GPTR(double, s.uv);
-    const double scale = (double)kClsBuckets / (double)c.H;
+    const int rowBuckets = c.sortClasses > 1 ? kClsBuckets / 4 : kClsBuckets;
+    const double scale = (double)rowBuckets / (double)c.H;
     // occupied cells of a window, counted in the (staged) bitmap
     auto count_window = [&](int x0, int y0, int nx, int ny) -> int {
         const int cx = x0 >> 5, sh = x0 & 31;
@@ -2348,9 +2375,16 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
         }
         if ((unsigned)k1 < c.countMin) return CLS_DEAD;
         if (!c.threadPath) return CLS_OVF;
+        // Queue order: by neighbour-count class first (longest lists first), by image row inside a class.  The lanes of a
+        // wavefront of the fused kernel iterate to the longest list among them - scan rounds, key / point round trips,
+        // histogram passes, the O(n^2) corner search - so wavefronts of like features waste the fewest lane-iterations; on
+        // a dense cloud (128 beams: 2 ... 21 neighbours, mean 8) that is worth more than the row order alone.  A 64-beam
+        // cloud keeps (nearly) every feature in the first class: row order as before.
         int b = 0;
-        if (v > 0.0) b = (v < (double)c.H) ? (int)(v * scale) : kClsBuckets - 1;
-        return b < kClsBuckets ? b : kClsBuckets - 1;
+        if (v > 0.0) b = (v < (double)c.H) ? (int)(v * scale) : rowBuckets - 1;
+        b = b < rowBuckets ? b : rowBuckets - 1;
+        const int cls = (k1 <= 8) ? 0 : ((k1 <= 12) ? 1 : ((k1 <= 16) ? 2 : 3));
+        return (c.sortClasses > 1 ? (3 - cls) * rowBuckets : 0) + b;
     };
     auto settle = [&](long long i, int cls) {  // results / overflow entries of the features that are not live
         if (cls == CLS_DEAD) {
@@ -2584,8 +2618,12 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDes
 #else
 #define MLD_FUSED_ATTR
 #endif
-template <int ROAD_MODE>
-__global__ __launch_bounds__(kWave, MLD_FUSED_WAVES) MLD_FUSED_ATTR void k_feature_fused(const SlotDesc* __restrict__ slots, SlotDesc single,
+// DENSE: the instantiation for long lists (dense clouds; list capacities beyond the default): two wavefronts per SIMD -
+// all the LDS of such lists allows - and therefore up to 256 registers, which the in-register corner search of main_tail
+// uses.  The other instantiation keeps to 168 registers: three wavefronts per SIMD alone, or two beside the projection
+// wavefronts of another context (mld_set_shared_gpu).
+template <int ROAD_MODE, bool DENSE>
+__global__ __launch_bounds__(kWave, DENSE ? 2 : MLD_FUSED_WAVES) MLD_FUSED_ATTR void k_feature_fused(const SlotDesc* __restrict__ slots, SlotDesc single,
                                                          int use_single, Calib c, int n_slots, int per_slot,
                                                          uint32_t tag_all) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -2660,7 +2698,7 @@ __global__ __launch_bounds__(kWave, MLD_FUSED_WAVES) MLD_FUSED_ATTR void k_featu
             Calib cm = c;
             cm.k1max = c.kMain;
             bool ovf1 = false;
-            main_after_scan(cm, s, nl, lane, k1, live, myu, myv, mytype, mydepth, ovf1 ST_PASS);
+            main_after_scan<DENSE>(cm, s, nl, lane, k1, live, myu, myv, mytype, mydepth, ovf1 ST_PASS);
             if (live && ovf1) overflow = true;  // segmented list too long for the per-thread triangle search: wave kernel
         }
         // ---------------- road fallback (DepthEstimator.cpp:578-597) on the list already scanned ----------------

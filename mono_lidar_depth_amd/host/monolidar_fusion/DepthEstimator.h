@@ -29,6 +29,18 @@
 #include <Eigen/Geometry>
 #define MLD_HAVE_EIGEN 1
 #endif
+// The reference's own cloud and image types (DepthEstimator.h:62-63: Cloud = pcl::PointCloud<pcl::PointXYZI>;
+// RansacPlane.h:189: SemanticPlane(const cv::Mat&, Camera, ...)): used as they are when their headers are on the include
+// path, so that tracklets_depth (tracklet_depth_module.cpp:63-117, 269-284) compiles against this header unchanged.
+#if __has_include(<pcl/point_cloud.h>) && __has_include(<pcl/point_types.h>)
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+#define MLD_HAVE_PCL 1
+#endif
+#if __has_include(<opencv2/core.hpp>)
+#include <opencv2/core.hpp>
+#define MLD_HAVE_OPENCV 1
+#endif
 #endif
 
 class CameraPinhole final {
@@ -76,18 +88,24 @@ enum DepthResultType {
     SuccessRegionGrowing = 20
 };
 
+#ifdef MLD_HAVE_PCL
+// the caller's own types: 32-byte records read in place by mld_set_cloud (stride 32), `points` a contiguous vector
+using PointXYZI = pcl::PointXYZI;
+using PointCloud = pcl::PointCloud<pcl::PointXYZI>;
+#else
 // pcl::PointXYZI memory layout (8 floats, 32 bytes): x,y,z,pad, intensity,pad,pad,pad.
 struct alignas(16) PointXYZI {
     float x, y, z, pad0_;
     float intensity, pad1_, pad2_, pad3_;
 };
-static_assert(sizeof(PointXYZI) == 32, "PointXYZI must match pcl::PointXYZI");
 
 struct PointCloud {
     using Ptr = std::shared_ptr<PointCloud>;
     using ConstPtr = std::shared_ptr<const PointCloud>;
     std::vector<PointXYZI> points;
 };
+#endif
+static_assert(sizeof(PointXYZI) == 32, "PointXYZI must match pcl::PointXYZI");
 
 class DepthEstimatorParameters : public mld_params {
 public:
@@ -160,11 +178,20 @@ public:
         materialize();
         return _inliersIndex;
     }
+    // RansacPlane.h:116-122: a std::map<int, bool> lookup in the reference; here a bitmask over the point indices,
+    // built on the first call for the current inlier list (O(1) per call afterwards)
     bool CheckPointInPlane(const int index) const {
         materialize();
-        for (int i : _inliersIndex)
-            if (i == index) return true;
-        return false;
+        if (_lookupSize != _inliersIndex.size() || _lookupData != _inliersIndex.data()) {
+            int mx = -1;
+            for (int i : _inliersIndex) mx = i > mx ? i : mx;
+            _lookup.assign((size_t)(mx + 1 + 63) / 64, 0ull);
+            for (int i : _inliersIndex)
+                if (i >= 0) _lookup[(size_t)i >> 6] |= 1ull << (i & 63);
+            _lookupSize = _inliersIndex.size();
+            _lookupData = _inliersIndex.data();
+        }
+        return index >= 0 && ((size_t)index >> 6) < _lookup.size() && ((_lookup[(size_t)index >> 6] >> (index & 63)) & 1ull);
     }
     // A plane estimated on the GPU keeps its inlier set there (a bitmask the kernels read); the index list of
     // getInlinersIndex (RansacPlane.h:100-103) is fetched when somebody asks for it - or when the frame slot that holds
@@ -172,9 +199,16 @@ public:
     virtual void materialize() const {}
 
 protected:
+    // a subclass that rewrites _inliersIndex in place (same size, same storage) calls this
+    void inliersChanged() const { _lookupData = nullptr; }
     bool is_segmented_ = false;
     std::array<float, 4> _modelCoeffs{{0, 0, 0, 0}};
     mutable std::vector<int> _inliersIndex;
+
+private:
+    mutable std::vector<uint64_t> _lookup;  // CheckPointInPlane's bitmask of _inliersIndex
+    mutable size_t _lookupSize = ~(size_t)0;
+    mutable const int* _lookupData = nullptr;
 };
 
 // RansacPlane (RansacPlane.h:129-170): a GroundPlane that DepthEstimator::setInputCloud estimates on the GPU while it
@@ -221,15 +255,44 @@ private:
 class SemanticPlane : public RansacPlane {
 public:
     using Ptr = std::shared_ptr<SemanticPlane>;
+    // SemanticPlane::Camera (RansacPlane.h:177-188).  The GPU estimator projects with the DepthEstimator's own
+    // calibration - which is what the reference's caller puts here (tracklet_depth_module.cpp:273-277: the same camera
+    // info and the same _camLidarTransform it initialises the estimator with); a Camera that differs from it is refused
+    // when the plane is estimated (DepthEstimator::checkSemanticCamera).
+    struct Camera {
+        double f = 0, cu = 0, cv = 0;
+#ifdef MLD_HAVE_EIGEN
+        Eigen::Affine3d transform_cam_lidar;
+#else
+        std::array<double, 12> transform_cam_lidar{};  // row-major 3x4
+#endif
+    };
     SemanticPlane(const uint8_t* img, int rows, int cols, int row_stride_bytes, std::set<int> groundplane_label,
                   double inlier_threshold)
             : rows_(rows), cols_(cols), groundplane_label_(groundplane_label.begin(), groundplane_label.end()),
               inlier_threshold_(inlier_threshold) {
-        semantic_image_.resize((size_t)rows * (size_t)cols);
-        for (int r = 0; r < rows; r++)
-            std::copy(img + (size_t)r * row_stride_bytes, img + (size_t)r * row_stride_bytes + cols,
-                      semantic_image_.begin() + (size_t)r * cols);
+        copyImage(img, rows, cols, row_stride_bytes);
     }
+    SemanticPlane(const uint8_t* img, int rows, int cols, int row_stride_bytes, Camera cam, std::set<int> groundplane_label,
+                  double inlier_threshold)
+            : SemanticPlane(img, rows, cols, row_stride_bytes, std::move(groundplane_label), inlier_threshold) {
+        cam_ = cam;
+        has_cam_ = true;
+    }
+#ifdef MLD_HAVE_OPENCV
+    // the reference's constructor (RansacPlane.h:189): an 8-bit single-channel label image, copied like its
+    // std::make_unique<cv::Mat>(img)
+    explicit SemanticPlane(const cv::Mat& img, Camera cam, std::set<int> groundplane_label, double inlier_threshold)
+            : rows_(img.rows), cols_(img.cols), groundplane_label_(groundplane_label.begin(), groundplane_label.end()),
+              inlier_threshold_(inlier_threshold), cam_(cam), has_cam_(true) {
+        if (img.type() != CV_8UC1) throw std::runtime_error("SemanticPlane: the label image must be CV_8UC1 (MONO8)");
+        semantic_image_.resize((size_t)rows_ * (size_t)cols_);
+        for (int r = 0; r < rows_; r++)
+            std::copy(img.ptr<uint8_t>(r), img.ptr<uint8_t>(r) + cols_, semantic_image_.begin() + (size_t)r * cols_);
+    }
+#endif
+    bool hasCamera() const { return has_cam_; }
+    const Camera& camera() const { return cam_; }
     const std::vector<uint8_t>& image() const { return semantic_image_; }
     int rows() const { return rows_; }
     int cols() const { return cols_; }
@@ -237,10 +300,18 @@ public:
     double inlierThreshold() const { return inlier_threshold_; }
 
 private:
+    void copyImage(const uint8_t* img, int rows, int cols, int row_stride_bytes) {
+        semantic_image_.resize((size_t)rows * (size_t)cols);
+        for (int r = 0; r < rows; r++)
+            std::copy(img + (size_t)r * row_stride_bytes, img + (size_t)r * row_stride_bytes + cols,
+                      semantic_image_.begin() + (size_t)r * cols);
+    }
     std::vector<uint8_t> semantic_image_;
     int rows_, cols_;
     std::vector<int> groundplane_label_{6, 7, 8, 9};
     double inlier_threshold_{0.1};
+    Camera cam_;
+    bool has_cam_ = false;
 };
 
 class DepthEstimator {
@@ -361,11 +432,24 @@ public:
         static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
         if (road && !groundPlane->isSegmented()) {
             if (!rp) {  // a foreign GroundPlane subclass estimates itself on the CPU
-                groundPlane->CalculateInliersPlane(cloud, _parameters->ransac_plane_min_z, _parameters->ransac_plane_max_z);
+                try {
+                    groundPlane->CalculateInliersPlane(cloud, _parameters->ransac_plane_min_z, _parameters->ransac_plane_max_z);
+                } catch (const GroundPlane::ExceptionPclInvalid&) {
+                    // the reference's two try blocks (tracklet_depth_module.cpp:318-347): the previous frame's features
+                    // are answered all the same - the frame runs without a plane -, the current ones are invalid
+                    const int rc0 = mld_tracklets_frame(_ctx, slot_cur, slot_last, cloud->points.data(), (int64_t)cloud->points.size(),
+                                                        (int)sizeof(PointXYZI), nullptr, nullptr, nullptr, 0, u_new, v_new, u_old,
+                                                        v_old, is_new, n_tracks, d_cur, d_last, nullptr, nullptr, nullptr, nullptr);
+                    noteCloud(cloud);
+                    for (int64_t i = 0; i < n_tracks; i++) d_cur[i] = -1.f;
+                    if (rc0 != MLD_OK && rc0 != MLD_ERR_CLOUD_TOO_SMALL) check(rc0);
+                    throw;
+                }
             } else {
                 rq.kind = MLD_PLANE_RANSAC;
                 rq.seed = rp->seed;
                 if (auto* sp = dynamic_cast<SemanticPlane*>(rp)) {
+                    checkSemanticCamera(*sp);
                     rq.kind = MLD_PLANE_SEMANTIC;
                     rq.label_image = sp->image().data();
                     rq.rows = sp->rows();
@@ -639,6 +723,7 @@ private:
         rq.seed = rp.seed;
         static_assert(sizeof(int) == sizeof(int32_t), "int must be 32 bit");
         if (auto* sp = dynamic_cast<SemanticPlane*>(&rp)) {
+            checkSemanticCamera(*sp);
             rq.kind = MLD_PLANE_SEMANTIC;
             rq.label_image = sp->image().data();
             rq.rows = sp->rows();
@@ -665,6 +750,25 @@ private:
         });
         if ((size_t)slot < _lazyPlane.size()) _lazyPlane[(size_t)slot] = owner;
         _installedPlane = &rp;
+    }
+    // SemanticPlane::Camera must be the estimator's calibration: the GPU estimator projects with that one
+    void checkSemanticCamera(const SemanticPlane& sp) const {
+        if (!sp.hasCamera()) return;
+        const mld_camera cam = _camera->asStruct();
+        const SemanticPlane::Camera& c = sp.camera();
+        bool same = c.f == cam.focal_length && c.cu == cam.principal_point_x && c.cv == cam.principal_point_y;
+        for (int r = 0; r < 3 && same; r++)
+            for (int k = 0; k < 4; k++) {
+#ifdef MLD_HAVE_EIGEN
+                const double v = c.transform_cam_lidar.matrix()(r, k);
+#else
+                const double v = c.transform_cam_lidar[(size_t)(r * 4 + k)];
+#endif
+                same = same && v == _transform[(size_t)(r * 4 + k)];
+            }
+        if (!same)
+            throw std::runtime_error("SemanticPlane::Camera differs from the calibration the DepthEstimator was initialised "
+                                     "with: the GPU plane estimator projects with the estimator's own (unsupported)");
     }
     // a plane whose inlier list still lives in `slot` gets it now: the slot's mask is about to be overwritten
     void flushLazyPlane(int slot) {

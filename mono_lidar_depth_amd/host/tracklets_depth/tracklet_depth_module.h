@@ -113,8 +113,9 @@ public:
             _depthEstimator.trackletsFrame(cloud_in, gp, slot_cur, slot_last, u_new.data(), v_new.data(), u_old.data(),
                                            v_old.data(), is_new.data(), n, d_cur.data(), d_last.data());
         } catch (const Mono_Lidar::GroundPlane::ExceptionPclInvalid&) {
-            // :337-347  current frame continues with invalid depths (the call has left -1 there and answered the previous
-            // frame's features), plane and cloud are forgotten
+            // :337-347  current frame continues with invalid depths (trackletsFrame has left -1 there and answered the
+            // previous frame's features - whether the GPU estimator or a foreign plane's CPU estimator threw), plane and
+            // cloud are forgotten
             cur_ok = false;
             gp = nullptr;
         }

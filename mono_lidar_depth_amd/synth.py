@@ -127,6 +127,43 @@ def make_features_near_points(cloud: np.ndarray, n: int, seed: int = 0, jitter_u
     return np.ascontiguousarray(uv, dtype=np.float64)
 
 
+def make_features_k_neighbours(cloud: np.ndarray, n: int, seed: int = 0, min_neighbours: int = 6,
+                               window=(6, 9), width: int = KITTI_W, height: int = KITTI_H) -> np.ndarray:
+    """[F, 2] float64 features on (sub-pixel jittered) image positions of LiDAR returns whose search window - `window` =
+    (pixelarea_search_witdh, pixelarea_search_height), NeighborFinderPixel.cpp:67-88 - holds at least `min_neighbours`
+    returns: BASELINE config 2 "at its stated neighbour count" (k = 7; a uniformly random feature sees 2-3 on a 64 x 2048
+    scan, and 40 % of them none).  The pixel occupancy is computed here with the path's own rule (first point per pixel,
+    z > 0, strict image bounds)."""
+    rng = np.random.default_rng(99000 + seed)
+    xyz = cloud[:, :3].astype(np.float64)
+    cam = xyz @ T_CAM_LIDAR[:, :3].T + T_CAM_LIDAR[:, 3]
+    with np.errstate(all="ignore"):
+        u = (KITTI_F * cam[:, 0] + KITTI_CU * cam[:, 2]) / cam[:, 2]
+        v = (KITTI_F * cam[:, 1] + KITTI_CV * cam[:, 2]) / cam[:, 2]
+        vis = np.nonzero((cam[:, 2] > 0) & (u > 0) & (u < width) & (v > 0) & (v < height))[0]
+    if vis.size == 0:
+        return make_features(n, seed, width=width, height=height)
+    xi, yi = u[vis].astype(np.int64), v[vis].astype(np.int64)
+    occ = np.zeros((height, width), dtype=np.int64)
+    occ[yi, xi] = 1
+    ii = np.zeros((height + 1, width + 1), dtype=np.int64)
+    ii[1:, 1:] = occ.cumsum(0).cumsum(1)
+    hx, hy = 0.5 * window[0], 0.5 * window[1]
+    # candidate features: every return's own pixel at a random sub-pixel position; the window of THAT position is counted
+    # (bounds exactly as NeighborFinderPixel.cpp:67-76: clamped doubles, truncation)
+    fu, fv = xi + rng.uniform(0.05, 0.95, xi.size), yi + rng.uniform(0.05, 0.95, yi.size)
+    x0 = np.maximum(fu - hx, 0.0).astype(np.int64)
+    x1 = np.minimum(fu + hx, width - 1.0).astype(np.int64)
+    y0 = np.maximum(fv - hy, 0.0).astype(np.int64)
+    y1 = np.minimum(fv + hy, height - 1.0).astype(np.int64)
+    k = ii[y1 + 1, x1 + 1] - ii[y0, x1 + 1] - ii[y1 + 1, x0] + ii[y0, x0]
+    good = np.nonzero(k >= min_neighbours)[0]
+    if good.size == 0:
+        good = np.arange(vis.size)
+    pick = rng.choice(good, n, replace=True)
+    return np.ascontiguousarray(np.stack([fu[pick], fv[pick]], axis=1), dtype=np.float64)
+
+
 def make_ground_plane(cloud: np.ndarray, subsample: int = 0, seed: int = 0):
     """Analytic plane of the scene in the lidar frame (0,0,1,1.73) + inliers |z + 1.73| < 0.3."""
     z = cloud[:, 2]

@@ -32,16 +32,20 @@ def _native_built():
     yield
 
 
-@pytest.fixture(params=["default", "fused", "wave-only"])
+@pytest.fixture(params=["default", "fused", "wave-only", "dense"])
 def feature_kernel_path(request, monkeypatch):
-    """Every test runs three ways:
+    """Every test runs four ways:
     default     the shipped library (libmld_hip.so): batches on k_classify + k_feature_fused (+ k_feature_wave for long
                 lists), single frames of up to 16 384 features on the wave-cooperative kernel
     fused       the lane-per-feature kernel for single frames as well: the test build of the same sources
                 (libmld_hip_ab.so, -DMLD_AB_SWITCHES) with MLD_FORCE_THREAD_PATH=1, read by its mld_create
-    wave-only   every feature, batches included, through the wave-cooperative kernel (MLD_FORCE_WAVE_PATH=1)"""
+    wave-only   every feature, batches included, through the wave-cooperative kernel (MLD_FORCE_WAVE_PATH=1)
+    dense       as "fused" with the list capacities of a dense cloud (MLD_K1MAX=48): the DENSE instantiation of the
+                lane-per-feature kernel (two wavefronts per SIMD, in-register corner search up to 24 points)"""
     if request.param != "default":
         monkeypatch.setenv("MLD_FORCE_WAVE_PATH" if request.param == "wave-only" else "MLD_FORCE_THREAD_PATH", "1")
+        if request.param == "dense":
+            monkeypatch.setenv("MLD_K1MAX", "48")
         from mono_lidar_depth_amd import capi
         monkeypatch.setattr(capi, "_lib", capi.load_ab())
     yield request.param
