@@ -138,7 +138,9 @@ typedef struct mld_params {
 void mld_params_default(mld_params* p);
 /* "C0": monolidar_fusion/parameters.yaml with do_use_depth_segmentation: 0. */
 void mld_params_c0(mld_params* p);
-/* DepthEstimatorParameters::fromFile (DepthEstimatorParameters.cpp:16-114): `key: value` YAML subset. */
+/* DepthEstimatorParameters::fromFile (DepthEstimatorParameters.cpp:16-114): `key: value` YAML subset, cv::FileStorage
+ * semantics: an absent key reads as 0, `(int)node` rounds to nearest (saturating here).  On failure `err` holds the
+ * reason; on success it holds a note listing the mirrored keys the file lacks ("absent (read as 0): a, b", or ""). */
 int mld_params_from_file(mld_params* p, const char* path, char* err, int err_len);
 
 typedef struct mld_ctx mld_ctx;

@@ -260,8 +260,11 @@ def params_default() -> MldParams:
 
 def params_from_file(path: str) -> MldParams:
     p = MldParams()
-    err = C.create_string_buffer(512)
-    rc = load().mld_params_from_file(C.byref(p), str(path).encode(), err, 512)
+    err = C.create_string_buffer(2048)
+    rc = load().mld_params_from_file(C.byref(p), str(path).encode(), err, 2048)
     if rc != MLD_OK:
         raise RuntimeError(err.value.decode())
+    # mirrored keys the file lacks (they read as 0, as cv::FileStorage reads them in the reference)
+    note = err.value.decode()
+    p.absent_keys = [k.strip() for k in note.split(":", 1)[1].split(",")] if note.startswith("absent") else []
     return p

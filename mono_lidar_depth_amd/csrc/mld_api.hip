@@ -219,6 +219,8 @@ struct mld_ctx {
     const uint32_t* gate_counter = nullptr;  // the counter / value this context's next projection waits for (k_gate)
     uint32_t gate_target = 0;
     bool gate_mode = true;              //   hand over through k_gate (a polling wavefront) instead of a cross-stream event
+    Calib* d_calib = nullptr;      // device copy of `calib` for k_feature_fused (fields fetched where they are used)
+    Calib calib_uploaded{};         //   what that copy holds
     mld_ctx* gate_src = nullptr;        //   the context whose cls_done this context's pending gate reads (its gate_waiter is this one)
     mld_ctx* gate_waiter = nullptr;     //   the context whose pending gate reads cls_done (either may be destroyed first)    //   order_ev is recorded; the next projection launch of this context waits for it
     // mld_pair_contexts: the batched projections of two contexts share ONE stream (back to back, no cross-stream
@@ -688,6 +690,8 @@ int ensure_queues(mld_ctx* ctx, Slot& s, int64_t F) {
     return MLD_OK;
 }
 
+int upload_descs(mld_ctx* ctx, int n_slots, hipStream_t st = nullptr, int first = 0, bool tags_in_descs = false);
+
 // k_classify (per slot) -> k_feature_fused over the live queues -> k_feature_wave over the overflow queues.
 // k_classify sets both queue lengths, so no counter needs clearing.
 int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int slot, const Calib* override_calib = nullptr) {
@@ -750,6 +754,7 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         w->gate_counter = nullptr;
         w->order_wait_pending = true;
     }
+    int rc_up = MLD_OK;
     if (calib.threadPath) {
         ScopedTimer tm(ctx, 1);
         // long lists (mld_set_list_capacity beyond the default 32 / 24: dense clouds) take the DENSE instantiation - two
@@ -758,8 +763,17 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         const bool dense = !(ctx->shared_arg & 1) && (calib.k1max > 32 || calib.kMain > 24);
         auto kf = dense ? (calib.roadMode ? mld::k_feature_fused<1, true> : mld::k_feature_fused<0, true>)
                         : (calib.roadMode ? mld::k_feature_fused<1, false> : mld::k_feature_fused<0, false>);
-        hipLaunchKernelGGL(kf, dim3((unsigned)per_slot * (unsigned)ns), dim3(kWave), ctx->lds_fused + ctx->lds_fused_pad, ctx->stream, ctx->d_slots,
-                           one, use_single, calib, ns, per_slot, tag_all);
+        // the kernel reads its slot descriptors in device memory (a single-slot call - the lane-per-feature kernel runs
+        // for one frame in the test routes only - uploads that slot's first; batches have theirs in place, tags included:
+        // the kernel never needs the map tag)
+        if (single && (rc_up = upload_descs(ctx, 1, nullptr, slot, true))) return rc_up;
+        // ... and the per-context constants (uploaded when they change: creation, mld_set_list_capacity)
+        if (std::memcmp(&calib, &ctx->calib_uploaded, sizeof(Calib)) != 0) {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_calib, &calib, sizeof(Calib), hipMemcpyHostToDevice, ctx->stream));  // (pageable: staged before the call returns)
+            ctx->calib_uploaded = calib;
+        }
+        hipLaunchKernelGGL(kf, dim3((unsigned)per_slot * (unsigned)ns), dim3(kWave), ctx->lds_fused + ctx->lds_fused_pad, ctx->stream,
+                           ctx->d_slots + (single ? slot : 0), ctx->d_calib, ns, per_slot);
     }
     {
         ScopedTimer tm(ctx, 3);
@@ -769,14 +783,15 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         const int chunk = few ? (int)std::min<int64_t>(8, std::max<int64_t>(1, (max_F + 8191) / 8192)) : 8;
         const int want = (int)((max_F + chunk - 1) / chunk);
         const int pw = std::max(1, std::min(want, std::max(4, (few ? 16384 : 4096) / ns)));
-        hipLaunchKernelGGL(k_feature_wave, dim3((unsigned)pw * (unsigned)ns), dim3(kWave), ctx->lds_bytes, ctx->stream,
-                           ctx->d_slots, one, use_single, calib, ns, pw, tag_all, chunk, few ? 1 : 0);
+        auto kw = few ? mld::k_feature_wave<true> : mld::k_feature_wave<false>;
+        hipLaunchKernelGGL(kw, dim3((unsigned)pw * (unsigned)ns), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots, one,
+                           use_single, calib, ns, pw, tag_all, chunk);
     }
     HIP_TRY(ctx, hipGetLastError());
     return MLD_OK;
 }
 
-int upload_descs(mld_ctx* ctx, int n_slots, hipStream_t st = nullptr, int first = 0, bool tags_in_descs = false) {
+int upload_descs(mld_ctx* ctx, int n_slots, hipStream_t st, int first, bool tags_in_descs) {
     if (!st) st = ctx->stream;
     // Steady-state batches (same buffers every step) change nothing but the map tags, and a tag common to the
     // batch travels as a kernel argument: skip the upload when the device copy is still right.
@@ -953,8 +968,11 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
         return hip_bail(e, "hipStreamCreate");
     if (ctx->lds_bytes > 48 * 1024) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_feature_wave), hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_feature_wave<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ctx->lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_feature_wave<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes);
         if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute(k_feature_wave)");
     }
     if (ctx->lds_classify > 48 * 1024) {
@@ -978,6 +996,8 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if ((e = hipMalloc((void**)&ctx->d_slots, sizeof(SlotDesc) * max_frames)) != hipSuccess)
         return hip_bail(e, "hipMalloc(slots)");
     if ((e = hipMalloc((void**)&ctx->dummy, 256)) != hipSuccess) return hip_bail(e, "hipMalloc(dummy)");
+    if ((e = hipMalloc((void**)&ctx->d_calib, sizeof(Calib))) != hipSuccess) return hip_bail(e, "hipMalloc(calib)");
+    std::memset(&ctx->calib_uploaded, 0xFF, sizeof(Calib));  // (nothing uploaded yet)
     if ((e = hipMemsetAsync(ctx->dummy, 0, 256, ctx->stream)) != hipSuccess) return hip_bail(e, "hipMemset(dummy)");
     size_t cells = (size_t)camera->width * camera->height + kMapPadCells;
     ctx->bitmap_words = (size_t)ctx->calib.bmStride * (size_t)((camera->width + 31) / 32 + 1) + 4;  // + a slack column
@@ -1050,6 +1070,7 @@ void mld_destroy(mld_ctx* ctx) {
     if (ctx->queue_slab) (void)hipFree(ctx->queue_slab);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->dummy) (void)hipFree(ctx->dummy);
+    if (ctx->d_calib) (void)hipFree(ctx->d_calib);
     if (ctx->queue_counts) (void)hipFree(ctx->queue_counts);  // also holds the bitmaps
     void* rsp[] = {ctx->rs_flags, ctx->rs_cand, ctx->rs_block, ctx->rs_M, ctx->rs_S, ctx->rs_sample, ctx->rs_sp,
                    ctx->rs_counts, ctx->rs_inl, ctx->rs_res, ctx->sem_img, ctx->sem_coeffs, ctx->sem_res, ctx->sem_groups};

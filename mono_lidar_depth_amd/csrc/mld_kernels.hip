@@ -1449,9 +1449,22 @@ typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 #define LST(e) lst[(e) * kWave + lane]
 
-__device__ __forceinline__ V3 cam_point(const Calib& c, const SlotDesc& s, uint32_t orig) {
+// The lane-per-feature kernel's view of a frame slot: the descriptor stays in device memory and a field is fetched - a
+// scalar load, the address is wave-uniform - where it is used, instead of all 50 scalar registers' worth of it being
+// loaded up front and carried (or spilled to vector lanes) across the whole kernel.
+struct SlotRef {
+    const SlotDesc& g;
+    const double* plane;  // prior_n[3], prior_off, coeffs[4] (floats): the descriptor's, or the device-estimated plane's
+                          // (PlaneDev starts with the same layout)
+    int has_plane;
+};
+static_assert(offsetof(SlotDesc, prior_off) == offsetof(SlotDesc, prior_n) + 24 && offsetof(SlotDesc, coeffs) == offsetof(SlotDesc, prior_n) + 32 &&
+                  offsetof(PlaneDev, prior_n) == 0 && offsetof(PlaneDev, prior_off) == 24 && offsetof(PlaneDev, coeffs) == 32,
+              "SlotRef::plane reads the prior and the coefficients through one pointer");
+
+__device__ __forceinline__ V3 cam_point(const Calib& c, const SlotRef& s, uint32_t orig) {
     double x, y, z;
-    load_point(s, (long long)orig, x, y, z);
+    load_point(s.g, (long long)orig, x, y, z);
     return lidar_to_cam(c, x, y, z);
 }
 
@@ -1461,11 +1474,12 @@ __device__ __forceinline__ V3 cam_point(const Calib& c, const SlotDesc& s, uint3
 struct RawP {
     float x, y, z;
 };
-__device__ __forceinline__ RawP load_raw(const SlotDesc& s, uint32_t i) {
+__device__ __forceinline__ RawP load_raw(const SlotRef& s, uint32_t i) {
     MLD_DIAG_FAKE_POINT(i);
-    const unsigned char* p = s.cloud + (size_t)i * (size_t)s.stride;
+    const unsigned char* cl = s.g.cloud;
+    const unsigned char* p = cl + (size_t)i * (size_t)s.g.stride;
     RawP r;
-    if ((((size_t)s.cloud) & 15) == 0) {
+    if ((((size_t)cl) & 15) == 0) {
         f32x4 q = *GPTR(f32x4, p);
         r.x = q.x;
         r.y = q.y;
@@ -1481,15 +1495,26 @@ __device__ __forceinline__ double raw_z(const Calib& c, RawP r) {
     return c.T[11] + ((c.T[8] * (double)r.x + c.T[9] * (double)r.y) + c.T[10] * (double)r.z);
 }
 __device__ __forceinline__ V3 raw_point(const Calib& c, RawP r) { return lidar_to_cam(c, (double)r.x, (double)r.y, (double)r.z); }
+// The same transform with fused multiply-adds (9 instructions instead of 18): for the road estimators only, which answer
+// to the 1e-4 m tolerance (their sums are re-associated anyway); the result differs from raw_point's by an ulp.
+__device__ __forceinline__ V3 raw_point_fma(const Calib& c, RawP r) {
+    const double x = (double)r.x, y = (double)r.y, z = (double)r.z;
+    V3 o;
+    o.x = fma(c.T[2], z, fma(c.T[1], y, fma(c.T[0], x, c.T[3])));
+    o.y = fma(c.T[6], z, fma(c.T[5], y, fma(c.T[4], x, c.T[7])));
+    o.z = fma(c.T[10], z, fma(c.T[9], y, fma(c.T[8], x, c.T[11])));
+    return o;
+}
 // list entry e of this lane, or 0 (a valid point index whenever any list is non-empty) beyond the list end
-#define LST_ID(e, n) (((e) < (n)) ? (LST(min((e), c.k1max - 1)) & kIdxMask) : 0u)
+// (lcap: capacity of the list `lst` addresses - the wide list's c.k1max or the narrow list's c.kMain)
+#define LST_ID(e, n) (((e) < (n)) ? (LST(min((e), lcap - 1)) & kIdxMask) : 0u)
 
 // Max-spanning triangle for lists of at most M entries, fully unrolled: all M points are fetched in one batch and
 // kept in registers, pairs are visited in the reference's (i,j) order with strict '>' (first maximal pair wins),
 // then the third corner over k < n-1.  One memory round trip instead of one per pair.
 template <int M>
-__device__ __forceinline__ bool triangle_small(const Calib& c, const SlotDesc& s, int n, bool want, const uint32_t* lst,
-                                               int lane, V3& c1, V3& c2, V3& c3) {
+__device__ __forceinline__ bool triangle_small(const Calib& c, const SlotRef& s, int n, bool want, const uint32_t* lst,
+                                               int lane, const int lcap, V3& c1, V3& c2, V3& c3) {
     const int nn = want ? n : 0;
     RawP rp[M];
 #pragma unroll
@@ -1545,7 +1570,7 @@ __device__ __forceinline__ bool triangle_small(const Calib& c, const SlotDesc& s
 
 // Max-spanning triangle over the thread's list entries [0, n) (PlaneEstimationCalcMaxSpanningTriangle.cpp:37-100),
 // serial loops, n <= kK2Max.  The wave iterates to the longest list; shorter lanes idle.
-__device__ __forceinline__ bool triangle_thread(const Calib& c, const SlotDesc& s, int n, bool want, const uint32_t* lst, int lane, V3& c1,
+__device__ __forceinline__ bool triangle_thread(const Calib& c, const SlotRef& s, int n, bool want, const uint32_t* lst, int lane, V3& c1,
                                 V3& c2, V3& c3) {
     bool act = want && n >= 3;
     int i = 0, j = 1, bi = -1, bj = -1;
@@ -1626,12 +1651,13 @@ __device__ __forceinline__ void enqueue_features(int32_t* queue, int32_t* count,
 // ROAD_MODE: 0 = M-estimator, 1 = max-spanning triangle, -1 = decided at run time (c.roadMode).
 // The road fallback once the wide-window list (k2 entries, original point indices in the low 24 bits) is in `lst`.
 template <int ROAD_MODE>
-__device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, bool cand,
+__device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s, uint32_t* lst, const int lane, bool cand,
                                                 const int k2, const uint32_t list_states, const double myu,
                                                 const double myv, int& mytype,
                                                 double& mydepth, bool& overflow ST_ARG) {
     const int roadMode = ROAD_MODE >= 0 ? ROAD_MODE : c.roadMode;
     const int resultOld = mytype;
+    const int lcap = c.k1max;  // `lst` is the wide list
     if (cand && k2 > c.k1max) {
         overflow = true;
         cand = false;
@@ -1653,15 +1679,19 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
     // reciprocal estimates + Newton steps (road tolerance)
     double sw = 0, mx = 0, my = 0, mz = 0;
     double q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
-    const V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
+    const auto* pl = GPTR(double, s.plane);
+    const V3 pn = {pl[0], pl[1], pl[2]};
+    const double prior_off = pl[3];
     // one inlier of the plane: depth / lateral extent of the set and West's update of the weighted mean and scatter
     auto add_inlier = [&](const V3 p) {
-        if (p.z < zmn) zmn = p.z;
-        if (p.z > zmx) zmx = p.z;
-        if (p.x < xmn) xmn = p.x;
-        if (p.x > xmx) xmx = p.x;
+        zmn = fmin(zmn, p.z);  // (a NaN coordinate leaves the extremes alone, as `if (p.z < zmn)` does)
+        zmx = fmax(zmx, p.z);
+        if (roadMode != 0) {   // the lateral extent is the triangle estimator's (LinePlaneIntersectionCeckXZTreshold)
+            xmn = fmin(xmn, p.x);
+            xmx = fmax(xmx, p.x);
+        }
         if (roadMode == 0) {
-            const double w = fast_rcp(fabs(vdot(pn, p) + s.prior_off));  // PlaneEstimationMEstimator.cpp:32
+            const double w = fast_rcp(fabs(fma(pn.x, p.x, fma(pn.y, p.y, fma(pn.z, p.z, prior_off)))));  // PlaneEstimationMEstimator.cpp:32
             const double swn = sw + w;
             const double r = w * fast_rcp(swn);
             const double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
@@ -1685,7 +1715,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
     // that holds an "unsure" entry (|distance - threshold| within the projection's single-precision margin) takes the
     // general loop below.
     bool by_state = false;
-    if (s.mask_in_key) {
+    if (s.g.mask_in_key) {
         // (what the scan saw in the lane's keys: scan_window_flagged)
         far = n2 > 0 && (list_states & 1u);
         by_state = !wave_any(n2 > 0 && (list_states & 2u));
@@ -1714,7 +1744,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
             for (int q = 0; q < kRoadBatch; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ni));
 #pragma unroll
             for (int q = 0; q < kRoadBatch; q++)
-                if (e0 + q < ni) add_inlier(raw_point(c, rp[q]));
+                if (e0 + q < ni) add_inlier(raw_point_fma(c, rp[q]));
         }
     } else {
     const int n2max = uniform(wave_max_i32(n2));
@@ -1726,7 +1756,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
             const uint32_t ent = (e0 + q < n2) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
             ids[q] = ent & kIdxMask;
             rp[q] = load_raw(s, ids[q]);
-            mw[q] = GPTR(uint32_t, s.inlier_mask)[ids[q] >> 5];
+            mw[q] = GPTR(uint32_t, s.g.inlier_mask)[ids[q] >> 5];
         }
 #pragma unroll
         for (int q = 0; q < kRoadBatch; q++) {
@@ -1737,7 +1767,8 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
             double yl = c.Tinv[7] + (c.Tinv[4] * p.x + (c.Tinv[5] * p.y + c.Tinv[6] * p.z));
             double zl = c.Tinv[11] + (c.Tinv[8] * p.x + (c.Tinv[9] * p.y + c.Tinv[10] * p.z));
             float xf = (float)xl, yf = (float)yl, zf = (float)zl;
-            float d = fabsf(s.coeffs[0] * xf + s.coeffs[1] * yf + s.coeffs[2] * zf + s.coeffs[3]);
+            const auto* co = GPTR(float, s.plane + 4);
+            float d = fabsf(co[0] * xf + co[1] * yf + co[2] * zf + co[3]);
             far = far || ((double)d > c.roadDistThr);
             bool inl = (mw[q] >> (id & 31)) & 1u;
             if (inl) {
@@ -1775,7 +1806,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
             cand = false;
         }
         V3 c1, c2, c3;
-        bool ok = triangle_small<kTriSmall>(c, s, kk, cand && kk <= kTriSmall, lst, lane, c1, c2, c3);
+        bool ok = triangle_small<kTriSmall>(c, s, kk, cand && kk <= kTriSmall, lst, lane, lcap, c1, c2, c3);
         if (__any(cand && kk > kTriSmall)) {
             V3 d1, d2, d3;
             bool ok2 = triangle_thread(c, s, kk, cand && kk > kTriSmall, lst, lane, d1, d2, d3);
@@ -1812,8 +1843,8 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotDesc& 
 // First half: depth segmentation of the lane's neighbour list (DepthEstimator.cpp:726-780).  On return the list holds
 // the segmented points (ks entries, reference order) and minZ / maxZ their depth range; a failed histogram sets
 // mytype = HistogramNoLocalMax and clears `live`.
-__device__ __forceinline__ void main_hist(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, const int k,
-                                          bool& live, int& mytype, int& ks, double& minZ, double& maxZ ST_ARG) {
+__device__ __forceinline__ void main_hist(const Calib& c, const SlotRef& s, uint32_t* lst, const int lane, const int lcap,
+                                          const int k, bool& live, int& mytype, int& ks, double& minZ, double& maxZ ST_ARG) {
     ks = live ? k : 0;
     minZ = 1.7976931348623157e308;
     maxZ = -1.7976931348623157e308;
@@ -1926,7 +1957,7 @@ __device__ __forceinline__ void main_hist(const Calib& c, const SlotDesc& s, uin
                     for (int e = kZc; e < kmax; e += 4) {
                         uint32_t vv[4];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) vv[q] = LST(min(e + q, c.k1max - 1));
+                        for (int q = 0; q < 4; q++) vv[q] = LST(min(e + q, lcap - 1));
 #pragma unroll
                         for (int q = 0; q < 4; q++)
                             cnt += ((e + q < ks) && ((vv[q] >> kIdxBits) == (uint32_t)irel)) ? 1 : 0;
@@ -1971,7 +2002,7 @@ __device__ __forceinline__ void main_hist(const Calib& c, const SlotDesc& s, uin
             uint32_t packed[kBatch];
 #pragma unroll
             for (int q = 0; q < kBatch; q++) {
-                packed[q] = (e0 + q < ks) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
+                packed[q] = (e0 + q < ks) ? LST(min(e0 + q, lcap - 1)) : 0u;
                 rp[q] = load_raw(s, packed[q] & kIdxMask);
             }
 #pragma unroll
@@ -2020,7 +2051,8 @@ __device__ __forceinline__ void main_hist(const Calib& c, const SlotDesc& s, uin
 // Second half: CalculateDepthSegmented (DepthEstimator.cpp:903-1037) on the segmented list: corner selection (max
 // spanning triangle / first three points / PCA moments), planarity, ray-plane intersection, thresholds.
 template <bool DENSE>
-__device__ __forceinline__ void main_tail(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane, const int ks_in,
+__device__ __forceinline__ void main_tail(const Calib& c, const SlotRef& s, uint32_t* lst, const int lane, const int lcap,
+                                          const int ks_in,
                                           bool live, const double minZ, const double maxZ, const double myu,
                                           const double myv, int& mytype, double& mydepth, bool& overflow ST_ARG) {
     MLD_DIAG_SKIP_TAIL();
@@ -2045,7 +2077,7 @@ __device__ __forceinline__ void main_tail(const Calib& c, const SlotDesc& s, uin
         bool ok;
         const int ksmax = uniform(wave_max_i32(live ? ks : 0));
         if (!DENSE || ksmax <= kTriSmall || ksmax > kTriHuge) {
-            ok = triangle_small<kTriSmall>(c, s, ks, live && ks <= kTriSmall, lst, lane, c1, c2, c3);
+            ok = triangle_small<kTriSmall>(c, s, ks, live && ks <= kTriSmall, lst, lane, lcap, c1, c2, c3);
             if (ksmax > kTriSmall) {  // longer segmented lists: the generic serial loops
                 V3 d1, d2, d3;
                 bool ok2 = triangle_thread(c, s, ks, live && ks > kTriSmall, lst, lane, d1, d2, d3);
@@ -2057,11 +2089,11 @@ __device__ __forceinline__ void main_tail(const Calib& c, const SlotDesc& s, uin
                 }
             }
         } else if (ksmax <= kTriMid) {
-            ok = triangle_small<DENSE ? kTriMid : 1>(c, s, ks, live, lst, lane, c1, c2, c3);
+            ok = triangle_small<DENSE ? kTriMid : 1>(c, s, ks, live, lst, lane, lcap, c1, c2, c3);
         } else if (ksmax <= kTriLarge) {
-            ok = triangle_small<DENSE ? kTriLarge : 1>(c, s, ks, live, lst, lane, c1, c2, c3);
+            ok = triangle_small<DENSE ? kTriLarge : 1>(c, s, ks, live, lst, lane, lcap, c1, c2, c3);
         } else {
-            ok = triangle_small<DENSE ? kTriHuge : 1>(c, s, ks, live, lst, lane, c1, c2, c3);
+            ok = triangle_small<DENSE ? kTriHuge : 1>(c, s, ks, live, lst, lane, lcap, c1, c2, c3);
         }
         if (live && !ok) {
             mytype = MLD_TriangleNotPlanarInsufficientPoints;
@@ -2121,13 +2153,13 @@ __device__ __forceinline__ void main_tail(const Calib& c, const SlotDesc& s, uin
 }
 
 template <bool DENSE>
-__device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& s, uint32_t* lst, const int lane,
-                                                const int k, bool live, const double myu, const double myv,
+__device__ __forceinline__ void main_after_scan(const Calib& c, const SlotRef& s, uint32_t* lst, const int lane,
+                                                const int lcap, const int k, bool live, const double myu, const double myv,
                                                 int& mytype, double& mydepth, bool& overflow ST_ARG) {
     int ks;
     double minZ, maxZ;
-    main_hist(c, s, lst, lane, k, live, mytype, ks, minZ, maxZ ST_PASS);
-    main_tail<DENSE>(c, s, lst, lane, ks, live, minZ, maxZ, myu, myv, mytype, mydepth, overflow ST_PASS);
+    main_hist(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
+    main_tail<DENSE>(c, s, lst, lane, lcap, ks, live, minZ, maxZ, myu, myv, mytype, mydepth, overflow ST_PASS);
 }
 
 // Wave-cooperative kernel for the features the thread kernels could not hold (lists longer than their capacities).
@@ -2140,9 +2172,12 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotDesc& 
 // direct != 0 (ONE frame per call): no queue - entry e IS feature e, and the block settles the features without
 // enough neighbours itself (what k_classify does for batches: window count in the occupancy bitmap, which the projection
 // has just left in L2), so a single-frame call is projection + this kernel.
+// (DIRECT as a template parameter: the one-frame instantiation is straight-line code - one pass per block, nothing for
+// the compiler to hoist in front of a loop and carry in spilled scalar registers)
+template <bool DIRECT>
 __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restrict__ slots, SlotDesc single, int use_single,
-                                                        Calib c, int n_slots, int per_slot, uint32_t tag_all, int chunk,
-                                                        int direct) {
+                                                        Calib c, int n_slots, int per_slot, uint32_t tag_all, int chunk) {
+    constexpr int direct = DIRECT ? 1 : 0;
     extern __shared__ __align__(16) unsigned char smem[];
     int slot, j;
     decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
@@ -2162,7 +2197,7 @@ __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restri
         count = *GPTR(int32_t, s.ovf_count);
     }
     const int lane = threadIdx.x;
-    for (int e0 = j * chunk; e0 < count; e0 += per_slot * chunk) {
+    auto pass = [&](const int e0) {
         bool active = lane < chunk && e0 + lane < count;
         long long f = 0;
         int code = 0;
@@ -2221,6 +2256,11 @@ __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restri
         }
         ST_MARK(12);
         ST_END();
+    };
+    if (DIRECT) {  // (the host sizes the one-frame grid so that one pass per block covers every feature)
+        if (j * chunk < count) pass(j * chunk);
+    } else {
+        for (int e0 = j * chunk; e0 < count; e0 += per_slot * chunk) pass(e0);
     }
 }
 
@@ -2492,11 +2532,11 @@ constexpr int kKeyBatchF = MLD_KEY_BATCH_F;  // map keys fetched per round trip 
 // While the keys are in registers the scan also writes the narrow list `nl` (the flagged entries' point indices, same
 // order, at most c.kMain of them) and gathers what the road fallback wants to know about the lane's list before it
 // touches a point: states = bit 0 "a far point", bit 1 "an unsure point" (k_project_scatter's plane states).
-__device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDesc& s, int x0, int y0, int nx, int ny,
+__device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef& s, int x0, int y0, int nx, int ny,
                                                    int xn0, int yn0, int nxn, int nyn, uint32_t* lst, uint32_t* nl,
                                                    int lane, int& kflag, uint32_t& states ST_ARG) {
     const int nymax = uniform(wave_max_i32(ny));
-    const auto* bm = GPTR(uint32_t, s.bitmap);
+    const auto* bm = GPTR(uint32_t, s.g.bitmap);
     // windows are at most 32 cells wide here (k_classify routes wider ones to the wave kernel): 32-bit row masks
     const uint32_t colmask = (nx >= 32) ? ~0u : ((1u << nx) - 1u);
     // columns of the narrow window relative to x0
@@ -2581,7 +2621,7 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDes
     // cell index -> original point index (every set bit has a key of the current tag)
     const int kk = k <= c.k1max ? k : 0;
     const int kmax = uniform(wave_max_i32(kk));
-    const auto* mp = GPTR(uint32_t, s.map);
+    const auto* mp = GPTR(uint32_t, s.g.map);
     int kn = 0;
     uint32_t st_any = 0u;
     for (int e0 = 0; e0 < kmax; e0 += kKeyBatchF) {
@@ -2589,7 +2629,7 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDes
 #pragma unroll
         for (int q = 0; q < kKeyBatchF; q++) cell[q] = (e0 + q < kk) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
 #pragma unroll
-        for (int q = 0; q < kKeyBatchF; q++) key[q] = (e0 + q < kk) ? MLD_DIAG_KEY(mp[cell[q] & 0x7FFFFFFFu], s.tag, cell[q]) : 0u;
+        for (int q = 0; q < kKeyBatchF; q++) key[q] = (e0 + q < kk) ? MLD_DIAG_KEY(mp[cell[q] & 0x7FFFFFFFu], s.g.tag, cell[q]) : 0u;
 #pragma unroll
         for (int q = 0; q < kKeyBatchF; q++)
             if (e0 + q < kk) {
@@ -2623,20 +2663,31 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotDes
 // uses.  The other instantiation keeps to 168 registers: three wavefronts per SIMD alone, or two beside the projection
 // wavefronts of another context (mld_set_shared_gpu).
 template <int ROAD_MODE, bool DENSE>
-__global__ __launch_bounds__(kWave, DENSE ? 2 : MLD_FUSED_WAVES) MLD_FUSED_ATTR void k_feature_fused(const SlotDesc* __restrict__ slots, SlotDesc single,
-                                                         int use_single, Calib c, int n_slots, int per_slot,
-                                                         uint32_t tag_all) {
+__global__ __launch_bounds__(kWave, DENSE ? 2 : MLD_FUSED_WAVES) MLD_FUSED_ATTR void k_feature_fused(const SlotDesc* __restrict__ slots,
+                                                         const Calib* __restrict__ calib, int n_slots, int per_slot) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int total = n_slots * per_slot;
-    for (int w = (int)blockIdx.x; w < total; w += (int)gridDim.x) {
+    // The per-context constants stay in device memory as well (mld_ctx::d_calib): a field is fetched by a scalar load
+    // where a stage uses it.  Passed by value, the compiler fetched all 600 bytes in the prologue and carried - spilled -
+    // them through the kernel.
+    const Calib& c = *calib;
+    // One wavefront of features per block, n_slots * per_slot blocks: straight-line code.  (A grid-stride loop around
+    // this body - there for a persistent-grid experiment that lost - made the compiler hoist every wave-uniform quantity
+    // of the body in front of the loop: ~190 scalars written to vector lanes in the prologue and 850 v_readlane in the
+    // body to get them back, in a kernel that is bound by VALU issue.)
+    {
+        const int w = (int)blockIdx.x;
+        if (w >= n_slots * per_slot) return;
         int slot, j;
         decode_block(w, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
-        SlotDesc s = use_single ? single : slots[slot];
-        apply_plane_dev(s);
-        if (tag_all) s.tag = tag_all;
-        const int count = *GPTR(int32_t, s.live_count);
+        // (nothing of the descriptor but what a stage needs is ever held: see SlotRef.  The map tag is not among it - every
+        // bit of the occupancy bitmap has a key of the current tag.)
+        const SlotDesc& sg = slots[slot];
+        const auto* pdev = GPTR(PlaneDev, sg.plane_dev);  // a plane estimated on the device overrides the descriptor's
+        const SlotRef s = {sg, sg.plane_dev ? reinterpret_cast<const double*>(sg.plane_dev) : sg.prior_n,
+                           sg.plane_dev ? pdev->has_plane : sg.has_plane};
+        const int count = *GPTR(int32_t, sg.live_count);
         const int e0 = j * kWave;
-        if (e0 >= count) continue;
+        if (e0 >= count) return;
         ST_BEGIN(0);
         const int lane = threadIdx.x;
         const bool active = e0 + lane < count;
@@ -2645,15 +2696,15 @@ __global__ __launch_bounds__(kWave, DENSE ? 2 : MLD_FUSED_WAVES) MLD_FUSED_ATTR 
         long long f = 0;
         double myu = 0, myv = 0;
         if (active) {
-            f = (long long)GPTR(int32_t, s.live_queue)[e0 + lane];
-            const auto* q = GPTR(double, s.uv) + 2 * f;
+            f = (long long)GPTR(int32_t, sg.live_queue)[e0 + lane];
+            const auto* q = GPTR(double, sg.uv) + 2 * f;
             myu = q[0];
             myv = q[1];
         }
         ST_USE_F64(myu);
         ST_USE_F64(myv);
         ST_MARK(1);
-        const bool road_on = c.useRoad && s.has_plane && s.inlier_mask;
+        const bool road_on = c.useRoad && s.has_plane && sg.inlier_mask;
         // narrow window (DepthEstimator.cpp:509, scale 1 x 1) and the window that is scanned: the road window
         // (:585, scale 2.0 x 1.5), a superset, when the fallback is on
         int xn0 = 0, yn0 = 0, nxn, nyn, x0 = 0, y0 = 0, nx, ny;
@@ -2695,11 +2746,9 @@ __global__ __launch_bounds__(kWave, DENSE ? 2 : MLD_FUSED_WAVES) MLD_FUSED_ATTR 
             live = false;
         }
         {
-            Calib cm = c;
-            cm.k1max = c.kMain;
             bool ovf1 = false;
-            main_after_scan<DENSE>(cm, s, nl, lane, k1, live, myu, myv, mytype, mydepth, ovf1 ST_PASS);
-            if (live && ovf1) overflow = true;  // segmented list too long for the per-thread triangle search: wave kernel
+            main_after_scan<DENSE>(c, s, nl, lane, c.kMain, k1, live, myu, myv, mytype, mydepth, ovf1 ST_PASS);
+            if (live && ovf1) overflow = true;  // (a list the per-thread corner search cannot take: wave kernel)
         }
         // ---------------- road fallback (DepthEstimator.cpp:578-597) on the list already scanned ----------------
         const bool cand = road_on && active && !overflow && (mytype != MLD_Success) &&
@@ -2713,10 +2762,10 @@ __global__ __launch_bounds__(kWave, DENSE ? 2 : MLD_FUSED_WAVES) MLD_FUSED_ATTR 
                 ovf_code = resultOld;
             }
         }
-        enqueue_features(s.ovf_queue, s.ovf_count, overflow && active, lane, f, ovf_code);
+        enqueue_features(sg.ovf_queue, sg.ovf_count, overflow && active, lane, f, ovf_code);
         if (active) {
-            GPTRW(double, s.depth)[f] = mydepth;
-            if (s.type) GPTRW(int32_t, s.type)[f] = mytype;
+            GPTRW(double, sg.depth)[f] = mydepth;
+            if (sg.type) GPTRW(int32_t, sg.type)[f] = mytype;
         }
         ST_MARK(12);
         ST_END();

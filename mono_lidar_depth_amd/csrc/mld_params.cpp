@@ -4,6 +4,7 @@
 // DepthEstimatorParameters.h:7-173) and its loader DepthEstimatorParameters::fromFile
 // (monolidar_fusion/src/DepthEstimatorParameters.cpp:16-114) for the fields the path reads.
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -157,6 +158,7 @@ int mld_params_from_file(mld_params* p, const char* path, char* err, int err_len
     FILE* f = std::fopen(path, "r");
     if (!f) return fail(std::string("Cant find settings file: ") + path);  // DepthEstimatorParameters.cpp:24
     std::memset(p, 0, sizeof(*p));
+    bool seen[sizeof(kFields) / sizeof(kFields[0])] = {};
     char line[1024];
     while (std::fgets(line, sizeof(line), f)) {
         std::string s(line);
@@ -176,19 +178,39 @@ int mld_params_from_file(mld_params* p, const char* path, char* err, int err_len
         char* end = nullptr;
         double d = std::strtod(val.c_str(), &end);
         if (end == val.c_str()) continue;  // non-numeric node: reads as 0
-        for (const Field& fd : kFields) {
+        for (size_t fi = 0; fi < sizeof(kFields) / sizeof(kFields[0]); fi++) {
+            const Field& fd = kFields[fi];
             if (key != fd.key) continue;
+            seen[fi] = true;
             char* base = reinterpret_cast<char*>(p);
             if (fd.is_double) {
                 *reinterpret_cast<double*>(base + fd.offset) = d;
             } else {
-                int iv = static_cast<int>(std::nearbyint(d));
+                // cvRound of the node's value; out-of-range / NaN values saturate instead of being undefined
+                const double r = std::nearbyint(d);
+                int iv = 0;
+                if (r >= 2147483647.0)
+                    iv = 2147483647;
+                else if (r <= -2147483648.0)
+                    iv = -2147483647 - 1;
+                else if (r == r)
+                    iv = static_cast<int>(r);
                 if (is_bool_field(fd.key)) iv = (iv != 0) ? 1 : 0;
                 *reinterpret_cast<int32_t*>(base + fd.offset) = iv;
             }
         }
     }
     std::fclose(f);
+    // On success `err` carries a NOTE: the mirrored keys the file does not hold, which therefore read as 0 exactly as
+    // the reference's cv::FileStorage reads them.  The reference's own parameters.yaml lacks ransac_plane_min_z /
+    // ransac_plane_max_z: they load as 0 / 0, the z pass-through (RansacPlane.cpp:58-64) then keeps only points with
+    // z == 0 and the RANSAC plane estimate fails - a caller that wants the header's +-10000 must say so in the file.
+    if (err && err_len > 0) {
+        std::string note;
+        for (size_t fi = 0; fi < sizeof(kFields) / sizeof(kFields[0]); fi++)
+            if (!seen[fi]) note += (note.empty() ? "absent (read as 0): " : ", ") + std::string(kFields[fi].key);
+        std::snprintf(err, static_cast<size_t>(err_len), "%s", note.c_str());
+    }
     return MLD_OK;
 }
 

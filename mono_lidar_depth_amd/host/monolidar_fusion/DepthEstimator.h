@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <array>
 #include <cstdint>
+#include <cstdio>
 #include <exception>
 #include <functional>
 #include <memory>
@@ -111,9 +112,22 @@ class DepthEstimatorParameters : public mld_params {
 public:
     DepthEstimatorParameters() { mld_params_default(this); }
     void fromFile(const std::string& filePath) {
-        char err[512];
+        char err[2048];
         if (mld_params_from_file(this, filePath.c_str(), err, sizeof(err)) != MLD_OK) throw std::string(err);
+        absentKeys = err;  // "absent (read as 0): ..." or empty
+        // The reference's own parameters.yaml has no ransac_plane_min_z / ransac_plane_max_z: cv::FileStorage reads 0 / 0,
+        // the z pass-through keeps only points with z == 0 and every RANSAC plane estimate fails
+        // (GroundPlane::ExceptionPclInvalid).  Same behaviour here - but said out loud.
+        if (do_use_ransac_plane && (absentKeys.find("ransac_plane_min_z") != std::string::npos ||
+                                    absentKeys.find("ransac_plane_max_z") != std::string::npos))
+            std::fprintf(stderr,
+                         "DepthEstimatorParameters: %s holds no ransac_plane_min_z / ransac_plane_max_z; they read as 0 "
+                         "(as in the reference), so RansacPlane keeps only points with z == 0 and its estimate fails. "
+                         "Add them (the header's defaults are -10000 / 10000) unless every frame brings a SemanticPlane or "
+                         "a segmented plane.\n",
+                         filePath.c_str());
     }
+    std::string absentKeys;
 };
 
 // DepthCalculationStatistics (DepthCalculationStatistics.h:11-260): per-call counters of the result types (cleared by

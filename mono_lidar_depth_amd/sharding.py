@@ -102,3 +102,77 @@ def gather_over_ranks(value: float, device=None):
     out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
     return [float(x.item()) for x in out]
+
+
+# ---------------------------------------------------------------------------------------------- host placement
+def _parse_cpulist(text: str) -> List[int]:
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-")
+            out.extend(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+def gpu_numa_nodes(sysfs_root: str = "/sys") -> List[Tuple[str, int]]:
+    """(PCI address, NUMA node) of every AMD GPU with a render node, in PCI-address order - the order the HIP runtime
+    enumerates them in when no *_VISIBLE_DEVICES variable re-orders it.  Reads sysfs only: no GPU call."""
+    import glob
+    import os
+    found = {}
+    for node in glob.glob(os.path.join(sysfs_root, "class/drm/renderD*")):
+        dev = os.path.realpath(os.path.join(node, "device"))
+        try:
+            with open(os.path.join(dev, "vendor")) as f:
+                if f.read().strip().lower() != "0x1002":
+                    continue
+            with open(os.path.join(dev, "numa_node")) as f:
+                numa = int(f.read().strip())
+        except (OSError, ValueError):
+            continue
+        found[os.path.basename(dev)] = numa
+    return sorted(found.items())
+
+
+def bind_to_gpu_numa_node(local_rank: int, sysfs_root: str = "/sys") -> dict:
+    """Pins the calling process to the CPU cores of the NUMA node its GPU hangs off (config 4: every rank streams its
+    sequence from pinned host memory, 8 x ~50 GB/s on one node - a rank whose staging buffers and copy threads sit on
+    the other socket pays the inter-socket link on every frame).  Call it in the worker BEFORE the first GPU call and
+    before any pinned allocation: memory is then first-touched, and the runtime's helper threads are created, on that
+    node.  Never re-executes anything.  Returns what it did (reported as `distributed.affinity` by bench.py)."""
+    import os
+    info = {"local_rank": int(local_rank), "applied": False, "numa_node": None, "pci": None, "cpus": None}
+    try:
+        before = sorted(os.sched_getaffinity(0))
+    except AttributeError:  # not Linux
+        return info
+    info["cpus"] = len(before)
+    gpus = gpu_numa_nodes(sysfs_root)
+    visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
+    index = int(local_rank)
+    if visible:
+        try:
+            ids = [int(x) for x in visible.split(",") if x.strip() != ""]
+            index = ids[index % len(ids)] if ids else index
+        except ValueError:
+            return {**info, "reason": "non-numeric *_VISIBLE_DEVICES"}
+    if not gpus:
+        return {**info, "reason": "no AMD render node in sysfs"}
+    pci, numa = gpus[index % len(gpus)]
+    info.update({"pci": pci, "numa_node": numa})
+    if numa < 0:
+        return {**info, "reason": "the GPU reports no NUMA node (single-node host)"}
+    try:
+        with open(os.path.join(sysfs_root, f"devices/system/node/node{numa}/cpulist")) as f:
+            node_cpus = set(_parse_cpulist(f.read()))
+    except OSError:
+        return {**info, "reason": f"node{numa}/cpulist unreadable"}
+    want = sorted(node_cpus & set(before))
+    if not want:
+        return {**info, "reason": "none of the node's cores is in this process's affinity mask"}
+    os.sched_setaffinity(0, want)
+    return {**info, "applied": want != before, "cpus": len(want), "cpu_first": want[0], "cpu_last": want[-1]}

@@ -2,7 +2,7 @@
 # Profiles bench.py under rocprofv3 on the GPU box (invoke through gpurun from the repo root):
 #   gpurun -- 'bash profiles/run_profile.sh r3'
 # Writes raw output under gpurun_out/prof_<tag>/; profiles/summarize.py condenses it into profiles/<tag>_*.
-TAG=${1:-r4}
+TAG=${1:-r5}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -34,9 +34,25 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 for c in 3 5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c$c -- python3 $REPO/bench.py --only-config $c > $OUT/bench_c$c.json 2> $OUT/trace_c$c.log
 done
+# counter passes of the other legs (one leg per command, one context, so that a kernel's launches are all of one size):
+#   2k     config 2 at k = 7 (features on returns whose window holds >= 6 returns), 1024 frames per launch
+#   3n     config 3, features around the returns (c0_dispose), 256 frames per launch
+#   5b256  config 5, 256 sequences per step (the DENSE instantiation of the feature kernel)
+leg() {  # key, bench arguments
+  local key=$1; shift
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/leg_${key}_trace -- python3 $REPO/bench.py "$@" > $OUT/leg_${key}_trace.json 2> $OUT/leg_${key}_trace.log
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/leg_${key}_fetch -- python3 $REPO/bench.py "$@" > $OUT/leg_${key}_fetch.json 2> $OUT/leg_${key}_fetch.log
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/leg_${key}_write -- python3 $REPO/bench.py "$@" > $OUT/leg_${key}_write.json 2> $OUT/leg_${key}_write.log
+}
+leg 2k --only-config 2 --contexts 1 --frames-per-step 1024
+leg 3n --only-config 3 --leg near
+leg 5b256 --only-config 5 --leg 256
 cd $REPO
 python3 profiles/summarize.py $TAG > $OUT/summary.log 2>&1
+python3 profiles/summarize_config_pmc.py $TAG 2k 1024 "python3 bench.py --only-config 2 --contexts 1 --frames-per-step 1024" >> $OUT/summary.log 2>&1
+python3 profiles/summarize_config_pmc.py $TAG 3n 256 "python3 bench.py --only-config 3 --leg near" >> $OUT/summary.log 2>&1
+python3 profiles/summarize_config_pmc.py $TAG 5b256 256 "python3 bench.py --only-config 5 --leg 256" >> $OUT/summary.log 2>&1
 python3 profiles/summarize_config.py $TAG 3 >> $OUT/summary.log 2>&1
 python3 profiles/summarize_config.py $TAG 5 >> $OUT/summary.log 2>&1
-mkdir -p $OUT/keep && cp profiles/${TAG}_*.md profiles/${TAG}_*.csv profiles/traffic.json $OUT/keep/ 2>/dev/null
+mkdir -p $OUT/keep && cp profiles/${TAG}_*.md profiles/${TAG}_*.csv profiles/${TAG}_*.txt profiles/traffic.json $OUT/keep/ 2>/dev/null
 tail -40 $OUT/summary.log

@@ -73,10 +73,18 @@ def test_params_from_file(tmp_path):
         assert getattr(p, name) == getattr(c0, name), name
     assert p.ransac_plane_min_z == 0 and p.ransac_plane_max_z == 0
     assert p.set_all_depths_to_zero == 0  # key absent in the yaml -> 0
+    # the loader says which mirrored keys were absent (the reference's own parameters.yaml lacks exactly these: its
+    # RansacPlane then keeps only points with z == 0 and the estimate fails - reproduced, and reported)
+    assert p.absent_keys == ["ransac_plane_min_z", "ransac_plane_max_z", "set_all_depths_to_zero"]
     y2 = tmp_path / "q.yaml"
     y2.write_text("do_use_ransac_plane: 5\ntreshold_depth_max: 79.6\n")
     q = capi.params_from_file(str(y2))
     assert q.do_use_ransac_plane == 1 and q.treshold_depth_max == 80 and q.pixelarea_search_witdh == 0
+    assert "pixelarea_search_witdh" in q.absent_keys and "treshold_depth_max" not in q.absent_keys
+    y3 = tmp_path / "r.yaml"   # values beyond int: saturate (cvRound of such a value is undefined in the reference)
+    y3.write_text("treshold_depth_max: 1e300\ntreshold_depth_min: -1e300\nradiusSearch_count_min: nan\n")
+    r = capi.params_from_file(str(y3))
+    assert r.treshold_depth_max == 2**31 - 1 and r.treshold_depth_min == -2**31 and r.radiusSearch_count_min == 0
     with pytest.raises(RuntimeError, match="Cant find settings file"):
         capi.params_from_file(str(tmp_path / "missing.yaml"))
 

@@ -69,3 +69,50 @@ def test_pack_roundtrip_and_identity_without_process_group():
     assert P3 is P and cam3 is cam
     assert sharding.max_over_ranks(3.5) == 3.5 and sharding.sum_over_ranks(2.0) == 2.0
     assert sharding.assign_sequences(3, 8) == [[0], [1], [2], [], [], [], [], []]
+
+
+def _fake_sysfs(root, gpus, nodes):
+    """gpus: [(pci, vendor, numa)], nodes: {node: cpulist} - the sysfs entries bind_to_gpu_numa_node reads."""
+    for i, (pci, vendor, numa) in enumerate(gpus):
+        dev = root / "devices" / "pci0000:00" / pci
+        dev.mkdir(parents=True)
+        (dev / "vendor").write_text(vendor + "\n")
+        (dev / "numa_node").write_text(f"{numa}\n")
+        node = root / "class" / "drm" / f"renderD{128 + i}"
+        node.mkdir(parents=True)
+        (node / "device").symlink_to(dev)
+    for n, cpus in nodes.items():
+        d = root / "devices" / "system" / "node" / f"node{n}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+
+
+def test_rank_is_pinned_to_the_numa_node_of_its_gpu(tmp_path, monkeypatch):
+    """Config 4 readiness: rank r's process is confined to the cores of GPU r's NUMA node before any GPU call
+    (sysfs only).  GPUs are taken in PCI-address order; a foreign render node (not AMD) is skipped."""
+    have = sorted(os.sched_getaffinity(0))
+    if len(have) < 2:
+        import pytest
+        pytest.skip("needs two cores in the affinity mask")
+    lo, hi = have[:len(have) // 2], have[len(have) // 2:]
+    as_list = lambda cs: ",".join(str(c) for c in cs)  # noqa: E731
+    _fake_sysfs(tmp_path, [("0000:85:00.0", "0x1002", 1), ("0000:05:00.0", "0x1002", 0), ("0000:03:00.0", "0x10de", 0),
+                           ("0000:c5:00.0", "0x1002", -1)], {0: as_list(lo), 1: as_list(hi)})
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    assert sharding.gpu_numa_nodes(str(tmp_path)) == [("0000:05:00.0", 0), ("0000:85:00.0", 1), ("0000:c5:00.0", -1)]
+    try:
+        a = sharding.bind_to_gpu_numa_node(0, str(tmp_path))
+        assert a["numa_node"] == 0 and a["pci"] == "0000:05:00.0" and sorted(os.sched_getaffinity(0)) == lo and a["applied"]
+        os.sched_setaffinity(0, have)
+        b = sharding.bind_to_gpu_numa_node(1, str(tmp_path))
+        assert b["numa_node"] == 1 and sorted(os.sched_getaffinity(0)) == hi and b["cpus"] == len(hi)
+        os.sched_setaffinity(0, have)
+        c = sharding.bind_to_gpu_numa_node(2, str(tmp_path))   # a GPU without a NUMA node: nothing changes
+        assert c["numa_node"] == -1 and not c["applied"] and sorted(os.sched_getaffinity(0)) == have
+        monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")       # local rank 0 is device 1 of the PCI order
+        d = sharding.bind_to_gpu_numa_node(0, str(tmp_path))
+        assert d["pci"] == "0000:85:00.0" and sorted(os.sched_getaffinity(0)) == hi
+    finally:
+        os.sched_setaffinity(0, have)
+    assert sharding.bind_to_gpu_numa_node(0, str(tmp_path / "nothing"))["applied"] is False
