@@ -1282,7 +1282,13 @@ def main():
     }
     entries["k_project_scatter"]["design_model"] = "16 B/point + 4 B per map entry + occupancy and inlier-mask words touched"
     entries["k_feature_fused"]["gather"] = gather
-    dominant = max(entries, key=lambda k: ms(k))
+    # The dominant kernel.  With two contexts the projection of one step and the feature kernel of the previous one run
+    # side by side for (nearly) the whole step and their launch durations differ by a few per cent, in either direction
+    # from box to box: among the kernels within 15 % of the longest launch the one that moves the most HBM bytes is taken -
+    # the projection, which also sits on the chain that sets the step period (projection -> classification -> hand-over).
+    longest = max(ms(k) for k in entries)
+    near = [k for k in entries if ms(k) >= 0.85 * longest] or list(entries)
+    dominant = max(near, key=lambda k: (entries[k]["traffic"] or 0.0, ms(k)))
     dom = entries[dominant]
     if dom["frac"] is None:  # no committed counter profile: the design bytes (projection) are the only physical count at hand
         fb = design_project if dominant == "k_project_scatter" else None
@@ -1327,7 +1333,8 @@ def main():
         "bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["frac"],
         "traffic": dom["traffic"],
         "kernel": dominant, "kernel_ms": ms(dominant), "bytes_source": dom["bytes_source"],
-        "dominant_by": "longest average launch in the timed schedule (hipEvents, this run)",
+        "dominant_by": ("most HBM bytes among the kernels within 15 % of the longest average launch of the timed schedule "
+                        "(hipEvents, this run)"),
         # ---- scalars beside it
         "frac_exclusive": dom.get("frac_exclusive"),           # the same bytes over a launch that has the GPU to itself
         "exclusive_kernel_ms": dom.get("exclusive_kernel_ms"),

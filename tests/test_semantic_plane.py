@@ -147,3 +147,50 @@ def test_hip_label_image_smaller_than_the_camera_and_odd_label_sets():
     c_hip, n_hip = est.estimateSemanticPlane(small, labels, 0.2)
     assert np.array_equal(c_hip, coeffs) and n_hip == inl.size
     assert np.array_equal(est.getGroundPlaneInliers(), inl)
+
+
+def _fit_sequential_f32(xyz32, member, fallback):
+    """optimizeModelCoefficients with the moments summed the way the reference sums them: PCL's
+    computeMeanAndCovarianceMatrix accumulates the nine float sums point by point in index order (one sequential float32
+    chain each; np.add.accumulate in float32 is exactly that chain)."""
+    idx = np.nonzero(member)[0]
+    if idx.size < 4:
+        return np.asarray(fallback, dtype=np.float32)
+    v = xyz32[idx]
+    x, y, z = v[:, 0], v[:, 1], v[:, 2]
+    m = np.float32(idx.size)
+    seq = lambda q: np.add.accumulate(q.astype(np.float32), dtype=np.float32)[-1] / m  # noqa: E731
+    a = [seq(q) for q in (x * x, x * y, x * z, y * y, y * z, z * z, x, y, z)]
+    cov = np.array([[a[0] - a[6] * a[6], a[1] - a[6] * a[7], a[2] - a[6] * a[8]],
+                    [a[1] - a[6] * a[7], a[3] - a[7] * a[7], a[4] - a[7] * a[8]],
+                    [a[2] - a[6] * a[8], a[4] - a[7] * a[8], a[5] - a[8] * a[8]]], dtype=np.float64)
+    _, vec = np.linalg.eigh(cov)
+    n = vec[:, 0].astype(np.float32)
+    d = np.float32(-1.0) * (n[0] * a[6] + n[1] * a[7] + n[2] * a[8])
+    return np.array([n[0], n[1], n[2], d], dtype=np.float32)
+
+
+@pytest.mark.parametrize("seed,thr", [(3, 0.1), (4, 0.3), (5, 0.05), (11, 0.1)])
+def test_group_tree_sums_stay_close_to_the_reference_summation_order(seed, thr):
+    """The kernels (and both restatements) sum the plane fit's float32 moments in a group tree + 256 interleaved partials;
+    the reference sums them sequentially (PCL).  Nothing pins one against the other bit for bit - the association is
+    not the reference's - so this test BOUNDS the drift: the same candidate set fitted in PCL's order gives the same
+    plane to ~1e-6 (normal) / ~1e-5 m (offset) and the same inlier set up to a handful of borderline points."""
+    cloud, img = _frame(seed)
+    cand, c1, inl, c2 = np_restatement.semantic_plane(cloud, synth.T_CAM_LIDAR, synth.KITTI_F, synth.KITTI_CU, synth.KITTI_CV,
+                                                      img, LABELS, thr)
+    xyz32 = cloud[:, :3].astype(np.float32)
+    is_cand = np.zeros(cloud.shape[0], dtype=bool)
+    is_cand[cand] = True
+    s1 = _fit_sequential_f32(xyz32, is_cand, [0, 0, 1, 0])
+    with np.errstate(invalid="ignore"):
+        dist = np.abs(((s1[0] * xyz32[:, 0] + s1[1] * xyz32[:, 1]) + s1[2] * xyz32[:, 2]) + s1[3])
+    sel = dist.astype(np.float64) < thr
+    s2 = _fit_sequential_f32(xyz32, sel, s1)
+    for a, b in ((c1, s1), (c2, s2)):
+        sgn = 1.0 if np.dot(a[:3], b[:3]) > 0 else -1.0
+        assert np.abs(a[:3] - sgn * b[:3]).max() < 2e-5, (a, b)     # normal (observed: 1e-7 ... 1e-6)
+        assert abs(a[3] - sgn * b[3]) < 2e-4, (a, b)                # offset, metres (observed: 1e-6 ... 1e-5)
+    inl_seq = np.nonzero(sel)[0]
+    # points within the drift of the threshold may change sides; nothing else may
+    assert np.setxor1d(inl, inl_seq).size <= max(8, inl.size // 2000), (inl.size, np.setxor1d(inl, inl_seq).size)  # observed: 0 ... 7
