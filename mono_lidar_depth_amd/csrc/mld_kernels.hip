@@ -1438,7 +1438,14 @@ constexpr int kTriMid = MLD_TRI_MID, kTriLarge = MLD_TRI_LARGE, kTriHuge = MLD_T
 #ifndef MLD_KZC
 #define MLD_KZC 12
 #endif
-constexpr int kZc = MLD_KZC;      // list entries whose depth stays in registers over the histogram passes
+constexpr int kZcDefault = MLD_KZC;  // list entries whose depth stays in registers over the histogram passes ...
+#ifndef MLD_KZC_MID
+#define MLD_KZC_MID 16
+#endif
+#ifndef MLD_KZC_DENSE
+#define MLD_KZC_DENSE 24
+#endif
+constexpr int kZcMid = MLD_KZC_MID, kZcDense = MLD_KZC_DENSE;  // ... and in the further tiers of the DENSE instantiation
 #ifndef MLD_ROAD_BATCH
 #define MLD_ROAD_BATCH 4
 #endif
@@ -1843,6 +1850,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s
 // First half: depth segmentation of the lane's neighbour list (DepthEstimator.cpp:726-780).  On return the list holds
 // the segmented points (ks entries, reference order) and minZ / maxZ their depth range; a failed histogram sets
 // mytype = HistogramNoLocalMax and clears `live`.
+template <int kZc>  // list entries whose depth stays in registers over the histogram passes
 __device__ __forceinline__ void main_hist(const Calib& c, const SlotRef& s, uint32_t* lst, const int lane, const int lcap,
                                           const int k, bool& live, int& mytype, int& ks, double& minZ, double& maxZ ST_ARG) {
     ks = live ? k : 0;
@@ -2158,7 +2166,15 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotRef& s
                                                 int& mytype, double& mydepth, bool& overflow ST_ARG) {
     int ks;
     double minZ, maxZ;
-    main_hist(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
+    // (DENSE: a wavefront whose longest list exceeds the first tier keeps 16 / 24 depths in registers - one memory round
+    // trip for the depths instead of three passes of four-entry round trips over the tail)
+    const int kmax0 = DENSE ? uniform(wave_max_i32(live ? k : 0)) : 0;
+    if (DENSE && kmax0 > kZcDefault && kmax0 <= kZcMid)
+        main_hist<DENSE ? kZcMid : kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
+    else if (DENSE && kmax0 > kZcMid)
+        main_hist<DENSE ? kZcDense : kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
+    else
+        main_hist<kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
     main_tail<DENSE>(c, s, lst, lane, lcap, ks, live, minZ, maxZ, myu, myv, mytype, mydepth, overflow ST_PASS);
 }
 
