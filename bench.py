@@ -12,11 +12,14 @@ child process, before this process touches the GPU) unless it already runs under
 
 The JSON line also carries
   verified      sampled slots of the timed batch compared with the CPU oracle after the timed region (exit 1 if not)
-  roofline      the dominant kernel priced on the bytes THIS design moves, / its hipEvent-measured duration, vs 8 TB/s
-                (`formula_GBps` keeps SURVEY.md §8(d)'s formula, which also charges a map clear and a camera-frame
-                copy that are never performed)
+  roofline      PHYSICAL: HBM bytes the PMC counters saw for the dominant kernel (committed profile, profiles/traffic.json,
+                scaled to this run's launch size) / its hipEvent-measured duration here, vs 8 TB/s; beside it the scalars
+                frac_exclusive, whole_step_frac_of_peak, whole_step_compulsory_frac, whole_step_hbm_busy_frac, gather_frac
+                and, marked as such, SURVEY.md §8(d)'s formula figures (formula_*: they charge a map clear and a
+                camera-frame copy that are never performed and may exceed the peak)
   cpu_baseline  the restated reference CPU path (oracle/, kind "port") timed on this host, rank 0, N=1 only
-  latency / streaming / configs["3"], configs["5"]   PCIe-inclusive legs and the other single-GPU BASELINE configs
+  latency / streaming / configs["2"|"3"|"5"]   PCIe-inclusive legs (16- and 32-byte cloud records) and the other single-GPU
+                BASELINE configs (config 2 at its stated neighbour count, config 3, config 5), each with its own roofline
 """
 from __future__ import annotations
 
@@ -689,6 +692,9 @@ def config_roofline(key, kt, frames_per_launch):
     separate --pmc passes), scaled to this run's frames per launch.  None where no counter profile is committed."""
     tj = traffic_profile_json() or {}
     prof = (tj.get("configs") or {}).get(key)
+    if prof is None and key.startswith("5b"):  # config 5 at another batch size: the S = 256 profile, scaled by the slots
+        key = "5b256"
+        prof = (tj.get("configs") or {}).get(key)
     times = {k: v["avg_ms"] for k, v in kt.items() if v.get("avg_ms", 0.0) > 0}
     if not prof or not times:
         return None

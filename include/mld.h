@@ -214,7 +214,10 @@ int mld_set_shared_gpu(mld_ctx* ctx, int shared);
  * longer are handled by the wave-cooperative kernel (same results, ~10x the cost per feature).  Default 32 / 24: right
  * for 64-beam clouds (config 2: 11 / 2.3 neighbours on average).  Dense clouds (128 beams x 4096: 16 / 6 on average, 48
  * at most in the road window) want 48 / 24: BASELINE config 5 at batch size runs 1.8x faster with it.  LDS per wavefront
- * = (wide + narrow) * 256 bytes.  8 <= narrow <= wide <= 64.
+ * = (wide + narrow) * 256 bytes.  8 <= narrow <= wide <= 64.  Capacities beyond the default also select the kernel's
+ * DENSE instantiation (unless mld_set_shared_gpu is on): two wavefronts per SIMD - all that much LDS allows - and the
+ * corner search of up to 24 segmented points, the histogram depths of up to 24 neighbours in registers (config 5 at 256
+ * sequences per step: 1.12 -> 1.8 G associations/s).
  */
 int mld_set_list_capacity(mld_ctx* ctx, int wide_entries, int narrow_entries);
 

@@ -32,15 +32,35 @@ struct TrackRec {
 };
 static_assert(sizeof(TrackRec) == 32, "record layout");
 
+// A GroundPlane subclass of the CALLER's (not one of the shim's GPU-estimated planes): it segments itself on the CPU
+// when setInputCloud finds it un-segmented (DepthEstimator.cpp:281-283) - here from a prepared inlier list - or throws
+// ExceptionPclInvalid, as RansacPlane does for an unusable cloud (RansacPlane.cpp:44-50).
+class ForeignPlane : public GroundPlane {
+public:
+    ForeignPlane(std::vector<int> inliers, bool fail) : inl_(std::move(inliers)), fail_(fail) {}
+    void CalculateInliersPlane(const Cloud::ConstPtr&, double, double) override {
+        if (fail_) throw ExceptionPclInvalid();
+        _modelCoeffs = {0.f, 0.f, 1.f, 1.73f};
+        _inliersIndex = inl_;
+        is_segmented_ = true;
+    }
+
+private:
+    std::vector<int> inl_;
+    bool fail_;
+};
+
 int main(int argc, char** argv) {
     if (argc < 4) {
-        std::cerr << "usage: mld_tracklet_demo <dir> <n_frames> <estimate_plane 0|1>\n";
+        std::cerr << "usage: mld_tracklet_demo <dir> <n_frames> <plane: 0 supplied | 1 estimated on the GPU | 2 a foreign "
+                     "CPU-estimated plane that fails on frame 2>\n";
         return 2;
     }
     try {
         const std::string dir = argv[1];
         const int n_frames = std::atoi(argv[2]);
-        const bool estimate = std::atoi(argv[3]) != 0;
+        const int plane_mode = std::atoi(argv[3]);
+        const bool estimate = plane_mode == 1;
         DepthEstimatorParameters P;
         mld_params_c0(&P);
         tracklets_depth::TrackletDepthModule mod(P);
@@ -58,7 +78,9 @@ int main(int argc, char** argv) {
                 in.tracks[i].feature_points = {{recs[i].u0, recs[i].v0}, {recs[i].u1, recs[i].v1}};
             }
             GroundPlane::Ptr gp;
-            if (!estimate) {
+            if (plane_mode == 2) {
+                gp = std::make_shared<ForeignPlane>(slurp<int>(dir + "/inl_" + sk + ".bin"), k == 2);
+            } else if (!estimate) {
                 std::vector<int> inl = slurp<int>(dir + "/inl_" + sk + ".bin");
                 gp = std::make_shared<GroundPlane>(std::array<float, 4>{0.f, 0.f, 1.f, 1.73f}, inl);
             }

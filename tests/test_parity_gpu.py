@@ -484,3 +484,47 @@ def test_pending_gate_survives_either_context_going_first(destroy_first):
         _, (d0, t0) = run_oracle(P, clouds[i], uvs[i], planes[i])
         assert_depth_parity(d[i].cpu().numpy(), t[i].cpu().numpy(), d0, t0)
     survivor.close()
+
+
+def test_rearmed_waiter_leaves_no_dangling_back_pointer():
+    """A context that holds an unconsumed gate on one context and is then re-armed behind ANOTHER one
+    (mld_order_after_classify again, before any projection of its own consumed the first hand-over): destroying it must
+    clear its registration at BOTH - the second context then goes on to classify and compute a correct batch (its
+    release_waiter used to point at freed memory), and so does the first."""
+    import torch
+    P = capi.params_c0()
+    S, F = 3, 250
+    dev = torch.device("cuda:0")
+    a, b, w = (make_estimator(P, max_frames=S, max_features=F) for _ in range(3))
+
+    def batch(e, seed):
+        clouds = [synth.make_cloud(synth.HDL64_KITTI, seed=seed, frame=i) for i in range(S)]
+        planes = [synth.make_ground_plane(c) for c in clouds]
+        uvs = [synth.make_features(F, seed=seed + i) for i in range(S)]
+        d = [torch.empty(F, dtype=torch.float64, device=dev) for _ in range(S)]
+        t = [torch.empty(F, dtype=torch.int32, device=dev) for _ in range(S)]
+        masks = []
+        for p, c in zip(planes, clouds):
+            m = np.zeros((c.shape[0] + 31) // 32, dtype=np.uint32)
+            np.bitwise_or.at(m, p[1] >> 5, (np.uint32(1) << (p[1] & 31).astype(np.uint32)))
+            masks.append(torch.from_numpy(m.view(np.int32)).to(dev))
+        pb = e.prepareBatch([torch.from_numpy(c).to(dev) for c in clouds], [torch.from_numpy(u).to(dev) for u in uvs], d, t,
+                            np.stack([p[0] for p in planes]), masks)
+        return pb, clouds, planes, uvs, d, t
+
+    ba, bb = batch(a, 700), batch(b, 800)
+    torch.cuda.synchronize()
+    a.runBatchBeside(ba[0], w)     # w's gate is pending on a's counter (w never projects: the gate stays unconsumed)
+    a.synchronize()
+    w.orderAfterClassify(b)        # ... and w is re-armed behind b
+    w.close()                      # both registrations must die with w
+    for e, bt in ((b, bb), (a, batch(a, 900))):
+        torch.cuda.synchronize()
+        e.runBatch(bt[0])          # (b: launch_features consults its release_waiter)
+        e.synchronize()
+        _, clouds, planes, uvs, d, t = bt
+        for i in range(S):
+            _, (d0, t0) = run_oracle(P, clouds[i], uvs[i], planes[i])
+            assert_depth_parity(d[i].cpu().numpy(), t[i].cpu().numpy(), d0, t0)
+    a.close()
+    b.close()

@@ -132,3 +132,61 @@ def test_cpp_tracklet_module_matches_oracle(tmp_path):
         assert f"frame {k} tracks {n_tracks} stored {n_tracks}" in r.stdout
         known = set(int(i) for i in fids)
         ref_last = ref
+
+
+@pytest.mark.gpu
+def test_cpp_tracklet_module_foreign_plane_that_fails(tmp_path):
+    """A caller's own GroundPlane subclass estimates itself on the CPU inside process(); on frame 2 it throws
+    ExceptionPclInvalid (tracklet_depth_module.cpp:318-347): the current frame's depths are -1, the new tracks' features
+    on the PREVIOUS frame are still answered from its resident slot, and frame 3 has no previous cloud any more."""
+    from oracle import oracle
+    from helpers import make_oracle
+    P = capi.params_c0()
+    rng = np.random.default_rng(18)
+    n_tracks, n_frames = 1200, 4
+    ids = np.arange(n_tracks, dtype=np.uint64)
+    next_id = n_tracks
+    frames = []
+    for k in range(n_frames):
+        cloud = synth.make_cloud(synth.HDL64_KITTI, seed=23, frame=2 * k, stride_floats=8)
+        coeffs, inl = synth.make_ground_plane(cloud)
+        if k > 0:
+            repl = rng.choice(n_tracks, n_tracks // 5, replace=False)
+            ids = ids.copy()
+            ids[repl] = np.arange(next_id, next_id + repl.size, dtype=np.uint64)
+            next_id += repl.size
+        u0 = rng.uniform(0, synth.KITTI_W, n_tracks).astype(np.float32)
+        v0 = rng.uniform(100, synth.KITTI_H, n_tracks).astype(np.float32)
+        u1 = (u0 + rng.normal(0, 3, n_tracks)).astype(np.float32)
+        v1 = (v0 + rng.normal(0, 2, n_tracks)).astype(np.float32)
+        rec = np.zeros(n_tracks, dtype=[("id", "<u8"), ("u0", "<f4"), ("v0", "<f4"), ("u1", "<f4"), ("v1", "<f4"), ("pad", "<f4"), ("pad2", "<f4")])
+        rec["id"], rec["u0"], rec["v0"], rec["u1"], rec["v1"] = ids, u0, v0, u1, v1
+        (tmp_path / f"cloud_{k}.bin").write_bytes(cloud.tobytes())
+        (tmp_path / f"tracks_{k}.bin").write_bytes(rec.tobytes())
+        (tmp_path / f"inl_{k}.bin").write_bytes(inl.tobytes())
+        frames.append((cloud, (coeffs, inl), ids.copy(), u0, v0, u1, v1))
+    r = subprocess.run([str(TRACKLET_DEMO), str(tmp_path), str(n_frames), "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    known, ref_last = set(), None
+    for k, (cloud, (coeffs, inl), fids, u0, v0, u1, v1) in enumerate(frames):
+        coeffs = coeffs.copy()
+        coeffs[3] = np.float32(1.73)
+        is_new = np.array([int(i) not in known for i in fids])
+        out = np.frombuffer((tmp_path / f"out_{k}.bin").read_bytes(), dtype=[("d0", "<f4"), ("d1", "<f4"), ("len", "<i4")])
+        if k == 2:
+            assert (out["d0"] == -1).all()                       # current frame: invalid depths
+            uv_old = np.stack([np.trunc(u1[is_new]).astype(np.float64), np.trunc(v1[is_new]).astype(np.float64)], axis=1)
+            d_prev, _ = ref_last.calculate_depth(uv_old, 4)      # previous frame: answered from its resident slot
+            assert np.allclose(out["d1"][is_new], d_prev.astype(np.float32), rtol=0, atol=1e-4) and (d_prev >= 0).sum() > 10
+            ref_last = None                                      # cloud and plane are forgotten (:333-348)
+        else:
+            ref = make_oracle(P)
+            ref.set_cloud(cloud)
+            ref.set_ground_plane(coeffs, inl)
+            e_cur, e_last, _, _ = oracle.tracklets_depth(ref, ref_last, u0, v0, u1, v1, is_new, n_threads=8)
+            assert np.allclose(out["d0"], e_cur, rtol=0, atol=1e-4)
+            assert np.allclose(out["d1"][is_new], e_last[is_new], rtol=0, atol=1e-4)
+            if k == 3:
+                assert (out["d1"][is_new] == -1).all()           # no previous cloud after the failed frame
+            ref_last = ref
+        known = set(int(i) for i in fids)
