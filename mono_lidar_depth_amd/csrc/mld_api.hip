@@ -219,8 +219,8 @@ struct mld_ctx {
     const uint32_t* gate_counter = nullptr;  // the counter / value this context's next projection waits for (k_gate)
     uint32_t gate_target = 0;
     bool gate_mode = true;              //   hand over through k_gate (a polling wavefront) instead of a cross-stream event
-    Calib* d_calib = nullptr;      // device copy of `calib` for k_feature_fused (fields fetched where they are used)
-    Calib calib_uploaded{};         //   what that copy holds
+    Calib* d_calib = nullptr;      // device copies of `calib` for the feature kernels (fields fetched where they are used):
+    Calib calib_uploaded[2]{};      //   [0] the context's, [1] a call's override; what the copies hold
     mld_ctx* gate_src = nullptr;        //   the context whose cls_done this context's pending gate reads (its gate_waiter is this one)
     mld_ctx* gate_waiter = nullptr;     //   the context whose pending gate reads cls_done (either may be destroyed first)    //   order_ev is recorded; the next projection launch of this context waits for it
     // mld_pair_contexts: the batched projections of two contexts share ONE stream (back to back, no cross-stream
@@ -454,6 +454,10 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     const size_t cls_fixed = (size_t)(kClsBuckets + kClsThreads / kWave + 4) * sizeof(int);
     const size_t cls_bitmap = (size_t)c.bmStride * (size_t)ctx->bm_ncolp * sizeof(uint32_t);
     ctx->classify_staged = cls_fixed + cls_bitmap <= 128 * 1024;
+#ifdef MLD_AB_SWITCHES
+    //   MLD_CLASSIFY_STAGED=0  k_classify reads the occupancy bitmap in place (4 KB of LDS per block instead of 68)
+    if (const char* e = std::getenv("MLD_CLASSIFY_STAGED")) ctx->classify_staged = ctx->classify_staged && e[0] != '0';
+#endif
     ctx->lds_classify = cls_fixed + (ctx->classify_staged ? cls_bitmap : 0);
 }
 
@@ -755,6 +759,22 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         w->order_wait_pending = true;
     }
     int rc_up = MLD_OK;
+    // The two feature kernels read the per-context constants in device memory: entry 0 = the context's own (uploaded when
+    // they change: creation, mld_set_list_capacity), entry 1 = the variant of a call that overrides them (the per-call
+    // "no road fallback" of mld_calculate_depth_opts).  `threadPath` is left out of the comparison: only k_classify -
+    // which takes its copy by value - looks at it, and the one-frame / debug routes differ from the context in nothing else.
+    const Calib* d_calib = ctx->d_calib;
+    {
+        Calib want = calib;
+        want.threadPath = ctx->calib.threadPath;
+        const int which = std::memcmp(&want, &ctx->calib, sizeof(Calib)) == 0 ? 0 : 1;
+        if (std::memcmp(&want, &ctx->calib_uploaded[which], sizeof(Calib)) != 0) {
+            // (pageable source: staged by the runtime before the call returns)
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_calib + which, &want, sizeof(Calib), hipMemcpyHostToDevice, ctx->stream));
+            ctx->calib_uploaded[which] = want;
+        }
+        d_calib = ctx->d_calib + which;
+    }
     if (calib.threadPath) {
         ScopedTimer tm(ctx, 1);
         // long lists (mld_set_list_capacity beyond the default 32 / 24: dense clouds) take the DENSE instantiation - two
@@ -767,13 +787,8 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         // for one frame in the test routes only - uploads that slot's first; batches have theirs in place, tags included:
         // the kernel never needs the map tag)
         if (single && (rc_up = upload_descs(ctx, 1, nullptr, slot, true))) return rc_up;
-        // ... and the per-context constants (uploaded when they change: creation, mld_set_list_capacity)
-        if (std::memcmp(&calib, &ctx->calib_uploaded, sizeof(Calib)) != 0) {
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_calib, &calib, sizeof(Calib), hipMemcpyHostToDevice, ctx->stream));  // (pageable: staged before the call returns)
-            ctx->calib_uploaded = calib;
-        }
         hipLaunchKernelGGL(kf, dim3((unsigned)per_slot * (unsigned)ns), dim3(kWave), ctx->lds_fused + ctx->lds_fused_pad, ctx->stream,
-                           ctx->d_slots + (single ? slot : 0), ctx->d_calib, ns, per_slot);
+                           ctx->d_slots + (single ? slot : 0), d_calib, ns, per_slot);
     }
     {
         ScopedTimer tm(ctx, 3);
@@ -785,7 +800,7 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         const int pw = std::max(1, std::min(want, std::max(4, (few ? 16384 : 4096) / ns)));
         auto kw = few ? mld::k_feature_wave<true> : mld::k_feature_wave<false>;
         hipLaunchKernelGGL(kw, dim3((unsigned)pw * (unsigned)ns), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots, one,
-                           use_single, calib, ns, pw, tag_all, chunk);
+                           use_single, d_calib, ns, pw, tag_all, chunk);
     }
     HIP_TRY(ctx, hipGetLastError());
     return MLD_OK;
@@ -996,8 +1011,8 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if ((e = hipMalloc((void**)&ctx->d_slots, sizeof(SlotDesc) * max_frames)) != hipSuccess)
         return hip_bail(e, "hipMalloc(slots)");
     if ((e = hipMalloc((void**)&ctx->dummy, 256)) != hipSuccess) return hip_bail(e, "hipMalloc(dummy)");
-    if ((e = hipMalloc((void**)&ctx->d_calib, sizeof(Calib))) != hipSuccess) return hip_bail(e, "hipMalloc(calib)");
-    std::memset(&ctx->calib_uploaded, 0xFF, sizeof(Calib));  // (nothing uploaded yet)
+    if ((e = hipMalloc((void**)&ctx->d_calib, 2 * sizeof(Calib))) != hipSuccess) return hip_bail(e, "hipMalloc(calib)");
+    std::memset(ctx->calib_uploaded, 0xFF, sizeof(ctx->calib_uploaded));  // (nothing uploaded yet)
     if ((e = hipMemsetAsync(ctx->dummy, 0, 256, ctx->stream)) != hipSuccess) return hip_bail(e, "hipMemset(dummy)");
     size_t cells = (size_t)camera->width * camera->height + kMapPadCells;
     ctx->bitmap_words = (size_t)ctx->calib.bmStride * (size_t)((camera->width + 31) / 32 + 1) + 4;  // + a slack column

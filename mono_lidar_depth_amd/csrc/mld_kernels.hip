@@ -2192,8 +2192,10 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotRef& s
 // the compiler to hoist in front of a loop and carry in spilled scalar registers)
 template <bool DIRECT>
 __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restrict__ slots, SlotDesc single, int use_single,
-                                                        Calib c, int n_slots, int per_slot, uint32_t tag_all, int chunk) {
+                                                        const Calib* __restrict__ calib, int n_slots, int per_slot,
+                                                        uint32_t tag_all, int chunk) {
     constexpr int direct = DIRECT ? 1 : 0;
+    const Calib& c = *calib;  // (in device memory, as for k_feature_fused: fields are fetched where they are used)
     extern __shared__ __align__(16) unsigned char smem[];
     int slot, j;
     decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
@@ -2389,17 +2391,23 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
         const int cx = x0 >> 5, sh = x0 & 31;
         const uint32_t colmask = (nx >= 32) ? ~0u : ((1u << nx) - 1u);
         int k = 0;
-        for (int r = 0; r < ny; r++) {
-            const int y = y0 + r;
-            uint32_t lo, hi;
-            if (STAGED) {
-                lo = lbm[y * ncolp + cx];
-                hi = lbm[y * ncolp + cx + 1];
-            } else {
-                lo = bm[(size_t)cx * c.bmStride + y];
-                hi = bm[(size_t)(cx + 1) * c.bmStride + y];
+        if (STAGED) {
+            for (int r = 0; r < ny; r++) {
+                const int y = y0 + r;
+                const uint32_t lo = lbm[y * ncolp + cx], hi = lbm[y * ncolp + cx + 1];
+                k += __popc(__builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh) & colmask);
             }
-            k += __popc(__builtin_amdgcn_alignbit(hi, lo, (uint32_t)sh) & colmask);
+        } else {
+            // in place: the rows of a word column are contiguous - four rows per 16-byte load, as the feature kernel's
+            // scan reads them (the slack behind a column covers the rows read past the window)
+            const auto* c0 = bm + (size_t)cx * c.bmStride + y0;
+            const auto* c1 = c0 + c.bmStride;
+            for (int r0 = 0; r0 < ny; r0 += 4) {
+                const u32x4u a = *GPTR(u32x4u, c0 + r0), b = *GPTR(u32x4u, c1 + r0);
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (r0 + q < ny) k += __popc(__builtin_amdgcn_alignbit(b[q], a[q], (uint32_t)sh) & colmask);
+            }
         }
         return k;
     };

@@ -136,3 +136,57 @@ def test_many_features_in_one_call():
     road = t2 == 16
     assert np.array_equal(d2[~road], d[sel][~road])
     assert np.abs(d2[road] - d[sel][road]).max() < 1e-9
+
+
+def _batch_against_oracle(P, cam, est, clouds, planes, uvs):
+    import torch
+    dev = torch.device("cuda:0")
+    B, F = len(clouds), uvs[0].shape[0]
+    masks = []
+    for p, c in zip(planes, clouds):
+        m = np.zeros((c.shape[0] + 31) // 32, dtype=np.uint32)
+        np.bitwise_or.at(m, p[1] >> 5, (np.uint32(1) << (p[1] & 31).astype(np.uint32)))
+        masks.append(torch.from_numpy(m.view(np.int32)).to(dev))
+    d = [torch.full((F,), float("nan"), dtype=torch.float64, device=dev) for _ in range(B)]
+    t = [torch.full((F,), -77, dtype=torch.int32, device=dev) for _ in range(B)]
+    b = est.prepareBatch([torch.from_numpy(c).to(dev) for c in clouds], [torch.from_numpy(u).to(dev) for u in uvs], d, t,
+                         np.stack([p[0] for p in planes]), masks)
+    est.runBatch(b)
+    est.synchronize()
+    for i in range(B):
+        _, (d0, t0) = run_oracle(P, clouds[i], uvs[i], planes[i], camera=cam)
+        assert_depth_parity(d[i].cpu().numpy(), t[i].cpu().numpy(), d0, t0)
+    return t
+
+
+def test_classification_reads_a_large_image_bitmap_in_place():
+    """An image whose occupancy bitmap (345 KB) does not fit the LDS of a classification block: k_classify reads the
+    bitmap where it lies (16-byte loads of four rows, as the feature kernel's scan) - batches against the oracle."""
+    W, H = 2600, 1000
+    P = capi.params_c0()
+    cam = CameraPinhole(W, H, 1500.0, W / 2.0 + 3.5, H / 2.0 - 7.25)
+    clouds = [synth.make_cloud(synth.DENSE128, seed=57, frame=f) for f in range(3)]  # (dense: neighbours at this resolution)
+    planes = [synth.make_ground_plane(c) for c in clouds]
+    rng = np.random.default_rng(57)
+    uvs = [np.stack([rng.uniform(-5, W + 5, 3000), rng.uniform(H * 0.4, H + 5, 3000)], axis=1) for _ in clouds]
+    est = make_estimator(P, camera=cam, max_frames=3, max_features=3000)
+    t = _batch_against_oracle(P, cam, est, clouds, planes, uvs)
+    seen = set(int(x) for x in np.unique(np.concatenate([x.cpu().numpy() for x in t])))
+    assert 2 in seen and len(seen) >= 4, seen   # dead features and several live outcomes
+    est.close()
+
+
+def test_classification_in_place_equals_staged(monkeypatch):
+    """The same in-place classification forced for a KITTI-size image (test build: MLD_CLASSIFY_STAGED=0): every class
+    boundary of k_classify - dead, live, long lists, windows clipped by the image border - against the oracle."""
+    monkeypatch.setenv("MLD_CLASSIFY_STAGED", "0")
+    monkeypatch.setattr(capi, "_lib", capi.load_ab())
+    P = capi.params_c0()
+    cam = kitti_camera()
+    clouds = [synth.make_cloud(sc, seed=58, frame=f) for f, sc in enumerate((synth.HDL64_KITTI, synth.DENSE128, synth.VLP16))]
+    planes = [synth.make_ground_plane(c) for c in clouds]
+    rng = np.random.default_rng(58)
+    uvs = [np.stack([rng.uniform(-3, synth.KITTI_W + 3, 4000), rng.uniform(-3, synth.KITTI_H + 3, 4000)], axis=1) for _ in clouds]
+    est = make_estimator(P, max_frames=3, max_features=4000)
+    _batch_against_oracle(P, cam, est, clouds, planes, uvs)
+    est.close()
