@@ -24,6 +24,7 @@ The JSON line also carries
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -930,11 +931,11 @@ def config5_leg(cam, T, device, n_frames):
                                                   t_cur.data_ptr(), t_last.data_ptr(), None))
 
     slot = 0
+    est.timingEnable(True)  # (the timers' events are created during the warm-up, not inside the timed loop)
     for it in range(6):
         frame(it, slot, it > 0)
         slot = 1 - slot
     est.synchronize()
-    est.timingEnable(True)
     est.timingReset()
     t0 = time.perf_counter()
     for it in range(6, 6 + n_frames):
@@ -970,7 +971,7 @@ def config5_leg(cam, T, device, n_frames):
     }
 
 
-def config5_batched_leg(cam, T, device, S, steps=6):
+def config5_batched_leg(cam, T, device, S, steps=6, two_contexts=False):
     """BASELINE config 5 at batch size: the current frames of S independent sequences (128x4096 cloud, 10 000 tracks, 10 %
     new) per step through mld_set_clouds_planes_range_device + mld_tracklets_depths_device; every sequence's previous
     frame stays resident in the other bank of slots.  Distinct HBM per slot; checked per sequence against the oracle."""
@@ -1023,23 +1024,69 @@ def config5_batched_leg(cam, T, device, S, steps=6):
 
     prep = prepared(tb, d_cur, d_last, t_cur, t_last)
     torch.cuda.synchronize()
-    for it in range(3):
+    # (warm-up WITH the kernel timers on and as long as the timed loop: the hipEvents they record exist afterwards)
+    tb.est.timingEnable(True)
+    warm = steps + (steps & 1) + 1  # (odd: the timed loop starts on the other bank)
+    for it in range(warm):
         tb.run(prep[it % 2])
     tb.est.synchronize()
-    tb.est.timingEnable(True)
     tb.est.timingReset()
     t0 = time.perf_counter()
-    for it in range(3, 3 + steps):
+    for it in range(warm, warm + steps):
         tb.run(prep[it % 2])
     tb.est.synchronize()
     el = time.perf_counter() - t0
     kt = kernel_times(tb.est)
     tb.est.timingEnable(False)
-    # (No two-context schedule here: the DENSE instantiation of the feature kernel takes the whole register file - two
-    # wavefronts of 256 registers per SIMD -, there is nothing left for another context's projection wavefronts to run in.
-    # Rounds 3-4 measured the alternating pair for this config with the 168-register kernel: 0.6-1.6 ms per 64-sequence
-    # step from run to run, slower than one context on average.)
-    last_b = (3 + steps - 1) % 2  # data set of the last frame the context processed
+    last_b = (warm + steps - 1) % 2  # data set of the last frame the context processed
+    # Two contexts in turn (a second set of S sequences - here the same resident clouds and tracks, own frame slots and
+    # outputs): each step still is the current frames of S sequences, but its projection runs beside the other set's feature
+    # kernel - the schedule of the config-2 bench, with the 168-register dense instantiation of the feature kernel (DENSE 1).
+    two = None
+    if two_contexts:
+        d2c, d2l = torch.empty_like(d_cur), torch.zeros_like(d_last)
+        t2c, t2l = torch.empty_like(t_cur), torch.zeros_like(t_last)
+        tb2 = TrackletBatch(P, cam, T, S, n_tracks, device=device, list_capacity=(48, 24))
+        for x in (tb, tb2):
+            x.est.setSharedGpu(1)
+        prep2 = prepared(tb2, d2c, d2l, t2c, t2l)
+        pair = [(tb, prep), (tb2, prep2)]
+        torch.cuda.synchronize()
+        two = {}
+        for ho in ("classify",):
+            n2 = 2 * steps
+            for x in (tb, tb2):
+                x.est.timingEnable(True)
+            for it in range(n2):  # (a whole repetition's worth)
+                x, pr = pair[it % 2]
+                x.run(pr[(it // 2) % 2], pair[(it + 1) % 2][0], ho)
+            reps, kts, submit = [], [], []
+            for _ in range(5):
+                for x in (tb, tb2):
+                    x.est.synchronize()
+                    x.est.timingReset()
+                t0 = time.perf_counter()
+                for it in range(n2, 2 * n2):
+                    x, pr = pair[it % 2]
+                    x.run(pr[(it // 2) % 2], pair[(it + 1) % 2][0], ho)
+                submit.append(time.perf_counter() - t0)
+                for x in (tb, tb2):
+                    x.est.synchronize()
+                reps.append(time.perf_counter() - t0)
+                kts.append(kernel_times([tb.est, tb2.est]))
+            el2 = float(np.median(reps))
+            kt2 = kts[int(np.argsort(reps)[len(reps) // 2])]
+            for x in (tb, tb2):
+                x.est.timingEnable(False)
+            two[ho] = {"ms_per_step": 1e3 * el2 / n2, "associations_per_s": (n_tracks + n_tracks // 10) * S * n2 / el2,
+                       "ms_per_step_runs": [1e3 * r / n2 for r in reps],
+                       "submit_ms_per_step_runs": [1e3 * r / n2 for r in submit],
+                       "kernels_ms_per_launch_runs": [{k: round(v["avg_ms"], 4) for k, v in kt_.items()} for kt_ in kts],
+                       "kernels_ms_per_launch": {k: v["avg_ms"] for k, v in kt2.items()}}
+        last_b = ((2 * n2 - 2) // 2) % 2  # (the first context's last step in this phase)
+        tb.est.setSharedGpu(0)
+        two["second_context_equals_first"] = bool(torch.equal(t2c, t_cur) and torch.equal(d2c, d_cur))
+        tb2.close()
     # the last step's bank against the oracle: EVERY sequence, both slots (the sequences cycle through a few distinct
     # (current cloud, previous cloud, track set) combinations, each of which the oracle computes once)
     b = last_b
@@ -1074,7 +1121,9 @@ def config5_batched_leg(cam, T, device, S, steps=6):
             "roofline": config_roofline(f"5b{S}", kt, S),
             "roofline_project": {"design_bytes_per_launch": db["bytes"] * S, "kernel_ms": pms,
                                  "frac": db["bytes"] * S / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS if pms > 0 else None},
-            "sequences_checked": S, "distinct_oracle_cases": len(expect), "mismatching_sequences": bad_seq[:32], "verified": ok}
+            "two_contexts": two,
+            "sequences_checked": S, "distinct_oracle_cases": len(expect), "mismatching_sequences": bad_seq[:32],
+            "verified": ok and (two is None or two["second_context_equals_first"])}
 
 
 # ------------------------------------------------------------------------------------------------ worker
@@ -1086,6 +1135,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # No cyclic garbage collection while legs are timed (a full collection of this process's heap is milliseconds on the
+    # submitting thread, a step of the short legs 0.2-0.4 ms); reference counting frees everything the legs allocate.
+    # (Not what made the S = 64 two-context leg of rounds 4 and 5 bimodal - that was a DMA queue being set up inside a
+    # hipMemcpyAsync of the step's descriptors, LAB.md 5.16; `submit_ms_per_step_runs` is the host-side check for either.)
+    gc.disable()
     # Host placement first - before torch is imported, before the first GPU call and before any pinned buffer exists: the
     # rank's threads and its staging memory belong on the NUMA node of ITS GPU (sysfs only; nothing is re-executed).
     affinity = None
@@ -1132,12 +1186,13 @@ def main():
         elif args.only_config == 3:
             leg = config3_leg(cam, T, gpu_index, args.config_frames, only_near=args.leg == "near")
         elif args.leg:
-            S5 = int(args.leg)
-            leg = {"workload": "BASELINE config 5, batched leg only", "batched": {str(S5): config5_batched_leg(cam, T, gpu_index, S5)}}
+            S5 = int(args.leg.rstrip("t"))  # ("256t": with the two-context schedule as well)
+            leg = {"workload": "BASELINE config 5, batched leg only",
+                   "batched": {str(S5): config5_batched_leg(cam, T, gpu_index, S5, two_contexts=args.leg.endswith("t"))}}
             leg["verified"] = leg["batched"][str(S5)]["verified"]
         else:
             leg = config5_leg(cam, T, gpu_index, min(args.config_frames, 200))
-            leg["batched"] = {str(S5): config5_batched_leg(cam, T, gpu_index, S5) for S5 in (16, 64, 256)}
+            leg["batched"] = {str(S5): config5_batched_leg(cam, T, gpu_index, S5, two_contexts=True) for S5 in (16, 64, 256)}
             leg["verified"] = bool(leg["verified"] and all(v["verified"] for v in leg["batched"].values()))
         print(json.dumps({"config": str(args.only_config), **leg}), flush=True)
         sys.exit(0 if leg.get("verified") else 1)
@@ -1462,7 +1517,7 @@ def main():
         torch.cuda.empty_cache()
         configs["3"] = config3_leg(cam, T, gpu_index, args.config_frames)
         configs["5"] = config5_leg(cam, T, gpu_index, min(args.config_frames, 200))
-        configs["5"]["batched"] = {str(S5): config5_batched_leg(cam, T, gpu_index, S5) for S5 in (16, 64, 256)}
+        configs["5"]["batched"] = {str(S5): config5_batched_leg(cam, T, gpu_index, S5, two_contexts=True) for S5 in (16, 64, 256)}
         configs["5"]["verified"] = bool(configs["5"]["verified"] and
                                         all(v["verified"] for v in configs["5"]["batched"].values()))
 

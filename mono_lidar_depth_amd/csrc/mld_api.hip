@@ -235,6 +235,17 @@ struct mld_ctx {
     bool timing = false;
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
+    // Small host -> device uploads of a step (slot and sequence descriptors, constants) leave from a ring of pinned
+    // generations owned by the context and are moved by a kernel (k_upload), not by hipMemcpyAsync: with several such
+    // copies in flight the runtime spreads them over further DMA engines, and the first copy on an engine sets its queue up
+    // - ~6 ms inside that hipMemcpyAsync on the submitting thread, once or twice somewhere in a run of short steps
+    // (LAB.md 5.16: the "bimodal" legs of rounds 4 and 5).
+    static constexpr int kUpGens = 16;
+    unsigned char* up_base = nullptr;
+    size_t up_gen_bytes = 0;
+    int up_next = 0;
+    hipEvent_t up_ev[kUpGens] = {};
+    bool up_busy[kUpGens] = {};
 };
 
 namespace {
@@ -696,6 +707,28 @@ int ensure_queues(mld_ctx* ctx, Slot& s, int64_t F) {
 
 int upload_descs(mld_ctx* ctx, int n_slots, hipStream_t st = nullptr, int first = 0, bool tags_in_descs = false);
 
+// `bytes` of host memory to `dst` on `st` through the context's pinned ring (see mld_ctx::up_base): `src` may be rewritten
+// as soon as this returns; the call waits only when the host runs kUpGens uploads ahead of the device.
+int upload_small(mld_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st) {
+    static_assert(sizeof(SlotDesc) % 4 == 0 && sizeof(TrkSeq) % 4 == 0 && sizeof(Calib) % 4 == 0, "k_upload moves 32-bit words");
+    if (!bytes) return MLD_OK;
+    if (bytes % 4) return fail(ctx, MLD_ERR_INVALID_ARG, "upload_small: size not a multiple of 4");
+    if (bytes > ctx->up_gen_bytes) return fail(ctx, MLD_ERR_CAPACITY, "upload_small: table larger than the context's upload ring");
+    const int g = ctx->up_next;
+    if (ctx->up_busy[g]) HIP_TRY(ctx, hipEventSynchronize(ctx->up_ev[g]));
+    if (!ctx->up_ev[g]) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->up_ev[g], hipEventDisableTiming));
+    unsigned char* stage = ctx->up_base + (size_t)g * ctx->up_gen_bytes;
+    std::memcpy(stage, src, bytes);
+    const int words = (int)(bytes / 4);  // (every table is made of 4- and 8-byte fields)
+    hipLaunchKernelGGL(mld::k_upload, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, reinterpret_cast<uint32_t*>(dst),
+                       reinterpret_cast<const uint32_t*>(stage), words);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->up_ev[g], st));
+    ctx->up_busy[g] = true;
+    ctx->up_next = (g + 1) % mld_ctx::kUpGens;
+    return MLD_OK;
+}
+
 // k_classify (per slot) -> k_feature_fused over the live queues -> k_feature_wave over the overflow queues.
 // k_classify sets both queue lengths, so no counter needs clearing.
 int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int slot, const Calib* override_calib = nullptr) {
@@ -770,19 +803,22 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         const int which = std::memcmp(&want, &ctx->calib, sizeof(Calib)) == 0 ? 0 : 1;
         if (std::memcmp(&want, &ctx->calib_uploaded[which], sizeof(Calib)) != 0) {
             // (pageable source: staged by the runtime before the call returns)
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_calib + which, &want, sizeof(Calib), hipMemcpyHostToDevice, ctx->stream));
+            int rc_c = upload_small(ctx, ctx->d_calib + which, &want, sizeof(Calib), ctx->stream);
+            if (rc_c) return rc_c;
             ctx->calib_uploaded[which] = want;
         }
         d_calib = ctx->d_calib + which;
     }
     if (calib.threadPath) {
         ScopedTimer tm(ctx, 1);
-        // long lists (mld_set_list_capacity beyond the default 32 / 24: dense clouds) take the DENSE instantiation - two
+        // long lists (mld_set_list_capacity beyond the default 32 / 24: dense clouds) take a DENSE instantiation: 2 = two
         // wavefronts per SIMD, which is what their LDS allows anyway, and the registers of the third for the in-register
-        // corner search; never in the shared-GPU mode, whose point is to leave registers to the other context's projection
-        const bool dense = !(ctx->shared_arg & 1) && (calib.k1max > 32 || calib.kMain > 24);
-        auto kf = dense ? (calib.roadMode ? mld::k_feature_fused<1, true> : mld::k_feature_fused<0, true>)
-                        : (calib.roadMode ? mld::k_feature_fused<1, false> : mld::k_feature_fused<0, false>);
+        // corner search (up to 24 points); 1 = in the shared-GPU mode, whose point is to leave registers to the other
+        // context's projection: the same within 168 registers (corner search up to 16 points)
+        const int dense = (calib.k1max > 32 || calib.kMain > 24) ? ((ctx->shared_arg & 1) ? 1 : 2) : 0;
+        auto kf = dense == 2 ? (calib.roadMode ? mld::k_feature_fused<1, 2> : mld::k_feature_fused<0, 2>)
+                  : dense == 1 ? (calib.roadMode ? mld::k_feature_fused<1, 1> : mld::k_feature_fused<0, 1>)
+                               : (calib.roadMode ? mld::k_feature_fused<1, 0> : mld::k_feature_fused<0, 0>);
         // the kernel reads its slot descriptors in device memory (a single-slot call - the lane-per-feature kernel runs
         // for one frame in the test routes only - uploads that slot's first; batches have theirs in place, tags included:
         // the kernel never needs the map tag)
@@ -821,10 +857,7 @@ int upload_descs(mld_ctx* ctx, int n_slots, hipStream_t st, int first, bool tags
         }
     }
     if (!dirty) return MLD_OK;
-    // pageable source: the runtime stages it before returning, so h_descs may be rewritten afterwards
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slots + first, ctx->h_descs.data() + first, sizeof(SlotDesc) * n_slots,
-                                hipMemcpyHostToDevice, st));
-    return MLD_OK;
+    return upload_small(ctx, ctx->d_slots + first, ctx->h_descs.data() + first, sizeof(SlotDesc) * n_slots, st);
 }
 
 int precheck_calc(mld_ctx* ctx, Slot& s, int64_t F) {
@@ -997,10 +1030,12 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
         if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute(k_classify)");
     }
     if (ctx->lds_fused > 48 * 1024) {
-        const void* fused[] = {reinterpret_cast<const void*>(mld::k_feature_fused<0, false>),
-                               reinterpret_cast<const void*>(mld::k_feature_fused<1, false>),
-                               reinterpret_cast<const void*>(mld::k_feature_fused<0, true>),
-                               reinterpret_cast<const void*>(mld::k_feature_fused<1, true>)};
+        const void* fused[] = {reinterpret_cast<const void*>(mld::k_feature_fused<0, 0>),
+                               reinterpret_cast<const void*>(mld::k_feature_fused<1, 0>),
+                               reinterpret_cast<const void*>(mld::k_feature_fused<0, 1>),
+                               reinterpret_cast<const void*>(mld::k_feature_fused<1, 1>),
+                               reinterpret_cast<const void*>(mld::k_feature_fused<0, 2>),
+                               reinterpret_cast<const void*>(mld::k_feature_fused<1, 2>)};
         for (const void* f : fused) {
             e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_fused);
             if (e != hipSuccess) return hip_bail(e, "hipFuncSetAttribute(k_feature_fused)");
@@ -1013,6 +1048,10 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if ((e = hipMalloc((void**)&ctx->dummy, 256)) != hipSuccess) return hip_bail(e, "hipMalloc(dummy)");
     if ((e = hipMalloc((void**)&ctx->d_calib, 2 * sizeof(Calib))) != hipSuccess) return hip_bail(e, "hipMalloc(calib)");
     std::memset(ctx->calib_uploaded, 0xFF, sizeof(ctx->calib_uploaded));  // (nothing uploaded yet)
+    // the upload ring at its working size now (pinning costs milliseconds): a step's largest upload is its descriptors
+    ctx->up_gen_bytes = (std::max(sizeof(SlotDesc) * (size_t)max_frames, sizeof(Calib)) + 4095) / 4096 * 4096;
+    if ((e = hipHostMalloc((void**)&ctx->up_base, ctx->up_gen_bytes * mld_ctx::kUpGens, hipHostMallocDefault)) != hipSuccess)
+        return hip_bail(e, "hipHostMalloc(upload ring)");
     if ((e = hipMemsetAsync(ctx->dummy, 0, 256, ctx->stream)) != hipSuccess) return hip_bail(e, "hipMemset(dummy)");
     size_t cells = (size_t)camera->width * camera->height + kMapPadCells;
     ctx->bitmap_words = (size_t)ctx->calib.bmStride * (size_t)((camera->width + 31) / 32 + 1) + 4;  // + a slack column
@@ -1134,6 +1173,9 @@ void mld_destroy(mld_ctx* ctx) {
         (void)hipEventDestroy(t.e1);
     }
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->up_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->up_base) (void)hipHostFree(ctx->up_base);
     if (ctx->stream && ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1398,7 +1440,7 @@ int mld_set_clouds_estimate_planes_device(mld_ctx* ctx, int n_slots, const void*
     // occupancy bitmaps and inlier masks of the batch: one fill each
     HIP_TRY(ctx, hipMemsetAsync(ctx->bitmaps, 0, ctx->bitmap_words * (size_t)n_slots * sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(ctx->rsb_masks, 0, ctx->rsb_mask_words * (size_t)n_slots * sizeof(uint32_t), st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->rsb_seeds, seeds, (size_t)n_slots * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    if ((rc = upload_small(ctx, ctx->rsb_seeds, seeds, (size_t)n_slots * sizeof(uint32_t), st))) return rc;
     const bool maps_cleared = clear_maps_on_common_wrap(ctx, 0, n_slots, st, rc);
     if (rc) return rc;
     for (int i = 0; i < n_slots; i++) {
@@ -2595,8 +2637,7 @@ int mld_tracklets_depths_device(mld_ctx* ctx, int n_seq, int bank_cur, int have_
         sl.d.type = type_last;
         if (have_last && (rc = ensure_queues(ctx, sl, t.n))) return rc;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->trkb_desc, ctx->trkb_host.data(), (size_t)n_seq * sizeof(TrkSeq), hipMemcpyHostToDevice,
-                                ctx->stream));
+    if ((rc = upload_small(ctx, ctx->trkb_desc, ctx->trkb_host.data(), (size_t)n_seq * sizeof(TrkSeq), ctx->stream))) return rc;
     const unsigned chunks = (unsigned)((max_n + kTrkBlock - 1) / kTrkBlock);
     hipLaunchKernelGGL(k_tracklets_gather, dim3(chunks, (unsigned)n_seq), dim3(kTrkBlock), 0, ctx->stream, ctx->trkb_desc);
     HIP_TRY(ctx, hipGetLastError());

@@ -2058,7 +2058,7 @@ __device__ __forceinline__ void main_hist(const Calib& c, const SlotRef& s, uint
 
 // Second half: CalculateDepthSegmented (DepthEstimator.cpp:903-1037) on the segmented list: corner selection (max
 // spanning triangle / first three points / PCA moments), planarity, ray-plane intersection, thresholds.
-template <bool DENSE>
+template <int DENSE>
 __device__ __forceinline__ void main_tail(const Calib& c, const SlotRef& s, uint32_t* lst, const int lane, const int lcap,
                                           const int ks_in,
                                           bool live, const double minZ, const double maxZ, const double myu,
@@ -2084,7 +2084,10 @@ __device__ __forceinline__ void main_tail(const Calib& c, const SlotRef& s, uint
         V3 c1, c2, c3;
         bool ok;
         const int ksmax = uniform(wave_max_i32(live ? ks : 0));
-        if (!DENSE || ksmax <= kTriSmall || ksmax > kTriHuge) {
+        // (DENSE 2: tiers up to 24 points; DENSE 1 - the dense kernel beside another context's projection, 168 registers -
+        // up to 16; the default instantiation 8)
+        constexpr int kTop = DENSE == 2 ? kTriHuge : (DENSE == 1 ? kTriLarge : kTriSmall);
+        if (ksmax <= kTriSmall || ksmax > kTop) {
             ok = triangle_small<kTriSmall>(c, s, ks, live && ks <= kTriSmall, lst, lane, lcap, c1, c2, c3);
             if (ksmax > kTriSmall) {  // longer segmented lists: the generic serial loops
                 V3 d1, d2, d3;
@@ -2101,7 +2104,7 @@ __device__ __forceinline__ void main_tail(const Calib& c, const SlotRef& s, uint
         } else if (ksmax <= kTriLarge) {
             ok = triangle_small<DENSE ? kTriLarge : 1>(c, s, ks, live, lst, lane, lcap, c1, c2, c3);
         } else {
-            ok = triangle_small<DENSE ? kTriHuge : 1>(c, s, ks, live, lst, lane, lcap, c1, c2, c3);
+            ok = triangle_small<DENSE == 2 ? kTriHuge : 1>(c, s, ks, live, lst, lane, lcap, c1, c2, c3);
         }
         if (live && !ok) {
             mytype = MLD_TriangleNotPlanarInsufficientPoints;
@@ -2160,7 +2163,7 @@ __device__ __forceinline__ void main_tail(const Calib& c, const SlotRef& s, uint
     ST_MARK(11);
 }
 
-template <bool DENSE>
+template <int DENSE>
 __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotRef& s, uint32_t* lst, const int lane,
                                                 const int lcap, const int k, bool live, const double myu, const double myv,
                                                 int& mytype, double& mydepth, bool& overflow ST_ARG) {
@@ -2169,10 +2172,10 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotRef& s
     // (DENSE: a wavefront whose longest list exceeds the first tier keeps 16 / 24 depths in registers - one memory round
     // trip for the depths instead of three passes of four-entry round trips over the tail)
     const int kmax0 = DENSE ? uniform(wave_max_i32(live ? k : 0)) : 0;
-    if (DENSE && kmax0 > kZcDefault && kmax0 <= kZcMid)
+    if (DENSE && kmax0 > kZcDefault && (kmax0 <= kZcMid || DENSE == 1))
         main_hist<DENSE ? kZcMid : kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
-    else if (DENSE && kmax0 > kZcMid)
-        main_hist<DENSE ? kZcDense : kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
+    else if (DENSE == 2 && kmax0 > kZcMid)
+        main_hist<DENSE == 2 ? kZcDense : kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
     else
         main_hist<kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
     main_tail<DENSE>(c, s, lst, lane, lcap, ks, live, minZ, maxZ, myu, myv, mytype, mydepth, overflow ST_PASS);
@@ -2544,6 +2547,13 @@ __global__ __launch_bounds__(kWave) void k_gate(const uint32_t* __restrict__ cou
     }
 }
 
+// A step's small tables (slot / sequence descriptors, constants) from the context's pinned host block to device memory,
+// in stream order, by load / store: no DMA engine takes part (see upload_small in mld_api.hip).
+__global__ __launch_bounds__(256) void k_upload(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src_host, int n_words) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_words) dst[i] = __builtin_nontemporal_load(src_host + i);
+}
+
 #ifndef MLD_KEY_BATCH_F
 #define MLD_KEY_BATCH_F 8
 #endif
@@ -2686,8 +2696,10 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef
 // all the LDS of such lists allows - and therefore up to 256 registers, which the in-register corner search of main_tail
 // uses.  The other instantiation keeps to 168 registers: three wavefronts per SIMD alone, or two beside the projection
 // wavefronts of another context (mld_set_shared_gpu).
-template <int ROAD_MODE, bool DENSE>
-__global__ __launch_bounds__(kWave, DENSE ? 2 : MLD_FUSED_WAVES) MLD_FUSED_ATTR void k_feature_fused(const SlotDesc* __restrict__ slots,
+// DENSE = 1: the same kernel for long lists within 168 registers (three wavefronts per SIMD's worth: tiers up to 16 points /
+// 16 depths), for the shared-GPU mode - it leaves a third of the register file to the other context's projection.
+template <int ROAD_MODE, int DENSE>
+__global__ __launch_bounds__(kWave, DENSE == 2 ? 2 : MLD_FUSED_WAVES) MLD_FUSED_ATTR void k_feature_fused(const SlotDesc* __restrict__ slots,
                                                          const Calib* __restrict__ calib, int n_slots, int per_slot) {
     extern __shared__ __align__(16) unsigned char smem[];
     // The per-context constants stay in device memory as well (mld_ctx::d_calib): a field is fetched by a scalar load

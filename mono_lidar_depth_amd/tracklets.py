@@ -191,7 +191,7 @@ class TrackletBatch:
                 "keep": (list(clouds), list(masks), list(u_new), list(v_new), list(u_old), list(v_old), list(is_new),
                          list(d_cur), list(d_last), t_cur, t_last)}
 
-    def run(self, f, nxt: Optional["TrackletBatch"] = None):
+    def run(self, f, nxt: Optional["TrackletBatch"] = None, handover: str = "projection"):
         """One frame of every sequence from prepared tables: projection of the current bank, then the tracklet call.
         `nxt`: another TrackletBatch (other sequences) that takes the next step - it is released as soon as this
         projection has finished, so that its projection runs beside these feature kernels (include/mld.h "Two contexts")."""
@@ -199,7 +199,11 @@ class TrackletBatch:
         est._check(lib.mld_set_clouds_planes_range_device(est._ctx, self.bank * S, S, f["clouds"], f["n"], 16,
                                                           f["coeffs"].ctypes.data_as(C.POINTER(C.c_float)), f["masks"]))
         if nxt is not None and nxt is not self:
-            nxt.est.orderAfter(est)
+            # (released at the end of this projection, or behind this step's classification kernel: include/mld.h)
+            if handover == "classify":
+                nxt.est.orderAfterClassify(est)
+            else:
+                nxt.est.orderAfter(est)
         est._check(lib.mld_tracklets_depths_device(est._ctx, S, self.bank, 1 if self.have_last else 0, f["u_new"], f["v_new"],
                                                    f["u_old"], f["v_old"], f["is_new"], f["nt"], f["d_cur"], f["d_last"],
                                                    f["t_cur"], f["t_last"]))

@@ -155,3 +155,63 @@ def test_tracklet_batch_of_sequences_equals_the_oracle_per_sequence():
             known[s] = set(int(i) for i in ids)
             ids_prev[s], ref_last[s] = ids, ref_cur
     tb.close()
+
+
+def test_tracklet_batch_far_ahead_of_the_device_equals_step_by_step():
+    """The step's descriptor tables leave through a ring of pinned generations (mld_api.hip upload_small); a host that
+    queues 45 steps without waiting laps that ring three times.  Every step's outputs (own arrays per step) must equal
+    those of the same steps submitted one at a time."""
+    import torch
+    from mono_lidar_depth_amd import TrackletBatch
+    P = capi.params_c0()
+    cam = kitti_camera()
+    dev = torch.device("cuda:0")
+    S, n_tracks, steps = 3, 1500, 45
+    rng = np.random.default_rng(23)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+
+    def mask_of(inl, n):
+        m = np.zeros((n + 31) // 32, dtype=np.uint32)
+        np.bitwise_or.at(m, inl >> 5, (np.uint32(1) << (inl & 31).astype(np.uint32)))
+        return torch.from_numpy(m.view(np.int32)).to(dev)
+
+    frames = []  # three distinct frames of every sequence, cycled
+    for k in range(3):
+        per = []
+        for s in range(S):
+            cloud = synth.make_cloud([synth.HDL64_KITTI, synth.VLP16, synth.DENSE128][s], seed=70 + s, frame=2 * k)
+            coeffs, inl = synth.make_ground_plane(cloud)
+            _, u0, v0, u1, v1 = _tracks(rng, None, n_tracks, 0.10, cam.width, cam.height)
+            per.append((to(cloud), coeffs, mask_of(inl, cloud.shape[0]), to(u0), to(v0), to(u1), to(v1),
+                        to((rng.random(n_tracks) < 0.1).astype(np.uint8))))
+        frames.append(per)
+
+    def run_all(wait_every_step):
+        tb = TrackletBatch(P, cam, synth.T_CAM_LIDAR, S, n_tracks, list_capacity=(48, 24))
+        outs, preps = [], []
+        for it in range(steps):
+            per = frames[it % 3]
+            o = ([torch.empty(n_tracks, dtype=torch.float32, device=dev) for _ in range(S)],
+                 [torch.full((n_tracks,), float("nan"), dtype=torch.float32, device=dev) for _ in range(S)],
+                 [torch.empty(n_tracks, dtype=torch.int32, device=dev) for _ in range(S)],
+                 [torch.zeros(n_tracks, dtype=torch.int32, device=dev) for _ in range(S)])
+            outs.append(o)
+            preps.append(tb.prepare([p[0] for p in per], np.stack([p[1] for p in per]), [p[2] for p in per],
+                                    [p[3] for p in per], [p[4] for p in per], [p[5] for p in per], [p[6] for p in per],
+                                    [p[7] for p in per], *o))
+        torch.cuda.synchronize()
+        tb.est._after_torch(frames[0][0][0])
+        for it in range(steps):
+            tb.run(preps[it])
+            if wait_every_step:
+                tb.est.synchronize()
+        tb.est.synchronize()
+        res = [[t.cpu().numpy() for group in o for t in group] for o in outs]
+        tb.close()
+        return res
+
+    ahead, stepwise = run_all(False), run_all(True)
+    for it in range(steps):
+        for a, b in zip(ahead[it], stepwise[it]):
+            assert np.array_equal(a, b, equal_nan=True), it
+    assert (ahead[-1][0] > 0).sum() > 100  # (depths were found)
