@@ -215,9 +215,10 @@ int mld_set_shared_gpu(mld_ctx* ctx, int shared);
  * for 64-beam clouds (config 2: 11 / 2.3 neighbours on average).  Dense clouds (128 beams x 4096: 16 / 6 on average, 48
  * at most in the road window) want 48 / 24: BASELINE config 5 at batch size runs 1.8x faster with it.  LDS per wavefront
  * = (wide + narrow) * 256 bytes.  8 <= narrow <= wide <= 64.  Capacities beyond the default also select the kernel's
- * DENSE instantiation (unless mld_set_shared_gpu is on): two wavefronts per SIMD - all that much LDS allows - and the
- * corner search of up to 24 segmented points, the histogram depths of up to 24 neighbours in registers (config 5 at 256
- * sequences per step: 1.12 -> 1.8 G associations/s).
+ * DENSE instantiations: the corner search over the segmented points and the histogram's depths in registers - up to 24 of
+ * each at two wavefronts per SIMD when the context has the GPU to itself, up to 16 inside 168 registers when
+ * mld_set_shared_gpu is on, so that another context's projection finds room beside it (config 5 at 256 sequences per
+ * step: 1.12 G associations/s in round 4 -> 1.85 G with one context, 1.98 G with two in turn).
  */
 int mld_set_list_capacity(mld_ctx* ctx, int wide_entries, int narrow_entries);
 
