@@ -117,3 +117,18 @@ def test_bench_schedules_agree():
     # (result types are summed over the output sets: two with the default schedule, one otherwise)
     assert b["result_types"] == c["result_types"]
     assert a["result_types_output_sets"] == 2 and a["result_types"] == {k: 2 * v for k, v in c["result_types"].items()}
+
+
+def test_bench_dense_leg_two_contexts_is_verified_and_steady():
+    """Config 5 (dense clouds, tracklet layer) with two sets of sequences in turn: every sequence of the last step equals the
+    oracle, the second set's outputs equal the first's, and the five repetitions agree - the 2x outliers of rounds 4-5 were
+    a host stall (profiles/r5_host_stall.md); the host-side submit time per repetition is reported so that one would show."""
+    out = _run(["--only-config", "5", "--leg", "16t"])
+    leg = out["batched"]["16"] if "batched" in out else out["configs"]["5"]["batched"]["16"]
+    assert leg["verified"] is True and leg["sequences_checked"] == 16 and leg["mismatching_sequences"] == []
+    two = leg["two_contexts"]
+    assert two["second_context_equals_first"] is True
+    runs, submit = two["classify"]["ms_per_step_runs"], two["classify"]["submit_ms_per_step_runs"]
+    assert len(runs) == 5 and max(runs) <= 1.25 * min(runs), runs
+    assert max(submit) < min(runs), (submit, runs)   # the host stays ahead of the device in every repetition
+    assert two["classify"]["ms_per_step"] < leg["ms_per_step"] * 1.05   # (two sets in turn are not slower than one)
