@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profiles bench.py under rocprofv3 on the GPU box (invoke through gpurun from the repo root):
-#   gpurun -- 'bash profiles/run_profile.sh r3'
+#   gpurun -- 'bash profiles/run_profile.sh r5'            (or: ... r5 latency)
 # Writes raw output under gpurun_out/prof_<tag>/; profiles/summarize.py condenses it into profiles/<tag>_*.
 TAG=${1:-r5}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -9,6 +9,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 COMMON="--cpu-seconds 0 --latency-frames 0 --streaming-batches 0 --config-frames 0"
 ARGS="--steps 200 --warmup 5 --repeats 1 $COMMON"
+# (second argument "latency": only the one-frame legs are re-run, the rest of gpurun_out/prof_<tag>/ is kept)
+ONLY=${2:-all}
+if [ "$ONLY" = all ]; then
 # the bench default: two contexts alternating (a projection beside the other context's feature kernels)
 # (only launches of the timed schedule in this trace: no plane-estimated leg, no kernels-alone pass)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $REPO/bench.py $ARGS --no-estimated --no-exclusive > $OUT/bench_trace.json 2> $OUT/trace.log
@@ -16,10 +19,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_x -- python3 $REPO/bench.py --contexts 1 $ARGS --no-estimated > $OUT/bench_trace_x.json 2> $OUT/trace_x.log
 # the plane-estimated leg on its own (k_rs_batch)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_e -- python3 $REPO/bench.py --steps 2 --warmup 1 --repeats 1 $COMMON --no-exclusive > $OUT/bench_trace_e.json 2> $OUT/trace_e.log
+fi
 # the one-frame-per-call legs (supplied plane, RANSAC and semantic plane estimated inside the call): kernels of a frame
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_l -- python3 $REPO/bench.py --steps 2 --warmup 1 --repeats 1 --min-timed-seconds 0 --frames-per-step 64 --verify-slots 4 --cpu-seconds 0 --latency-frames 100 --streaming-batches 0 --config-frames 0 --no-estimated --no-exclusive > $OUT/bench_trace_l.json 2> $OUT/trace_l.log
 # the same legs WITHOUT the tracer (the numbers of record for the one-frame calls: rocprofv3 costs them 15-30 us)
 python3 $REPO/bench.py --steps 2 --warmup 1 --repeats 1 --min-timed-seconds 0 --frames-per-step 64 --verify-slots 4 --cpu-seconds 8 --latency-frames 200 --streaming-batches 24 --config-frames 0 --no-estimated --no-exclusive > $OUT/bench_latency.json 2> $OUT/latency.log
+if [ "$ONLY" = all ]; then
 # counters: rocprofv3 serialises the kernels in these passes, so they are collected on the one-context schedule
 PMCARGS="--contexts 1 --steps 4 --warmup 1 --repeats 1 $COMMON --no-kernel-timing --no-estimated"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $REPO/bench.py $PMCARGS > $OUT/bench_pmc_fetch.json 2> $OUT/pmc_fetch.log
@@ -47,6 +52,7 @@ leg() {  # key, bench arguments
 leg 2k --only-config 2 --contexts 1 --frames-per-step 1024
 leg 3n --only-config 3 --leg near
 leg 5b256 --only-config 5 --leg 256
+fi
 cd $REPO
 python3 profiles/summarize.py $TAG > $OUT/summary.log 2>&1
 python3 profiles/summarize_config_pmc.py $TAG 2k 1024 "python3 bench.py --only-config 2 --contexts 1 --frames-per-step 1024" >> $OUT/summary.log 2>&1
