@@ -1160,6 +1160,14 @@ def main():
     torch.cuda.set_device(gpu_index)
     dev = torch.device("cuda", gpu_index)
     coll_dev = dev if backend == "nccl" else None
+    if affinity is not None:
+        # the sysfs guess against what the runtime says this rank's device is (HIP order need not be PCI order)
+        from mono_lidar_depth_amd.sharding import rebind_if_device_differs
+        pr = torch.cuda.get_device_properties(gpu_index)
+        pci = None
+        if all(hasattr(pr, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+            pci = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        affinity = rebind_if_device_differs(affinity, pci)
     if world > 1:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)

@@ -10,7 +10,7 @@ replicas only.
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 
@@ -136,6 +136,34 @@ def gpu_numa_nodes(sysfs_root: str = "/sys") -> List[Tuple[str, int]]:
             continue
         found[os.path.basename(dev)] = numa
     return sorted(found.items())
+
+
+def rebind_if_device_differs(info: dict, device_pci: Optional[str], sysfs_root: str = "/sys") -> dict:
+    """After the GPU is initialised: `device_pci` is the PCI address ("0000:c1:00.0") the runtime reports for this rank's
+    device.  bind_to_gpu_numa_node guessed the device from sysfs order; when the guess named another GPU, the process is
+    re-pinned to the right node's cores (sched_setaffinity only - nothing is re-executed; staging buffers are allocated
+    later).  Returns `info` with `pci_device`, `pci_matches` and, after a correction, the new node."""
+    import os
+    info = dict(info or {})
+    info["pci_device"] = device_pci
+    if not device_pci or not info.get("pci"):
+        info["pci_matches"] = None
+        return info
+    info["pci_matches"] = device_pci.lower() == str(info["pci"]).lower()
+    if info["pci_matches"]:
+        return info
+    nodes = dict((k.lower(), v) for k, v in gpu_numa_nodes(sysfs_root))
+    numa = nodes.get(device_pci.lower())
+    if numa is None or numa < 0:
+        return {**info, "reason": "device not found in sysfs / no NUMA node: affinity left as guessed"}
+    try:
+        with open(os.path.join(sysfs_root, f"devices/system/node/node{numa}/cpulist")) as f:
+            want = sorted(set(_parse_cpulist(f.read())))
+        os.sched_setaffinity(0, want)
+    except OSError as e:
+        return {**info, "reason": f"re-bind failed: {e}"}
+    return {**info, "pci": device_pci, "numa_node": numa, "applied": True, "cpus": len(want), "cpu_first": want[0],
+            "cpu_last": want[-1], "corrected_after_init": True}
 
 
 def bind_to_gpu_numa_node(local_rank: int, sysfs_root: str = "/sys") -> dict:

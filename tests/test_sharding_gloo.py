@@ -113,6 +113,17 @@ def test_rank_is_pinned_to_the_numa_node_of_its_gpu(tmp_path, monkeypatch):
         monkeypatch.setenv("HIP_VISIBLE_DEVICES", "1,0")       # local rank 0 is device 1 of the PCI order
         d = sharding.bind_to_gpu_numa_node(0, str(tmp_path))
         assert d["pci"] == "0000:85:00.0" and sorted(os.sched_getaffinity(0)) == hi
+        # after GPU initialisation the runtime names the rank's device: a wrong guess is corrected, a right one kept
+        monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+        os.sched_setaffinity(0, have)
+        e = sharding.bind_to_gpu_numa_node(0, str(tmp_path))
+        same = sharding.rebind_if_device_differs(e, "0000:05:00.0", str(tmp_path))
+        assert same["pci_matches"] is True and sorted(os.sched_getaffinity(0)) == lo and "corrected_after_init" not in same
+        moved = sharding.rebind_if_device_differs(e, "0000:85:00.0", str(tmp_path))
+        assert moved["pci_matches"] is False and moved["corrected_after_init"] and moved["numa_node"] == 1
+        assert sorted(os.sched_getaffinity(0)) == hi
+        unknown = sharding.rebind_if_device_differs(e, None, str(tmp_path))
+        assert unknown["pci_matches"] is None
     finally:
         os.sched_setaffinity(0, have)
     assert sharding.bind_to_gpu_numa_node(0, str(tmp_path / "nothing"))["applied"] is False
