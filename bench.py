@@ -75,7 +75,7 @@ def parse_args():
     ap.add_argument("--unique-frames", type=int, default=16, help="distinct synthetic clouds generated per rank")
     ap.add_argument("--features", type=int, default=2000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--latency-frames", type=int, default=200,
+    ap.add_argument("--latency-frames", type=int, default=1000,
                     help="frames of the one-frame-per-call host-pointer leg (PCIe-inclusive latency; 0 = skip)")
     ap.add_argument("--streaming-batches", type=int, default=24,
                     help="batches of the pipelined host->device leg (PCIe-inclusive throughput; 0 = skip)")
@@ -215,6 +215,11 @@ def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
         host_keys = ("pre_us", "copycall_us", "api_us", "wait_us", "total_us")
         host_med = {k: float(np.median([h[k] for h in host[10:]])) for k in host_keys}
         host_med["wrapper_us"] = float(np.median(ts) * 1e3 - host_med["total_us"])  # Python mirror around the C call
+        # where the slowest calls lose their time: the host phases of the calls at or above the 99th percentile
+        slow = np.nonzero(ts >= np.percentile(ts, 99))[0]
+        host_tail = {k: float(np.mean([host[10 + j][k] for j in slow])) for k in host_keys}
+        host_tail["wrapper_us"] = float(np.mean(ts[slow]) * 1e3 - host_tail["total_us"])
+        host_tail["calls"] = int(len(slow))
         # phase breakdown: the same call with the phase events on
         est.timingEnable(True)
         ph = []
@@ -227,7 +232,7 @@ def latency_leg(P, cam, T, clouds, planes, uvs, n_frames, device=0):
         out = {"frames": int(n_frames), "ms_per_frame_median": float(np.median(ts)),
                "ms_per_frame_p99": float(np.percentile(ts, 99)),
                "associations_per_s": float(uvs[0].shape[0] / np.median(ts) * 1e3),
-               "breakdown_us_median": breakdown, "host_us_median": host_med}
+               "breakdown_us_median": breakdown, "host_us_median": host_med, "host_us_p99_calls": host_tail}
         if kind != "supplied":  # the last frame against the oracle with the restatement's plane for the same request
             it, i, d, t = last
             ref = oracle.OracleDepthEstimator(P, cam.as_struct(), T)
