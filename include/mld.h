@@ -232,6 +232,13 @@ int mld_set_cloud_device(mld_ctx* ctx, int slot, const void* pts_dev, int64_t n,
 /* All slots [0, n_slots) in ONE launch; pts_dev[i] / n[i] are host arrays of device pointers / counts. */
 int mld_set_clouds_device(mld_ctx* ctx, int n_slots, const void* const* pts_dev, const int64_t* n,
                           int stride_bytes);
+/*
+ * Host-side staging for callers that stream frames through (pinned) upload buffers: copies n records of
+ * src_stride_bytes (32: pcl::PointXYZI as the reference's caller holds them, DepthEstimator.h:62-63; or 16) into packed
+ * 16-byte records {x, y, z, intensity} at dst16, with up to n_threads host threads (one per ~64 K points).  The copy a
+ * driver makes anyway then halves what crosses PCIe, the bound of the streamed path.  No GPU call; no context.
+ */
+int mld_pack_points_host(void* dst16, const void* src, int64_t n, int src_stride_bytes, int n_threads);
 
 /*
  * setInputCloud(cloud, groundPlane) with an already segmented plane (DepthEstimator.cpp:220-312, :281: nothing to

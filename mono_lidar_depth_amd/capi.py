@@ -172,6 +172,7 @@ _SIGNATURES = [
                                                      _P(MldPlaneRequest), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                                      _P(MldPlaneResult)]),
     ("mld_frame_timing", C.c_int, [C.c_void_p, _P(C.c_double)]),
+    ("mld_pack_points_host", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int]),
     ("mld_calculate_depth_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     ("mld_calculate_depths_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64),
                                               _P(C.c_void_p), _P(C.c_void_p)]),

@@ -184,3 +184,28 @@ def test_uv_layouts_of_the_python_mirror():
     assert torch.equal(e._uv_device(t2, "Fx2"), t2)
     t5 = torch.tensor(a)
     assert torch.equal(e._uv_device(t5), t5) and torch.equal(e._uv_device(t5.t().contiguous(), "2xF"), t5)
+
+
+def test_pack_points_host_repacks_pcl_records():
+    """mld_pack_points_host: 32-byte pcl::PointXYZI records (x,y,z,pad | intensity,pad,pad,pad) -> packed {x,y,z,intensity};
+    16-byte sources are copied; any thread count, aligned or unaligned destination, empty input; bad strides are refused."""
+    lib = capi.load()
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 5, 65536, 65537, 300001):
+        src = rng.standard_normal((n, 8)).astype(np.float32)
+        want = np.ascontiguousarray(src[:, [0, 1, 2, 4]])
+        for threads in (1, 3, 64):
+            for off in (0, 1):  # (a destination that is not 16-byte aligned takes the plain-store path)
+                raw = np.full(4 * n + 8, np.float32(-7.0), dtype=np.float32)
+                dst = raw[off:off + 4 * n]
+                rc = lib.mld_pack_points_host(dst.ctypes.data, src.ctypes.data, n, 32, threads)
+                assert rc == 0 and np.array_equal(dst.reshape(n, 4), want)
+                assert (raw[:off] == -7.0).all() and (raw[off + 4 * n:] == -7.0).all()   # nothing written outside
+        src16 = rng.standard_normal((n, 4)).astype(np.float32)
+        dst16 = np.empty_like(src16)
+        assert lib.mld_pack_points_host(dst16.ctypes.data, src16.ctypes.data, n, 16, 4) == 0
+        assert np.array_equal(dst16, src16)
+    a = np.zeros((4, 8), dtype=np.float32)
+    assert lib.mld_pack_points_host(a.ctypes.data, a.ctypes.data, 4, 24, 1) == capi.MLD_ERR_INVALID_ARG
+    assert lib.mld_pack_points_host(None, a.ctypes.data, 4, 32, 1) == capi.MLD_ERR_INVALID_ARG
+    assert lib.mld_pack_points_host(None, None, 0, 32, 1) == 0

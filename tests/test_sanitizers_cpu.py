@@ -231,3 +231,37 @@ def test_params_from_file_fuzz(tmp_path_factory, lines, eol):
         assert getattr(p, name) in (0, 1)
     written = {k for k, _ in lines}
     assert all(k in written or k in p.absent_keys for k in _KEYS)
+
+
+PACK_DRIVER = r"""
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "mld.h"
+int main() {
+    int bad = 0;
+    for (long long n : {0LL, 1LL, 7LL, 65536LL, 200003LL}) {
+        std::vector<float> src((size_t)n * 8 + 1), dst((size_t)n * 4 + 5, -7.f);
+        for (size_t i = 0; i < src.size(); i++) src[i] = (float)(i % 977) * 0.25f;
+        for (int threads : {1, 5, 64})
+            for (int off : {0, 1}) {   // exact-size heap blocks: a record read or written past the end trips ASAN
+                float* d = dst.data() + off;
+                if (mld_pack_points_host(d, src.data(), n, 32, threads) != MLD_OK) bad++;
+                for (long long i = 0; i < n; i++)
+                    if (d[4 * i] != src[8 * i] || d[4 * i + 1] != src[8 * i + 1] || d[4 * i + 2] != src[8 * i + 2] ||
+                        d[4 * i + 3] != src[8 * i + 4]) { bad++; break; }
+            }
+    }
+    if (mld_pack_points_host(nullptr, nullptr, 3, 32, 1) != MLD_ERR_INVALID_ARG) bad++;
+    std::printf("pack_asan ok %d\n", bad);
+    return bad;
+}
+"""
+
+
+def test_pack_points_host_under_asan_ubsan(tmp_path):
+    """mld_pack_points_host reads exactly 20 bytes of the last 32-byte record's 32 and writes exactly 16 n bytes."""
+    exe = _compile(tmp_path, "pack_asan", PACK_DRIVER, [ROOT / "mono_lidar_depth_amd" / "csrc" / "mld_host.cpp"], ["-pthread"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=ENV)
+    assert r.returncode == 0 and "pack_asan ok 0" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr
