@@ -132,3 +132,16 @@ def test_bench_dense_leg_two_contexts_is_verified_and_steady():
     assert len(runs) == 5 and max(runs) <= 1.25 * min(runs), runs
     assert max(submit) < min(runs), (submit, runs)   # the host stays ahead of the device in every repetition
     assert two["classify"]["ms_per_step"] < leg["ms_per_step"] * 1.05   # (two sets in turn are not slower than one)
+
+
+def test_bench_streaming_legs_include_the_repacked_pcl_records():
+    """`streaming`: pinned 16-byte batches, pinned 32-byte batches, and 32-byte records in ordinary memory repacked by host
+    threads while staged (mld_pack_points_host) - the repacked batch equals the source clouds."""
+    args = [a for a in SMALL]
+    args[args.index("--streaming-batches") + 1] = "3"
+    out = _run(args + ["--streaming-frames", "4"])
+    st = out["streaming"]
+    assert st["stride_bytes"] == 16 and st["stride32"]["stride_bytes"] == 32
+    p = st["stride32_packed"]
+    assert p["stride_bytes"] == 16 and p["pack_threads"] >= 1 and p["packed_equals_source"] is True
+    assert p["frames"] == 12 and p["frames_per_s"] > 0
