@@ -190,6 +190,12 @@ struct mld_ctx {
     int trkb_seqs = 0;
     TrkSeq* trkb_desc = nullptr;     // device copy of the per-sequence descriptors
     std::vector<TrkSeq> trkb_host;
+    // feature groups (mld_tracklets_depths_device with few sequences): G descriptor copies per slot, each over a slice of
+    // the slot's features with its own queue slices and counters - a slot's classification is then G blocks instead of one
+    SlotDesc* d_sub = nullptr;
+    int32_t* sub_counts = nullptr;  // [overflow, live] per group descriptor
+    size_t sub_cap = 0;             // group descriptors allocated
+    std::vector<SlotDesc> h_sub;
     // staging for the host-pointer tracklet entry point
     unsigned char* trk_stage = nullptr;
     size_t trk_stage_cap = 0;
@@ -731,8 +737,11 @@ int upload_small(mld_ctx* ctx, void* dst, const void* src, size_t bytes, hipStre
 
 // k_classify (per slot) -> k_feature_fused over the live queues -> k_feature_wave over the overflow queues.
 // k_classify sets both queue lengths, so no counter needs clearing.
-int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int slot, const Calib* override_calib = nullptr) {
+int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int slot, const Calib* override_calib = nullptr,
+                    const SlotDesc* group_descs = nullptr) {
+    // group_descs: n_slots descriptors in device memory that are not the context's slots (feature groups: tags inside)
     if (max_F <= 0) return MLD_OK;
+    const SlotDesc* const descs = group_descs ? group_descs : ctx->d_slots;
     Calib calib = override_calib ? *override_calib : ctx->calib;
     // ONE frame per call (the ROS usage, the tracklet path): too few wavefronts for the lane-per-feature kernel to be
     // anything but one wavefront's lifetime (41 us for 2000 features); the wave-cooperative kernel, one feature per
@@ -740,7 +749,7 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
     const bool few = single && max_F <= 16384 && !ctx->force_thread_path;
     if (few) calib.threadPath = 0;
     const int per_slot = (int)((max_F + kWave - 1) / kWave);
-    const uint32_t tag_all = single ? 0u : common_tag(ctx, n_slots);
+    const uint32_t tag_all = (single || group_descs) ? 0u : common_tag(ctx, n_slots);
     const SlotDesc one = single ? ctx->slots[slot].d : SlotDesc{};
     const int use_single = single ? 1 : 0, ns = single ? 1 : n_slots;
     if (few) {
@@ -754,7 +763,7 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
             HIP_TRY(ctx, hipMalloc((void**)&ctx->cls_done, sizeof(uint32_t)));
             HIP_TRY(ctx, hipMemsetAsync(ctx->cls_done, 0, sizeof(uint32_t), ctx->stream));
         }
-        hipLaunchKernelGGL(kc, dim3((unsigned)ns), dim3(kClsThreads), ctx->lds_classify, ctx->stream, ctx->d_slots, one,
+        hipLaunchKernelGGL(kc, dim3((unsigned)ns), dim3(kClsThreads), ctx->lds_classify, ctx->stream, descs, one,
                            use_single, calib, ctx->bm_ncol, ctx->bm_ncolp, gate ? ctx->cls_done : (uint32_t*)nullptr);
         if (gate) {
             mld_ctx* w = ctx->release_waiter;
@@ -824,7 +833,7 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         // the kernel never needs the map tag)
         if (single && (rc_up = upload_descs(ctx, 1, nullptr, slot, true))) return rc_up;
         hipLaunchKernelGGL(kf, dim3((unsigned)per_slot * (unsigned)ns), dim3(kWave), ctx->lds_fused + ctx->lds_fused_pad, ctx->stream,
-                           ctx->d_slots + (single ? slot : 0), d_calib, ns, per_slot);
+                           descs + (single ? slot : 0), d_calib, ns, per_slot);
     }
     {
         ScopedTimer tm(ctx, 3);
@@ -835,7 +844,7 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         const int want = (int)((max_F + chunk - 1) / chunk);
         const int pw = std::max(1, std::min(want, std::max(4, (few ? 16384 : 4096) / ns)));
         auto kw = few ? mld::k_feature_wave<true> : mld::k_feature_wave<false>;
-        hipLaunchKernelGGL(kw, dim3((unsigned)pw * (unsigned)ns), dim3(kWave), ctx->lds_bytes, ctx->stream, ctx->d_slots, one,
+        hipLaunchKernelGGL(kw, dim3((unsigned)pw * (unsigned)ns), dim3(kWave), ctx->lds_bytes, ctx->stream, descs, one,
                            use_single, d_calib, ns, pw, tag_all, chunk);
     }
     HIP_TRY(ctx, hipGetLastError());
@@ -1049,7 +1058,9 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if ((e = hipMalloc((void**)&ctx->d_calib, 2 * sizeof(Calib))) != hipSuccess) return hip_bail(e, "hipMalloc(calib)");
     std::memset(ctx->calib_uploaded, 0xFF, sizeof(ctx->calib_uploaded));  // (nothing uploaded yet)
     // the upload ring at its working size now (pinning costs milliseconds): a step's largest upload is its descriptors
-    ctx->up_gen_bytes = (std::max(sizeof(SlotDesc) * (size_t)max_frames, sizeof(Calib)) + 4095) / 4096 * 4096;
+    // (contexts with several slots may deal a slot's features to up to 512 group descriptors: mld_tracklets_depths_device)
+    const size_t up_descs = max_frames >= 2 ? std::max<size_t>((size_t)max_frames, 512) : 1;
+    ctx->up_gen_bytes = (std::max(sizeof(SlotDesc) * up_descs, sizeof(Calib)) + 4095) / 4096 * 4096;
     if ((e = hipHostMalloc((void**)&ctx->up_base, ctx->up_gen_bytes * mld_ctx::kUpGens, hipHostMallocDefault)) != hipSuccess)
         return hip_bail(e, "hipHostMalloc(upload ring)");
     if ((e = hipMemsetAsync(ctx->dummy, 0, 256, ctx->stream)) != hipSuccess) return hip_bail(e, "hipMemset(dummy)");
@@ -1132,6 +1143,8 @@ void mld_destroy(mld_ctx* ctx) {
         if (p) (void)hipFree(p);
     if (ctx->trkb) (void)hipFree(ctx->trkb);
     if (ctx->trkb_desc) (void)hipFree(ctx->trkb_desc);
+    if (ctx->d_sub) (void)hipFree(ctx->d_sub);
+    if (ctx->sub_counts) (void)hipFree(ctx->sub_counts);
     void* trk[] = {ctx->trk_uv_cur, ctx->trk_uv_last, ctx->trk_depth_cur, ctx->trk_depth_last, ctx->trk_type_cur,
                    ctx->trk_type_last, ctx->trk_rank, ctx->trk_n_new, ctx->trk_stage};
     for (void* p : trk)
@@ -2641,9 +2654,55 @@ int mld_tracklets_depths_device(mld_ctx* ctx, int n_seq, int bank_cur, int have_
     const unsigned chunks = (unsigned)((max_n + kTrkBlock - 1) / kTrkBlock);
     hipLaunchKernelGGL(k_tracklets_gather, dim3(chunks, (unsigned)n_seq), dim3(kTrkBlock), 0, ctx->stream, ctx->trkb_desc);
     HIP_TRY(ctx, hipGetLastError());
-    // one launch set over both banks; the banks carry different map tags, so the descriptors hold them
-    if ((rc = upload_descs(ctx, 2 * n_seq, nullptr, 0, true))) return rc;
-    rc = launch_features(ctx, 2 * n_seq, max_n, false, 0);
+    // Few sequences: one classification block per slot leaves most CUs idle (16 sequences of 10 000 tracks: 32 blocks of
+    // 60 us on 256 CUs).  The features of every slot are then dealt to G group descriptors - copies of the slot's with
+    // the feature arrays, the queues and the counters sliced - so that the launch set has ~512 classification blocks.
+    // Group g of slot i sits at g * n_desc + i: the groups of a slot stay on the slot's XCD (decode_block).
+    const int n_desc = 2 * n_seq;
+    const int G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, 256 / n_desc), max_n / 1024));
+    if (G > 1) {
+        const int64_t Fg = (((max_n + G - 1) / G) + 63) & ~(int64_t)63;
+        const size_t n_sub = (size_t)n_desc * (size_t)G;
+        if (n_sub > ctx->sub_cap) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->d_sub) HIP_TRY(ctx, hipFree(ctx->d_sub));
+            if (ctx->sub_counts) HIP_TRY(ctx, hipFree(ctx->sub_counts));
+            ctx->d_sub = nullptr;
+            ctx->sub_counts = nullptr;
+            ctx->sub_cap = 0;
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_sub, n_sub * sizeof(SlotDesc)));
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->sub_counts, n_sub * 2 * sizeof(int32_t)));
+            ctx->sub_cap = n_sub;
+        }
+        ctx->h_sub.resize(n_sub);
+        for (int g = 0; g < G; g++) {
+            const int64_t off = (int64_t)g * Fg;
+            for (int i = 0; i < n_desc; i++) {
+                const size_t idx = (size_t)g * (size_t)n_desc + (size_t)i;
+                SlotDesc d = ctx->slots[i].d;
+                const int64_t left = d.F - off;
+                d.F = left < 0 ? 0 : (left < Fg ? left : Fg);
+                if (d.F > 0) {  // (a group without features keeps the slot's pointers: nothing is read through them)
+                    d.uv += 2 * off;
+                    d.depth += off;
+                    if (d.type) d.type += off;
+                    if (d.corners) d.corners += 9 * off;
+                    if (d.ovf_queue) d.ovf_queue += 2 * off;
+                    if (d.live_queue) d.live_queue += off;
+                }
+                d.F_dev_off = off;
+                d.ovf_count = ctx->sub_counts + 2 * idx;
+                d.live_count = ctx->sub_counts + 2 * idx + 1;
+                ctx->h_sub[idx] = d;
+            }
+        }
+        if ((rc = upload_small(ctx, ctx->d_sub, ctx->h_sub.data(), n_sub * sizeof(SlotDesc), ctx->stream))) return rc;
+        rc = launch_features(ctx, (int)n_sub, Fg, false, 0, nullptr, ctx->d_sub);
+    } else {
+        // one launch set over both banks; the banks carry different map tags, so the descriptors hold them
+        if ((rc = upload_descs(ctx, n_desc, nullptr, 0, true))) return rc;
+        rc = launch_features(ctx, n_desc, max_n, false, 0);
+    }
     for (int q = 0; q < n_seq; q++) ctx->slots[last0 + q].d.F_dev = nullptr;  // (the uploaded copy keeps it)
     if (rc) return rc;
     hipLaunchKernelGGL(k_tracklets_scatter, dim3((unsigned)((max_n + 255) / 256), (unsigned)n_seq), dim3(256), 0, ctx->stream,

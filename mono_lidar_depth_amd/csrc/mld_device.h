@@ -120,6 +120,7 @@ struct SlotDesc {
     int has_plane;
     int mask_in_key;  // 1: the inlier / far flags of every map key are valid (the plane was known when the cloud was projected)
     float far_mg0, far_mg1;  // margins of the projection's single-precision far test for `coeffs` (far_margins)
+    long long F_dev_off;     // this descriptor's first feature among those *F_dev counts (feature groups of a slot; else 0)
 };
 
 // One sequence of the batched tracklet layer (mld_tracklets_depths_device): the arrays of

@@ -2209,7 +2209,8 @@ __global__ __launch_bounds__(kWave) void k_feature_wave(const SlotDesc* __restri
     if (direct) {
         long long Fn = s.F;
         if (s.F_dev) {
-            const long long fd = *GPTR(long long, s.F_dev);
+            long long fd = *GPTR(long long, s.F_dev) - s.F_dev_off;
+            fd = fd < 0 ? 0 : fd;
             Fn = fd < Fn ? fd : Fn;
         }
         count = (int)Fn;
@@ -2350,7 +2351,8 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
     apply_plane_dev(s);
     long long Fn = s.F;
     if (s.F_dev) {
-        const long long fd = *GPTR(long long, s.F_dev);
+        long long fd = *GPTR(long long, s.F_dev) - s.F_dev_off;
+        fd = fd < 0 ? 0 : fd;
         Fn = fd < Fn ? fd : Fn;
     }
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
