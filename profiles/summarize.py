@@ -197,6 +197,10 @@ try:
     traffic["frames_per_launch"] = b["config"].get("frame_slots_per_launch", b["config"]["frames_per_step"])
     traffic["source"] = (f"profiles/{tag}_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCP_* / TCC_*, separate passes, one "
                          "context; launch_s = that kernel alone, from the --contexts 1 trace)")
+    try:  # the per-leg entries (summarize_config_pmc.py) live in the same file: keep them
+        traffic["configs"] = json.load(open("profiles/traffic.json")).get("configs", {})
+    except Exception:  # noqa: BLE001
+        pass
     json.dump(traffic, open("profiles/traffic.json", "w"), indent=1)
 except Exception as e:  # noqa: BLE001
     print("traffic.json not written:", e)
