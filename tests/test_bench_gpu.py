@@ -126,6 +126,9 @@ def test_bench_dense_leg_two_contexts_is_verified_and_steady():
     out = _run(["--only-config", "5", "--leg", "16t"])
     leg = out["batched"]["16"] if "batched" in out else out["configs"]["5"]["batched"]["16"]
     assert leg["verified"] is True and leg["sequences_checked"] == 16 and leg["mismatching_sequences"] == []
+    # the leg's own physical roofline (counter bytes of the committed S = 256 profile scaled to this launch size)
+    r = leg["roofline"]
+    assert r is not None and r["bound"] == "hbm" and 0.0 < r["frac"] <= 1.0 and "5b256" in r["bytes_source"]
     two = leg["two_contexts"]
     assert two["second_context_equals_first"] is True
     runs, submit = two["classify"]["ms_per_step_runs"], two["classify"]["submit_ms_per_step_runs"]
