@@ -1058,7 +1058,8 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     if ((e = hipMalloc((void**)&ctx->d_calib, 2 * sizeof(Calib))) != hipSuccess) return hip_bail(e, "hipMalloc(calib)");
     std::memset(ctx->calib_uploaded, 0xFF, sizeof(ctx->calib_uploaded));  // (nothing uploaded yet)
     // the upload ring at its working size now (pinning costs milliseconds): a step's largest upload is its descriptors
-    // (contexts with several slots may deal a slot's features to up to 512 group descriptors: mld_tracklets_depths_device)
+    // (contexts with several slots may deal their slots' features to group descriptors - 256 of them, room for 512:
+    // mld_tracklets_depths_device)
     const size_t up_descs = max_frames >= 2 ? std::max<size_t>((size_t)max_frames, 512) : 1;
     ctx->up_gen_bytes = (std::max(sizeof(SlotDesc) * up_descs, sizeof(Calib)) + 4095) / 4096 * 4096;
     if ((e = hipHostMalloc((void**)&ctx->up_base, ctx->up_gen_bytes * mld_ctx::kUpGens, hipHostMallocDefault)) != hipSuccess)
@@ -2656,7 +2657,8 @@ int mld_tracklets_depths_device(mld_ctx* ctx, int n_seq, int bank_cur, int have_
     HIP_TRY(ctx, hipGetLastError());
     // Few sequences: one classification block per slot leaves most CUs idle (16 sequences of 10 000 tracks: 32 blocks of
     // 60 us on 256 CUs).  The features of every slot are then dealt to G group descriptors - copies of the slot's with
-    // the feature arrays, the queues and the counters sliced - so that the launch set has ~512 classification blocks.
+    // the feature arrays, the queues and the counters sliced - so that the launch set has ~256 classification blocks (more
+    // groups cost the feature kernel more partly filled wavefronts than the classification gains: LAB.md 5.24).
     // Group g of slot i sits at g * n_desc + i: the groups of a slot stay on the slot's XCD (decode_block).
     const int n_desc = 2 * n_seq;
     const int G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(8, 256 / n_desc), max_n / 1024));
