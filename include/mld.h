@@ -192,7 +192,8 @@ int mld_order_after(mld_ctx* ctx, mld_ctx* other);
  *   (one 1024-thread block and 63 KB of LDS per frame, 40 us per 1024 frames) then has the GPU to itself instead of competing with 131 072 projection blocks for wave
  *   slots, and the projection of `ctx` still runs beside the long feature kernels (measured: k_classify 70-90 -> 44 us,
  *   the step 0.5-1.5 % shorter and steadier; LAB.md 4.17).  The release itself is a one-wavefront kernel (k_gate) queued
- *   in front of the projection that polls a counter of finished classification blocks - 2-3 us from the last block to the
+ *   in front of the projection that polls a counter of the classification blocks that have been placed on a CU - once the
+ *   last one runs, nothing of that kernel still waits for wave slots or LDS (LAB.md 5.29) - 2-3 us from there to the
  *   projection's start instead of the ~15 us of a cross-stream event (LAB.md 4.28); its polling is bounded (it gives up
  *   after 100 000 polls, a fraction of a second), because nothing depends on it: purely a scheduling hint, the contexts share no data.  Nothing waits if
  *   `other` never issues that call; a pending hand-over ends with either context.

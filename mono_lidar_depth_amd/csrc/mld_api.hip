@@ -220,7 +220,7 @@ struct mld_ctx {
     mld_ctx* release_waiter = nullptr;  // mld_order_after_classify: released behind this context's next k_classify
     mld_ctx* waiting_on = nullptr;      //   (back pointer: either context may be destroyed first)
     bool order_wait_pending = false;
-    uint32_t* cls_done = nullptr;       //   gate hand-over: k_classify blocks of this context that have finished (device)
+    uint32_t* cls_done = nullptr;       //   gate hand-over: k_classify blocks of this context that have been placed (device)
     uint32_t cls_target = 0;            //   ... and how many there will be once everything queued so far has run
     const uint32_t* gate_counter = nullptr;  // the counter / value this context's next projection waits for (k_gate)
     uint32_t gate_target = 0;

@@ -2356,6 +2356,10 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
         Fn = fd < Fn ? fd : Fn;
     }
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    // (hand-over by gate, mld_order_after_classify: blocks that have been PLACED, counted for k_gate of the other context.
+    // Once the last block runs, nothing of this kernel still waits for wave slots or LDS, which is all the other context's
+    // projection blocks could take from it; counting at the end released them a block's lifetime - 12 us - later.)
+    if (done && tid == 0) __hip_atomic_fetch_add(GPTRW(uint32_t, done), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int b = tid; b < kClsBuckets; b += kClsThreads) hist[b] = 0;
     if (tid == 0) ctr[0] = 0;
     const auto* bm = GPTR(uint32_t, s.bitmap);
@@ -2529,11 +2533,6 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
     for (long long i = tid + (long long)kClsKeep * kClsThreads; i < Fn; i += kClsThreads) {
         const int cls = classify(uv[2 * i], uv[2 * i + 1]);
         if (cls >= 0) live[atomicAdd(&hist[cls], 1)] = (int32_t)i;
-    }
-    // (hand-over by gate, mld_order_after_classify: blocks that have finished, counted for k_gate of the other context)
-    if (done) {
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(GPTRW(uint32_t, done), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
