@@ -1502,16 +1502,6 @@ __device__ __forceinline__ double raw_z(const Calib& c, RawP r) {
     return c.T[11] + ((c.T[8] * (double)r.x + c.T[9] * (double)r.y) + c.T[10] * (double)r.z);
 }
 __device__ __forceinline__ V3 raw_point(const Calib& c, RawP r) { return lidar_to_cam(c, (double)r.x, (double)r.y, (double)r.z); }
-// The same transform with fused multiply-adds (9 instructions instead of 18): for the road estimators only, which answer
-// to the 1e-4 m tolerance (their sums are re-associated anyway); the result differs from raw_point's by an ulp.
-__device__ __forceinline__ V3 raw_point_fma(const Calib& c, RawP r) {
-    const double x = (double)r.x, y = (double)r.y, z = (double)r.z;
-    V3 o;
-    o.x = fma(c.T[2], z, fma(c.T[1], y, fma(c.T[0], x, c.T[3])));
-    o.y = fma(c.T[6], z, fma(c.T[5], y, fma(c.T[4], x, c.T[7])));
-    o.z = fma(c.T[10], z, fma(c.T[9], y, fma(c.T[8], x, c.T[11])));
-    return o;
-}
 // list entry e of this lane, or 0 (a valid point index whenever any list is non-empty) beyond the list end
 // (lcap: capacity of the list `lst` addresses - the wide list's c.k1max or the narrow list's c.kMain)
 #define LST_ID(e, n) (((e) < (n)) ? (LST(min((e), lcap - 1)) & kIdxMask) : 0u)
@@ -1698,7 +1688,12 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s
             xmx = fmax(xmx, p.x);
         }
         if (roadMode == 0) {
-            const double w = fast_rcp(fabs(fma(pn.x, p.x, fma(pn.y, p.y, fma(pn.z, p.z, prior_off)))));  // PlaneEstimationMEstimator.cpp:32
+            // PlaneEstimationMEstimator.cpp:32.  The distance is a cancellation (a road point lies on the prior plane to
+            // within centimetres or less) and its reciprocal is the weight: the point and the dot product are therefore
+            // evaluated in the reference's own operation order, rounding for rounding - a fused chain changes a weight by
+            // 1e-11 relative where the distance is 1e-4 m, and an estimate kilometres away (thresholds off) by 2e-4 m
+            // (profiles/tools/random_sweep.py, seed 1990; LAB.md 5.32)
+            const double w = fast_rcp(fabs(vdot(pn, p) + prior_off));
             const double swn = sw + w;
             const double r = w * fast_rcp(swn);
             const double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
@@ -1751,7 +1746,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s
             for (int q = 0; q < kRoadBatch; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ni));
 #pragma unroll
             for (int q = 0; q < kRoadBatch; q++)
-                if (e0 + q < ni) add_inlier(raw_point_fma(c, rp[q]));
+                if (e0 + q < ni) add_inlier(raw_point(c, rp[q]));
         }
     } else {
     const int n2max = uniform(wave_max_i32(n2));

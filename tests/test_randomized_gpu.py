@@ -53,7 +53,10 @@ def _random_setup(seed):
     return P, cam, T, scanner, kw
 
 
-@pytest.mark.parametrize("seed", range(24))
+# (1990: found by profiles/tools/random_sweep.py - depth thresholds off, a road estimate 3.8 km behind the camera: its depth
+#  answers to 1e-4 m only if the M-estimator's weights - reciprocals of a cancellation - are evaluated in the reference's
+#  own operation order; LAB.md 5.32)
+@pytest.mark.parametrize("seed", [*range(24), 1990])
 def test_random_configuration(seed):
     P, cam, T, scanner, kw = _random_setup(seed)
     cloud = synth.make_cloud(scanner, seed=200 + seed, frame=seed % 5)
