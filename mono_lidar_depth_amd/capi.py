@@ -243,7 +243,7 @@ def load_ab() -> C.CDLL:
     product path."""
     global _lib_ab
     if _lib_ab is None:
-        _lib_ab = _bind(LIB_AB_PATH)
+        _lib_ab = _bind(Path(os.environ.get("MLD_HIP_AB_LIBRARY") or LIB_AB_PATH))  # (the override: A/B tools only)
     return _lib_ab
 
 

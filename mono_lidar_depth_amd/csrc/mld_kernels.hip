@@ -834,9 +834,11 @@ __device__ void jacobi_eig3_fast(const double s[6], double ev[3], V3& n0) {
         d0 = d2;
         i0 = 2;
     }
+    // (smallest first; the other two as the middle and the largest)
+    const double e1 = (i0 == 0) ? a[1][1] : a[0][0], e2 = (i0 == 2) ? a[1][1] : a[2][2];
     ev[0] = d0;
-    ev[1] = 0;
-    ev[2] = 0;
+    ev[1] = e1 < e2 ? e1 : e2;
+    ev[2] = e1 < e2 ? e2 : e1;
     n0.x = (i0 == 0) ? v[0][0] : ((i0 == 1) ? v[0][1] : v[0][2]);
     n0.y = (i0 == 0) ? v[1][0] : ((i0 == 1) ? v[1][1] : v[1][2]);
     n0.z = (i0 == 0) ? v[2][0] : ((i0 == 1) ? v[2][1] : v[2][2]);
@@ -848,9 +850,9 @@ __device__ void jacobi_eig3_fast(const double s[6], double ev[3], V3& n0) {
 // A - lambda I, then two Rayleigh-quotient steps through the adjugate (cubic convergence; they repair the cancellation
 // in the cubic's coefficients).  ~300 instructions against ~2000 for the Jacobi sweeps of a wavefront.  Returns false
 // when the two smallest eigenvalues are closer than 1e-6 of the largest (or the input is not finite): the caller then
-// takes the Jacobi solver, which keeps relative accuracy there.  Measured against LAPACK on 40 000 road-like weighted
+// takes the Jacobi solver.  gap2 = ((lambda2 - lambda1)(lambda3 - lambda1) / trace^2)^2.  Measured against LAPACK on 40 000 road-like weighted
 // scatters: eigenvector error <= 1e-10 wherever it returns true.
-__device__ __forceinline__ bool smallest_eigvec_sym3(const double s[6], V3& n0) {
+__device__ __forceinline__ bool smallest_eigvec_sym3(const double s[6], V3& n0, double& gap2) {
     const double tr = s[0] + s[3] + s[5];
     const double sc = fast_rcp(tr);
     const double a00 = s[0] * sc, a01 = s[1] * sc, a02 = s[2] * sc, a11 = s[3] * sc, a12 = s[4] * sc, a22 = s[5] * sc;
@@ -896,6 +898,7 @@ __device__ __forceinline__ bool smallest_eigvec_sym3(const double s[6], V3& n0) 
     }
     n0 = v;
     // |adj(B) v| ~ (lambda2 - lambda1)(lambda3 - lambda1) in units of the trace
+    gap2 = g2;
     return (tr > 0.0) && (g2 > 1e-12) && isfinite(g2);
 }
 
@@ -1036,11 +1039,151 @@ __device__ void moments(int n, const Lists& L, int lane, bool weighted, const Sl
     cov[5] = wave_sum_f64(c5);
 }
 
+// PlaneEstimationMEstimator::EstimatePlane (:18-55) up to the decomposition: the weighted centre and the matrix
+// M = [sqrt(w_i) (p_i - c)] whose left singular vector of the smallest singular value is the plane's normal (JacobiSVD, :49).
+// Road points seen through a narrow window are nearly COLLINEAR (returns of neighbouring rings at one azimuth): the two
+// small singular values then differ by the coordinates' rounding noise, and the scatter matrix M M^T - which squares the
+// singular values - no longer holds the normal at all (estimates 0.3 ... 4 mm off, LAB.md 5.33).  So the wavefront takes
+// the thin QR of M^T (k x 3, rows in LDS over the list itself; modified Gram-Schmidt, whose R is that of a matrix within
+// rounding of M^T) and hands on R: M M^T = R^T R, and a one-sided Jacobi on the three rows of R^T (finish_road) is as
+// accurate as the reference's SVD of M.  out: center[3], R = r11 r12 r13 r22 r23 r33.
+__device__ void road_qr(int n, const Lists& L, int lane, const SlotDesc& s, double center[3], double R[6]) {
+    const V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
+    double sw = 0, sx = 0, sy = 0, sz = 0;
+    for (int b = 0; b < n; b += kWave) {
+        const int i = b + lane;
+        if (i < n) {
+            const V3 p = {L.x[i], L.y[i], L.z[i]};
+            const double w = 1 / fabs(vdot(pn, p) + s.prior_off);  // PlaneEstimationMEstimator.cpp:32
+            sw += w;
+            sx += w * p.x;
+            sy += w * p.y;
+            sz += w * p.z;
+        }
+    }
+    sw = wave_sum_f64(sw);
+    sx = wave_sum_f64(sx);
+    sy = wave_sum_f64(sy);
+    sz = wave_sum_f64(sz);
+    const double cx = sx / sw, cy = sy / sw, cz = sz / sw;
+    center[0] = cx;
+    center[1] = cy;
+    center[2] = cz;
+    // rows a_i = sqrt(w_i) (p_i - c), written over the list; first column's norm on the way
+    double t0 = 0;
+    for (int b = 0; b < n; b += kWave) {
+        const int i = b + lane;
+        if (i < n) {
+            const V3 p = {L.x[i], L.y[i], L.z[i]};
+            const double ws = sqrt(1 / fabs(vdot(pn, p) + s.prior_off));
+            const double ax = ws * (p.x - cx), ay = ws * (p.y - cy), az = ws * (p.z - cz);
+            L.x[i] = ax;
+            L.y[i] = ay;
+            L.z[i] = az;
+            t0 += ax * ax;
+        }
+    }
+    const double r11 = sqrt(wave_sum_f64(t0));
+    const double i11 = r11 > 0.0 ? 1 / r11 : 0.0;  // (all points in one place: a zero column stays zero)
+    double t1 = 0, t2 = 0;
+    for (int b = 0; b < n; b += kWave) {
+        const int i = b + lane;
+        if (i < n) {
+            const double q = L.x[i] * i11;
+            L.x[i] = q;
+            t1 += q * L.y[i];
+            t2 += q * L.z[i];
+        }
+    }
+    const double r12 = wave_sum_f64(t1), r13 = wave_sum_f64(t2);
+    t0 = 0;
+    for (int b = 0; b < n; b += kWave) {
+        const int i = b + lane;
+        if (i < n) {
+            const double q = L.x[i];
+            const double ay = L.y[i] - r12 * q;
+            L.y[i] = ay;
+            L.z[i] = L.z[i] - r13 * q;
+            t0 += ay * ay;
+        }
+    }
+    const double r22 = sqrt(wave_sum_f64(t0));
+    const double i22 = r22 > 0.0 ? 1 / r22 : 0.0;
+    t1 = 0;
+    for (int b = 0; b < n; b += kWave) {
+        const int i = b + lane;
+        if (i < n) {
+            const double q = L.y[i] * i22;
+            L.y[i] = q;
+            t1 += q * L.z[i];
+        }
+    }
+    const double r23 = wave_sum_f64(t1);
+    t0 = 0;
+    for (int b = 0; b < n; b += kWave) {
+        const int i = b + lane;
+        if (i < n) {
+            const double az = L.z[i] - r23 * L.y[i];
+            t0 += az * az;
+        }
+    }
+    const double r33 = sqrt(wave_sum_f64(t0));
+    R[0] = r11;
+    R[1] = r12;
+    R[2] = r13;
+    R[3] = r22;
+    R[4] = r23;
+    R[5] = r33;
+}
+
+// Left singular vector of the smallest singular value of M from the R of road_qr: one-sided (Hestenes) Jacobi on the
+// three rows of R^T - M = R^T Q^T, so the rows' inner products are M's - as the CPU restatement runs it on the rows of
+// M itself (oracle: mestimator_plane).
+__device__ __forceinline__ V3 normal_from_R(const double R[6]) {
+    double B[3][3] = {{R[0], 0.0, 0.0}, {R[1], R[3], 0.0}, {R[2], R[4], R[5]}};
+    double U[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; sweep++) {
+        bool rotated = false;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                const double app = B[p][0] * B[p][0] + B[p][1] * B[p][1] + B[p][2] * B[p][2];
+                const double aqq = B[q][0] * B[q][0] + B[q][1] * B[q][1] + B[q][2] * B[q][2];
+                const double apq = B[p][0] * B[q][0] + B[p][1] * B[q][1] + B[p][2] * B[q][2];
+                if (!(fabs(apq) > 1e-15 * sqrt(app * aqq)) || apq == 0.0) continue;
+                rotated = true;
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const double a = B[p][k], b = B[q][k];
+                    B[p][k] = cs * a - sn * b;
+                    B[q][k] = sn * a + cs * b;
+                    const double ua = U[k][p], ub = U[k][q];
+                    U[k][p] = cs * ua - sn * ub;
+                    U[k][q] = sn * ua + cs * ub;
+                }
+            }
+        if (!rotated) break;
+    }
+    double nrm[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) nrm[r] = B[r][0] * B[r][0] + B[r][1] * B[r][1] + B[r][2] * B[r][2];
+    int m = 0;
+    if (nrm[1] < nrm[m]) m = 1;
+    if (nrm[2] < nrm[m]) m = 2;
+    V3 n0;
+    n0.x = (m == 0) ? U[0][0] : ((m == 1) ? U[0][1] : U[0][2]);
+    n0.y = (m == 0) ? U[1][0] : ((m == 1) ? U[1][1] : U[1][2]);
+    n0.z = (m == 0) ? U[2][0] : ((m == 1) ? U[2][1] : U[2][2]);
+    return n0;
+}
+
 enum : int {
     ST_FINAL = 0,       // mytype/mydepth are final
     ST_TRIANGLE = 1,    // record = 3 corners + minZ,maxZ           -> phase 2
     ST_PCA = 2,         // record = mean, cov, minZ,maxZ            -> phase 2
-    ST_ROAD_MEST = 3,   // record = centre, cov, minZ,maxZ          -> phase 4
+    ST_ROAD_MEST = 3,   // record = centre, R (road_qr), minZ,maxZ  -> phase 4
     ST_ROAD_TRI = 4     // record = 3 corners + minZ,maxZ           -> phase 4
 };
 
@@ -1103,11 +1246,9 @@ __device__ __forceinline__ void finish_road(const Calib& c, bool triangle, doubl
     Plane pl;
     if (!triangle) {
         // PlaneEstimationMEstimator::EstimatePlane (:18-55): direction of least weighted variance
+        // (r[3..8] = the R of road_qr, not the scatter: see there)
         V3 center = {r[0], r[1], r[2]};
-        double ev[3];
-        V3 n0;
-        jacobi_eig3(&r[3], ev, n0);  // (a closed-form eigen-solve cannot separate the two tiny eigenvalues of
-                                     //  nearly collinear road points; Jacobi keeps their relative accuracy)
+        V3 n0 = normal_from_R(&r[3]);
         if (isnan(center.x) || isnan(center.y) || isnan(center.z)) {
             double qn = __builtin_nan("");
             n0 = {qn, qn, qn};
@@ -1129,19 +1270,29 @@ __device__ __forceinline__ void finish_road(const Calib& c, bool triangle, doubl
 
 // The M-estimator tail of finish_road with the reduced-cost arithmetic (thread path; results within the road
 // tolerance of the exact form).  r[0..2]: weighted centre, r[3..8]: weighted scatter, r[9], r[10]: min / max z.
-__device__ __forceinline__ void finish_road_fast(const Calib& c, double u, double v, const double r[kRecFields],
+// Returns false where the scatter cannot carry the normal to the road tolerance: the eigenvector's error is the sums'
+// rounding (a few 1e-15 of the trace) over the gap between the two small eigenvalues - nearly collinear points: returns of
+// one ring, of one azimuth - and the depth multiplies it by depth / cos(ray, normal).  Where that estimate passes 2e-5 m,
+// or the input is not finite, the caller hands the feature to the wave kernel (road_qr: SVD accuracy).  LAB.md 5.33.
+__device__ __forceinline__ bool finish_road_fast(const Calib& c, double u, double v, const double r[kRecFields],
                                                  int& out_type, double& out_depth) {
     const V3 dir = viewing_ray(c, u, v);
     const V3 support = {0, 0, 0};
     const V3 center = {r[0], r[1], r[2]};
     V3 n0;
-    const bool direct = smallest_eigvec_sym3(&r[3], n0);
+    double gap2 = 0.0;
+    const bool direct = smallest_eigvec_sym3(&r[3], n0, gap2);
+    double gap = sqrt(gap2);
     if (__any(!direct)) {  // (nearly) equal small eigenvalues somewhere in the wavefront: the sweeps for those lanes
         double ev[3];
         V3 nj;
         jacobi_eig3_fast(&r[3], ev, nj);
-        if (!direct) n0 = nj;
+        if (!direct) {
+            n0 = nj;
+            gap = (ev[1] - ev[0]) / ev[2];  // (NaN / negative noise: the estimate below fails, as it should)
+        }
     }
+    bool well = true;
     if (isnan(center.x) || isnan(center.y) || isnan(center.z)) {
         const double qn = __builtin_nan("");
         n0 = {qn, qn, qn};
@@ -1153,11 +1304,19 @@ __device__ __forceinline__ void finish_road_fast(const Calib& c, double u, doubl
     // the depth 0.0 exactly there, which sits ON the global threshold (treshold_depth_min = 0)
     double depth = -1.0;
     intersect(c, false, pl, dir, support, depth);  // n0 = direction, n1 = support (swapped, as the reference)
+    // (error estimate: see the head comment; a ray nearly parallel to the plane or an intersection kilometres away -
+    // depth thresholds off - fail it as well as a vanishing gap)
+    const double nd = fabs(vdot(pl.n, dir));
+#ifndef MLD_ROAD_ERR_C
+#define MLD_ROAD_ERR_C 1e-14
+#endif
+    if (!(fabs(depth) * MLD_ROAD_ERR_C <= 2e-5 * gap * nd)) well = false;
     int type = MLD_SuccessRoad;
     const int th = apply_thresholds(c, r[9], r[10], depth);
     if (th) type = th;
     out_type = type;
     out_depth = (type == MLD_SuccessRoad) ? depth : -1.0;
+    return well;
 }
 
 // Wave-cooperative path: processes the features whose bit is set in `mask` (wave-uniform), one at a time, with
@@ -1339,11 +1498,11 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
                 double mn, mx;
                 list_minmax_z(kk, L, lane, mn, mx);
                 if (c.roadMode == 0) {
-                    double ctr[3], cov[6];
-                    moments(kk, L, lane, true, s, ctr, cov, false);
+                    double ctr[3], R[6];
+                    road_qr(kk, L, lane, s, ctr, R);  // (rewrites the list: nothing reads it afterwards)
                     {
                         for (int t = 0; t < 3; t++) SREC(t, ctr[t]);
-                        for (int t = 0; t < 6; t++) SREC(3 + t, cov[t]);
+                        for (int t = 0; t < 6; t++) SREC(3 + t, R[t]);
                     }
                     state = ST_ROAD_MEST;
                 } else {
@@ -1398,11 +1557,8 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
 
     ST_MARK(8);
     // ---------------- phase 4 (lane = feature) ----------------
-    // (the M-estimator's normal from the direct eigenvector solver of the lane-per-feature kernel: with one or two
-    // queue entries per block this tail runs on one or two lanes, and the cyclic Jacobi sweeps were a third of the
-    // kernel's instructions)
     if (mystate == ST_ROAD_MEST) {
-        finish_road_fast(c, myu, myv, myr, mytype, mydepth);
+        finish_road(c, false, myu, myv, myr, mytype, mydepth);  // (normal from the R of road_qr)
     } else if (mystate == ST_ROAD_TRI) {
         finish_road(c, true, myu, myv, myr, mytype, mydepth);
     }
@@ -1798,7 +1954,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s
         // weighted centre (PlaneEstimationMEstimator.cpp:31-37) and scatter about it (:39-46)
         rr[0] = mx; rr[1] = my; rr[2] = mz;
         rr[3] = q0; rr[4] = q1; rr[5] = q2; rr[6] = q3; rr[7] = q4; rr[8] = q5;
-        if (cand) finish_road_fast(c, myu, myv, rr, mytype, mydepth);
+        if (cand && !finish_road_fast(c, myu, myv, rr, mytype, mydepth)) overflow = true;  // (redone by the wave kernel)
         ST_USE_F64(mydepth);
         ST_MARK(14);
     } else {

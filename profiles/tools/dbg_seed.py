@@ -1,9 +1,19 @@
-import os, sys
-os.environ["MLD_FORCE_THREAD_PATH"]="1"
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+"""One configuration of profiles/tools/random_sweep.py in detail: the features with the largest |depth - oracle|.
+usage: dbg_seed.py seed [route]     route: default | fused | wave-only | dense"""
+import os
+import sys
+from pathlib import Path
+route = sys.argv[2] if len(sys.argv) > 2 else "fused"
+if route != "default":
+    os.environ["MLD_FORCE_WAVE_PATH" if route == "wave-only" else "MLD_FORCE_THREAD_PATH"] = "1"
+    if route == "dense":
+        os.environ["MLD_K1MAX"] = "48"
+sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[2] / "tests"))
 import numpy as np
 from mono_lidar_depth_amd import GroundPlane, synth, capi
-capi._lib = capi.load_ab()
+if route != "default":
+    capi._lib = capi.load_ab()
 from helpers import make_estimator, run_oracle
 from test_randomized_gpu import _random_setup
 seed=int(sys.argv[1]) if len(sys.argv)>1 else 1990
