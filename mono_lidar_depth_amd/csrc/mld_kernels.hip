@@ -1137,8 +1137,8 @@ __device__ void road_qr(int n, const Lists& L, int lane, const SlotDesc& s, doub
 }
 
 // Left singular vector of the smallest singular value of M from the R of road_qr: one-sided (Hestenes) Jacobi on the
-// three rows of R^T - M = R^T Q^T, so the rows' inner products are M's - as the CPU restatement runs it on the rows of
-// M itself (oracle: mestimator_plane).
+// three rows of R^T - M = R^T Q^T, so the rows' inner products are M's - as the CPU restatement of the reference runs
+// it on the rows of M itself.
 __device__ __forceinline__ V3 normal_from_R(const double R[6]) {
     double B[3][3] = {{R[0], 0.0, 0.0}, {R[1], R[3], 0.0}, {R[2], R[4], R[5]}};
     double U[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
