@@ -2,7 +2,9 @@
 """Parity sweep beyond the committed seeds of tests/test_randomized_gpu.py: random parameter sets, cameras, mountings and
 scanners (the test's own generator), HIP against the oracle (TEST TOOL: the oracle is the checker) - result types equal,
 depths within 1e-4 m (bit-exact off the road / PCA paths), `_pointIndex` and the pixel map bit-exact.
-usage: random_sweep.py first_seed n_seeds [route]      route: default | fused | wave-only | dense (tests/conftest.py)"""
+usage: random_sweep.py first_seed n_seeds [route] [scanner]     route: default | fused | wave-only | dense (tests/conftest.py);
+       scanner "dense128": every configuration on the 128 x 4096 cloud of BASELINE config 5 with 4000 features (lists of up to
+       48 neighbours: the DENSE instantiations' register tiers)"""
 import sys
 import time
 from pathlib import Path
@@ -28,8 +30,11 @@ t0 = time.perf_counter()
 bad, types_seen, worst, worst_seed = [], {}, 0.0, -1
 for seed in range(first, first + count):
     P, cam, T, scanner, kw = _random_setup(seed)
+    nfeat = 900
+    if len(sys.argv) > 4 and sys.argv[4] == "dense128":
+        scanner, nfeat = synth.DENSE128, 4000
     cloud = synth.make_cloud(scanner, seed=200 + seed, frame=seed % 5)
-    uv = synth.make_features(900, seed=300 + seed, width=cam.width, height=cam.height)
+    uv = synth.make_features(nfeat, seed=300 + seed, width=cam.width, height=cam.height)
     plane = synth.make_ground_plane(cloud)
     est = make_estimator(P, camera=cam, T=T)
     try:
@@ -46,7 +51,8 @@ for seed in range(first, first + count):
         bad.append((seed, str(e)[:200]))
     finally:
         est.close()
-print(f"random sweep ({route} route): seeds {first} .. {first + count - 1}: {count - len(bad)} of {count} configurations equal to the oracle "
+tag = route + " route" + (", " + sys.argv[4] if len(sys.argv) > 4 else "")
+print(f"random sweep ({tag}): seeds {first} .. {first + count - 1}: {count - len(bad)} of {count} configurations equal to the oracle "
       f"in {time.perf_counter() - t0:.0f} s; max |depth - oracle| = {worst:.3e} m (seed {worst_seed})")
 print("result types met (type: features):", dict(sorted(types_seen.items())))
 for s, why in bad[:20]:
