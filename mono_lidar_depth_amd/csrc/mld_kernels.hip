@@ -1272,8 +1272,9 @@ __device__ __forceinline__ void finish_road(const Calib& c, bool triangle, doubl
 // tolerance of the exact form).  r[0..2]: weighted centre, r[3..8]: weighted scatter, r[9], r[10]: min / max z.
 // Returns false where the scatter cannot carry the normal to the road tolerance: the eigenvector's error is the sums'
 // rounding (a few 1e-15 of the trace) over the gap between the two small eigenvalues - nearly collinear points: returns of
-// one ring, of one azimuth - and the depth multiplies it by depth / cos(ray, normal).  Where that estimate passes 2e-5 m,
-// or the input is not finite, the caller hands the feature to the wave kernel (road_qr: SVD accuracy).  LAB.md 5.33.
+// one ring, of one azimuth - and the depth multiplies it by depth / cos(ray, normal).  Where that estimate could change
+// the OUTCOME - a depth handed out with more than 2e-5 m of it, a threshold decision within ten times of it - or the input
+// is not finite, the caller hands the feature to the wave kernel (road_qr: SVD accuracy).  LAB.md 5.33, 5.34.
 __device__ __forceinline__ bool finish_road_fast(const Calib& c, double u, double v, const double r[kRecFields],
                                                  int& out_type, double& out_depth) {
     const V3 dir = viewing_ray(c, u, v);
@@ -1310,12 +1311,32 @@ __device__ __forceinline__ bool finish_road_fast(const Calib& c, double u, doubl
 #ifndef MLD_ROAD_ERR_C
 #define MLD_ROAD_ERR_C 1e-14
 #endif
-    if (!(fabs(depth) * MLD_ROAD_ERR_C <= 2e-5 * gap * nd)) well = false;
+    const double raw = depth;
+    const double den = gap * nd;
+    // (est = 0 only for a clean estimate; a vanishing or NaN denominator gives +inf / NaN, which fails every test below)
+    const double est = fabs(raw) * MLD_ROAD_ERR_C / den;
     int type = MLD_SuccessRoad;
     const int th = apply_thresholds(c, r[9], r[10], depth);
     if (th) type = th;
     out_type = type;
     out_depth = (type == MLD_SuccessRoad) ? depth : -1.0;
+    // The depth itself is only handed out where no threshold touched it: there it must be good to 2e-5 m.  Where a
+    // threshold rejected or clamped it, the outcome (a result type, or the bound) is exact as long as the estimate stays
+    // clear of every bound by ten times its possible error - most ill-conditioned fits end kilometres away and are
+    // rejected by thresholds they miss by far; those need no second opinion.
+    if (type == MLD_SuccessRoad && depth == raw) {
+        well = est <= 2e-5;
+    } else {
+        const double m = 10.0 * est;
+        bool clear = m == m && m < 1.7976931348623157e308;  // (finite)
+        if (c.thrG_en) clear = clear && fabs(raw - c.thrG_min) > m && fabs(raw - c.thrG_max) > m;
+        if (c.thrL_en) {
+            const double tol = (c.thrL_type == 1) ? (r[10] - r[9]) * c.thrL_val : c.thrL_val;
+            // (after a global clamp the local test sees the bound, which is exact; before one, the raw depth)
+            clear = clear && fabs(raw - (r[9] - tol)) > m && fabs(raw - (r[10] + tol)) > m;
+        }
+        well = clear;
+    }
     return well;
 }
 
