@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""The secondary legs of the benchmark, one process, one GPU: everything `bench.py` reports BESIDE its headline line.
+
+    python bench_support/run_legs.py --legs estimated,latency,streaming,c2k,c3,c5 --out gpurun_out/bench_legs.json
+
+Legs (each inside its own try / except: a failing leg is recorded under "errors", the others still run):
+  estimated   config 2 with the plane of every frame estimated on the GPU (batched RANSAC), every frame re-checked
+  latency     one frame per call through the host-pointer entry points (PCIe-inclusive): supplied / RANSAC / semantic / process
+  streaming   pipelined host->device batches (PCIe-inclusive throughput), 16- and 32-byte records, repacked records
+  c2k         BASELINE config 2 at its stated neighbour count (k = 7), two contexts (c2k1: one context - counter passes)
+  c3          BASELINE config 3 (VLP-16, 5000 features, treatment-mode sweep) (c3n: the near-returns mode alone)
+  c5          BASELINE config 5 (128x4096, 10 000 tracks): one frame per call + batched S = 16 / 64 / 256
+              (c5b<S>: that batch size alone, one context; c5b<S>t: with the two-context schedule as well)
+The detail object {"legs": {...}, "verified": {leg: bool}, "errors": {leg: text}} is written to --out as ONE line; stdout gets
+the same line (profiles/summarize*.py read the last stdout line).  Exit code 1 if a leg ran and did not verify.
+"""
+from __future__ import annotations
+
+import argparse
+import gc
+import json
+import os
+import sys
+import time
+import traceback
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+DEFAULT_LEGS = "estimated,latency,streaming,c2k,c3,c5"
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--legs", default=DEFAULT_LEGS)
+    ap.add_argument("--out", default="")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--frames-per-step", type=int, default=1024)
+    ap.add_argument("--features", type=int, default=2000)
+    ap.add_argument("--unique-frames", type=int, default=16)
+    ap.add_argument("--contexts", type=int, default=2)
+    ap.add_argument("--shared-mode", type=int, default=1)
+    ap.add_argument("--est-steps", type=int, default=10)
+    ap.add_argument("--est-schedule", choices=["halves", "alternate"], default="halves")
+    ap.add_argument("--latency-frames", type=int, default=1000)
+    ap.add_argument("--streaming-batches", type=int, default=24)
+    ap.add_argument("--streaming-frames", type=int, default=64)
+    ap.add_argument("--config-frames", type=int, default=256)
+    return ap.parse_args(argv)
+
+
+def run(args):
+    gc.disable()  # (no cyclic collection while legs are timed; see bench.py)
+    import torch  # noqa: F401  (device memory for the legs)
+
+    from bench_support import legs as L
+    from mono_lidar_depth_amd import CameraPinhole, capi, synth
+
+    P = capi.params_c0()
+    cam = CameraPinhole(synth.KITTI_W, synth.KITTI_H, synth.KITTI_F, synth.KITTI_CU, synth.KITTI_CV)
+    T = synth.T_CAM_LIDAR
+    dev = args.device
+    B, F = args.frames_per_step, args.features
+    out, verified, errors, seconds = {}, {}, {}, {}
+    host = {}
+
+    def host_frames():  # (clouds / planes / features of the PCIe-inclusive legs: generated once)
+        if not host:
+            U = max(1, min(args.unique_frames, B))
+            host["clouds"] = [synth.make_cloud(synth.HDL64, seed=0, frame=f) for f in range(U)]
+            host["planes"] = [synth.make_ground_plane(c) for c in host["clouds"]]
+            host["uvs"] = [synth.make_features(F, seed=b) for b in range(max(U, args.streaming_frames))]
+        return host["clouds"], host["planes"], host["uvs"]
+
+    def leg_estimated():
+        r = L.estimated_leg(P, cam, T, dev, B, F, steps=args.est_steps, contexts=args.contexts,
+                            shared_mode=args.shared_mode, schedule=args.est_schedule)
+        return r, r["verified"]
+
+    def leg_latency():
+        c, p, u = host_frames()
+        r = L.latency_leg(P, cam, T, c, p, u, args.latency_frames, dev)
+        ok = True
+        if r.get("estimated"):
+            ok = all(r["estimated"][k]["verified"] for k in ("ransac", "semantic"))
+        return r, ok
+
+    def leg_streaming():
+        c, p, u = host_frames()
+        r = L.streaming_leg(P, cam, T, c, p, u, dev, args.streaming_frames, args.streaming_batches)
+        r["stride32"] = L.streaming_leg(P, cam, T, c, p, u, dev, args.streaming_frames, args.streaming_batches, stride_floats=8)
+        # the reference caller's records, repacked by host threads while they are staged (half the PCIe bytes)
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        r["stride32_packed"] = L.streaming_leg(P, cam, T, c, p, u, dev, args.streaming_frames, args.streaming_batches,
+                                               pack_threads=max(1, min(32, cores // 2)))
+        return r, r["stride32_packed"]["packed_equals_source"] is True
+
+    def leg_c2k(contexts):
+        r = {"near_returns": L.config2_k_leg(P, cam, T, dev, min(B, 1024), F, contexts=contexts, shared_mode=args.shared_mode)}
+        r["verified"] = r["near_returns"]["verified"]
+        return r, r["verified"]
+
+    def leg_c3(only_near):
+        r = L.config3_leg(cam, T, dev, args.config_frames, only_near=only_near)
+        return r, r["verified"]
+
+    def leg_c5(spec):
+        if spec:  # "256" / "256t"
+            S5 = int(spec.rstrip("t"))
+            r = {"workload": "BASELINE config 5, batched leg only",
+                 "batched": {str(S5): L.config5_batched_leg(cam, T, dev, S5, two_contexts=spec.endswith("t"))}}
+            r["verified"] = r["batched"][str(S5)]["verified"]
+            return r, r["verified"]
+        r = L.config5_leg(cam, T, dev, min(args.config_frames, 200))
+        r["batched"] = {str(S5): L.config5_batched_leg(cam, T, dev, S5, two_contexts=True) for S5 in (16, 64, 256)}
+        r["verified"] = bool(r["verified"] and all(v["verified"] for v in r["batched"].values()))
+        return r, r["verified"]
+
+    table = {"estimated": leg_estimated, "latency": leg_latency, "streaming": leg_streaming,
+             "c2k": lambda: leg_c2k(args.contexts), "c2k1": lambda: leg_c2k(1),
+             "c3": lambda: leg_c3(False), "c3n": lambda: leg_c3(True), "c5": lambda: leg_c5("")}
+    for name in [x for x in args.legs.split(",") if x and x != "none"]:
+        fn = table.get(name)
+        if fn is None and name.startswith("c5b"):
+            fn = (lambda spec: (lambda: leg_c5(spec)))(name[3:])
+        key = {"c2k": "2", "c2k1": "2", "c3": "3", "c3n": "3", "c5": "5"}.get(name, "5" if name.startswith("c5b") else name)
+        t0 = time.perf_counter()
+        try:
+            if fn is None:
+                raise ValueError(f"unknown leg {name!r}")
+            r, ok = fn()
+            out[key] = r
+            verified[name] = bool(ok)
+        except Exception as e:  # noqa: BLE001  (a secondary leg never takes the others down)
+            errors[name] = f"{type(e).__name__}: {e}"
+            print(f"[run_legs] leg {name} failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+        seconds[name] = round(time.perf_counter() - t0, 2)
+        try:
+            import torch
+            torch.cuda.empty_cache()
+        except Exception:  # noqa: BLE001
+            pass
+    configs = {k: out.pop(k) for k in ("2", "3", "5") if k in out}
+    return {"plane_estimated": out.get("estimated"), "latency": out.get("latency"), "streaming": out.get("streaming"),
+            "configs": configs, "verified": verified, "errors": errors, "seconds": seconds}
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    detail = run(args)
+    line = json.dumps(detail)
+    if args.out:
+        Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+        Path(args.out).write_text(line + "\n")
+    print(line, flush=True)
+    bad = [k for k, v in detail["verified"].items() if not v]
+    return 1 if (bad or detail["errors"]) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

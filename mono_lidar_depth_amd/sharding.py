@@ -158,7 +158,14 @@ def rebind_if_device_differs(info: dict, device_pci: Optional[str], sysfs_root: 
         return {**info, "reason": "device not found in sysfs / no NUMA node: affinity left as guessed"}
     try:
         with open(os.path.join(sysfs_root, f"devices/system/node/node{numa}/cpulist")) as f:
-            want = sorted(set(_parse_cpulist(f.read())))
+            want = set(_parse_cpulist(f.read()))
+        # never wider than the mask the process was started under (cgroup / taskset / launcher restriction)
+        allowed = info.get("initial_cpus")
+        if allowed is not None:
+            want &= set(allowed)
+        want = sorted(want)
+        if not want:
+            return {**info, "reason": "none of the right node's cores is in the process's initial affinity mask: left as guessed"}
         os.sched_setaffinity(0, want)
     except OSError as e:
         return {**info, "reason": f"re-bind failed: {e}"}
@@ -179,6 +186,7 @@ def bind_to_gpu_numa_node(local_rank: int, sysfs_root: str = "/sys") -> dict:
     except AttributeError:  # not Linux
         return info
     info["cpus"] = len(before)
+    info["initial_cpus"] = before  # (the mask the process was started under: a later re-bind stays inside it)
     gpus = gpu_numa_nodes(sysfs_root)
     visible = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")
     index = int(local_rank)

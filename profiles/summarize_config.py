@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/<tag>_config<N>_summary.md from gpurun_out/prof_<tag>/trace_c<N> (rocprofv3 --kernel-trace --stats of
-`python3 bench.py --only-config N`) and that run's JSON object."""
+`python3 bench_support/run_legs.py --legs cN`) and that run's JSON object."""
 import glob
 import json
 import os
@@ -14,8 +14,9 @@ fs = sorted(glob.glob(f"{src}/trace_c{cfg}/*/*kernel_stats.csv"), key=os.path.ge
 ks = pd.read_csv(fs[-1])
 ks = ks[ks.Name.str.contains("mld::")]
 b = json.loads(open(f"{src}/bench_c{cfg}.json").read().strip().splitlines()[-1])
+b = b.get("configs", {}).get(cfg, b)  # (bench_support/run_legs.py prints {"configs": {cfg: leg}, ...})
 lines = [f"# rocprofv3 summary - {tag}, BASELINE config {cfg}", "",
-         f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --only-config {cfg}`", "",
+         f"Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench_support/run_legs.py --legs c{cfg}`", "",
          b["workload"], "",
          "| kernel | calls | avg us | min us | max us | % |", "|---|---|---|---|---|---|"]
 for _, r in ks.iterrows():

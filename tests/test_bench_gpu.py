@@ -1,5 +1,6 @@
-"""bench.py end to end on the GPU box: the `--gpus N` launcher (two ranks sharing the one visible GPU, collectives over
-gloo through the MLD_BENCH_BACKEND hook) and the self-check of the timed batch against the oracle."""
+"""bench.py end to end on the GPU box: the compact contract line (one stdout line, <= 8 KB, physical roofline by the fixed
+rule, cpu_baseline), the detail file, the `--gpus N` launcher (ranks sharing the one visible GPU over the gloo hook), the
+fail-fast of a mis-sized RCCL launch, and the secondary legs (child process; a failing leg never takes the line down)."""
 import json
 import os
 import subprocess
@@ -12,119 +13,197 @@ ROOT = Path(__file__).resolve().parent.parent
 pytestmark = pytest.mark.gpu
 
 SMALL = ["--steps", "2", "--warmup", "1", "--repeats", "2", "--frames-per-step", "32", "--unique-frames", "4", "--cpu-seconds", "0",
-         "--latency-frames", "0", "--streaming-batches", "0", "--config-frames", "0"]
+         "--legs", "none"]
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "verified", "config", "roofline", "cpu_baseline")
 
 
-def _run(extra, env_extra=None):
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+def _env(env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                             "LOCAL_WORLD_SIZE")}
     env.update(env_extra or {})
+    return env
+
+
+def _run(extra, env_extra=None, tmp=None, rc=0):
+    detail = None
+    if tmp is not None:
+        detail = Path(tmp) / "detail.json"
+        extra = extra + ["--detail", str(detail)]
     r = subprocess.run([sys.executable, str(ROOT / "bench.py")] + extra, capture_output=True, text=True, timeout=900,
-                       env=env, cwd=str(ROOT))
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert len(lines) == 1, r.stdout[-2000:]
-    return json.loads(lines[0])
+                       env=_env(env_extra), cwd=str(ROOT))
+    assert r.returncode == rc, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    # stdout is the contract line and nothing else; it is small enough for any tail the driver keeps
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    assert len(lines[0].encode()) <= 8192, len(lines[0])
+    out = json.loads(lines[0])
+    if detail is not None:
+        out["_detail"] = json.loads(detail.read_text())
+    return out
 
 
-def test_bench_gpus_2_starts_two_ranks_and_each_checks_its_sequence():
+def _check_line(out):
+    for k in REQUIRED:
+        assert k in out, k
+    assert out["metric"] == "feature-depth associations/sec" and out["unit"].endswith("associations/s")
+    assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None
+    assert out["dtype"] == "f64" and out["data"] == "synthetic" and "workload" in out["config"]
+    assert all(len(v) <= 128 for v in out["config"].values() if isinstance(v, str))  # (what the driver keeps of a string)
+    r = out["roofline"]
+    for k in ("bound", "kernel", "kernel_ms", "traffic", "achieved", "peak", "unit", "frac", "bytes_source", "second"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and "PMC" in r["bytes_source"]
+    # PHYSICAL: counter bytes of the kernel over its hipEvent duration here; never above the peak
+    assert abs(r["achieved"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12 and 0.0 < r["frac"] <= 1.0
+    # THE RULE: the kernel with the longest average launch of the timed schedule, the other long one beside it
+    s = r["second"]
+    assert s["kernel"] != r["kernel"] and r["kernel_ms"] >= s["kernel_ms"] > 0
+    assert {r["kernel"], s["kernel"]} <= {"k_project_scatter", "k_feature_fused", "k_classify", "k_feature_wave"}
+    assert abs(s["frac"] - s["traffic"] / (s["kernel_ms"] * 1e-3) / 1e9 / 8000.0) <= 1e-9 and 0.0 < s["frac"] <= 1.0
+    assert "formula_frac" not in r and "formula_bytes_per_launch" not in r   # (formula figures live in the detail only)
+
+
+def test_bench_single_rank_line_is_compact_physical_and_verified(tmp_path):
+    out = _run(SMALL, tmp=tmp_path)
+    _check_line(out)
+    assert out["n_gpus"] == 1 and out["verified"] is True and out["frames_checked"] == 2 * 32
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
+    assert out["cpu_baseline"] is None and "legs" not in out   # (--cpu-seconds 0, --legs none)
+    r = out["roofline"]
+    assert 0.0 < r["frac_alone"] <= 1.0 and r["alone_ms"] > 0
+    ws = r["whole_step"]
+    assert 0.0 < ws["compulsory_frac"] <= ws["frac"] * 1.15 and ws["frac"] < 1.0
+    assert r["traffic"] <= ws["counter_bytes"] * (1 + 1e-9)
+    # ---- the detail file: everything the line left out
+    d = out["_detail"]
+    v = d["verification"]
+    assert v["output_sets"] == 2 and v["all_frames"] is True and v["frames_checked"] == 2 * 32
+    assert v["frames_per_output_set"] == [32, 32] and v["poison_left"]["type_minus77"] == 0 and v["mismatching_frames"] == []
+    rd = d["roofline"]
+    ks = rd["kernels"]
+    longest = max(ks, key=lambda k: ks[k]["avg_ms"])
+    assert rd["kernel"] == r["kernel"] == longest
+    assert ks["k_project_scatter"]["design_frac"] <= 1.0 and ks["k_project_scatter"]["formula_frac"] > 0
+    assert 0.0 < ks["k_feature_fused"]["gather"]["frac"] <= 1.0 and "never performs" in rd["formula_note"]
+    hb = rd["whole_step"]["hbm_busy"]
+    assert hb["streamed_bytes"] > rd["whole_step"]["compulsory_bytes"] and hb["random_lines"] > 0 and 0.0 < hb["frac_of_step"] < 1.5
+    assert rd["whole_step"]["compulsory_bytes"] == 16.0 * 131072 * 32
+    assert d["timed_loops"]["repeats"] >= 2 and len(d["timed_loops"]["ms_per_step"]) == d["timed_loops"]["repeats"]
+    assert d["result_types"] and d["frame_stats"]["n_visible"] > 0
+
+
+def test_bench_line_with_cpu_baseline_and_legs(tmp_path):
+    """The default shape of the line at small sizes: cpu_baseline measured, secondary legs run in the child process, their
+    verified flags and a few scalars on the line, their objects in the detail file."""
     args = [a for a in SMALL]
-    i = args.index("--streaming-batches")
-    args[i + 1] = "2"  # every rank streams its own sequence as well (BASELINE config 4)
-    out = _run(["--gpus", "2"] + args + ["--streaming-frames", "4"], {"MLD_BENCH_BACKEND": "gloo"})
-    assert out["n_gpus"] == 2 and out["config"]["sequences"] == 2
-    assert out["verified"] is True
-    assert out["value"] > 0 and out["scaling"] == "weak"
+    args[args.index("--cpu-seconds") + 1] = "6"
+    args[args.index("--legs") + 1] = "estimated,streaming,c3n"
+    out = _run(args + ["--streaming-batches", "3", "--streaming-frames", "4", "--config-frames", "16"], tmp=tmp_path)
+    _check_line(out)
+    c = out["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["ms_per_frame"] > 0 and len(c["sample"]) <= 128
+    lg = out["legs"]
+    assert lg["verified"] == {"estimated": True, "streaming": True, "c3n": True} and lg["errors"] == {} and lg["rc"] == 0
+    assert lg["brief"]["plane_estimated_ms_per_step"] > 0 and lg["brief"]["streaming_frames_per_s"]["repacked32"] > 0
+    d = out["_detail"]
+    pe = d["plane_estimated"]
+    assert pe["verified"] is True and pe["frames_checked"] == 32 and pe["all_frames"] is True
+    assert pe["mismatching_frames"] == [] and pe["poison_left"]["type_minus77"] == 0
+    st = d["streaming"]
+    assert st["stride_bytes"] == 16 and st["stride32"]["stride_bytes"] == 32
+    p = st["stride32_packed"]
+    assert p["stride_bytes"] == 16 and p["pack_threads"] >= 1 and p["packed_equals_source"] is True
+    assert p["frames"] == 12 and p["frames_per_s"] > 0
+    assert d["configs"]["3"]["near_returns"]["modes"]["c0_dispose"]["verified"] is True
+    assert d["cpu_baseline"]["stage_a_ms"] > 0 and d["cpu_baseline"]["one_thread"]["value"] > 0
+
+
+def test_bench_failing_leg_does_not_take_the_line_down(tmp_path):
+    out = _run(SMALL[:-1] + ["no_such_leg"], tmp=tmp_path)   # rc 0: the exit code follows the headline's `verified`
+    _check_line(out)
+    assert out["verified"] is True and "no_such_leg" in out["legs"]["errors"] and out["legs"]["rc"] == 1
+    assert out["_detail"]["errors"] == out["legs"]["errors"]
+
+
+def test_bench_gpus_2_starts_two_ranks_and_each_checks_its_sequence(tmp_path):
+    out = _run(["--gpus", "2"] + SMALL[:-2] + ["--streaming-batches", "2", "--streaming-frames", "4"], {"MLD_BENCH_BACKEND": "gloo"},
+               tmp=tmp_path)
+    _check_line(out)
+    assert out["n_gpus"] == 2 and out["config"]["sequences"] == 2 and out["verified"] is True and out["value"] > 0
     d = out["distributed"]
     assert d["backend"] == "gloo" and d["world_size"] == 2 and d["ranks_verified"] == 2
-    assert 0 < d["resident_associations_per_s_per_rank"]["min"] <= d["resident_associations_per_s_per_rank"]["max"]
-    st = out["streaming"]
+    assert d["gpus_distinct"] == 1     # (the hook: both ranks on the one visible GPU - an RCCL run reports N)
+    assert d["streaming_frames_per_s"] > 0
+    dd = out["_detail"]["distributed"]
+    assert 0 < dd["resident_associations_per_s_per_rank"]["min"] <= dd["resident_associations_per_s_per_rank"]["max"]
+    st = out["_detail"]["streaming"]   # every rank streams its own sequence as well (BASELINE config 4)
     assert st["ranks"] == 2 and st["frames_per_s"] > 0
     assert 0 < st["frames_per_s_per_rank"]["min"] <= st["frames_per_s_per_rank"]["max"]
 
 
-def test_bench_gpus_8_over_gloo_every_rank_its_own_sequence():
+def test_bench_gpus_8_over_gloo_every_rank_its_own_sequence(tmp_path):
     """BASELINE config 4's layout at full rank count where only one GPU is visible: eight ranks (sequences 0 ... 7), one
     calibration broadcast, no data-path collective, every rank verifies and streams its own sequence.  (On an 8-GPU node
-    the same command without the hook runs over RCCL: `backend: nccl`.)"""
+    the same command without the hook runs over RCCL: `backend: nccl`, `gpus_distinct: 8`.)"""
     tiny = ["--steps", "2", "--warmup", "1", "--repeats", "1", "--min-timed-seconds", "0", "--frames-per-step", "8",
-            "--unique-frames", "2", "--features", "500", "--cpu-seconds", "0", "--latency-frames", "0", "--streaming-batches", "2",
-            "--streaming-frames", "2", "--config-frames", "0", "--no-estimated", "--no-exclusive"]
-    out = _run(["--gpus", "8"] + tiny, {"MLD_BENCH_BACKEND": "gloo"})
+            "--unique-frames", "2", "--features", "500", "--cpu-seconds", "0", "--streaming-batches", "2",
+            "--streaming-frames", "2", "--no-exclusive"]
+    out = _run(["--gpus", "8"] + tiny, {"MLD_BENCH_BACKEND": "gloo"}, tmp=tmp_path)
     assert out["n_gpus"] == 8 and out["config"]["sequences"] == 8 and out["verified"] is True
     d = out["distributed"]
     assert d["backend"] == "gloo" and d["world_size"] == 8 and d["ranks_verified"] == 8
-    assert len(d["affinity"]["numa_node_per_rank"]) == 8 and d["affinity"]["rank0"]["local_rank"] == 0
-    st = out["streaming"]
+    aff = out["_detail"]["distributed"]["affinity"]
+    assert len(aff["numa_node_per_rank"]) == 8 and aff["rank0"]["local_rank"] == 0
+    st = out["_detail"]["streaming"]
     assert st["ranks"] == 8 and st["frames"] == 4 and st["frames_per_s"] > 0
-    assert 0 < st["frames_per_s_per_rank"]["min"] <= st["frames_per_s_per_rank"]["max"]
     assert out["value"] > 0 and out["scaling"] == "weak" and out["config"]["parallelism"] == "sequence-per-gpu x8"
 
 
-def test_bench_single_rank_line_is_physical():
-    out = _run(SMALL)
-    assert out["n_gpus"] == 1 and out["verified"] is True
-    r = out["roofline"]
-    # the line's roofline is PHYSICAL: HBM bytes the counters saw for the dominant kernel (committed profile, scaled to this
-    # run's launch size) over its hipEvent duration here; nothing on top is derived from SURVEY 8(d)'s formula bytes
-    assert 0.0 < r["frac"] <= 1.0 and r["bound"] == "hbm" and r["peak"] == 8000.0
-    assert abs(r["achieved"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-6 * r["achieved"]
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-12
-    assert "PMC" in r["bytes_source"]
-    assert 0.0 < r["frac_exclusive"] <= 1.0 and 0.0 < r["whole_step_frac_of_peak"] <= 1.0
-    assert 0.0 < r["whole_step_compulsory_frac"] <= r["whole_step_frac_of_peak"] * 1.15
-    assert 0.0 < r["gather_frac"] <= 1.0 and 0.0 < r["feature_kernel_frac"] <= 1.0
-    # the dominant kernel's bytes are part of the step's bytes (a step of this size is one launch set per context)
-    assert r["traffic"] <= r["whole_step"]["counter_bytes"] * (1 + 1e-9)
-    # the formula figures are kept, marked as such, and may exceed the peak
-    assert r["formula_frac"] > 0 and r["whole_step_formula_frac"] > 0 and "never performs" in r["formula_note"]
-    assert r["kernels"]["k_project_scatter"]["frac"] <= 1.0 and r["kernels"]["k_project_scatter"]["design_frac"] <= 1.0
-    assert out["verification"]["mismatching_frames"] == []
-    # the dominant kernel is the one with the longest measured launch; both long kernels carry their own roofline
-    ks = r["kernels"]
-    longest = max(ks[k]["avg_ms"] for k in ("k_project_scatter", "k_feature_fused"))
-    near = [k for k in ("k_project_scatter", "k_feature_fused") if ks[k]["avg_ms"] >= 0.85 * longest]
-    assert r["kernel"] == max(near, key=lambda k: ks[k]["traffic"])   # (most bytes among the near-longest launches)
-    assert ks["k_feature_fused"]["bound"] == "hbm" and 0.0 < ks["k_feature_fused"]["frac"] <= 1.0
-    # EVERY frame of both contexts' output sets was checked against the oracle, no poisoned entry survived the timed
-    # region, several timed loops ran
-    v = out["verification"]
-    assert v["output_sets"] == 2 and v["all_frames"] is True and v["frames_checked"] == 2 * 32
-    assert v["frames_per_output_set"] == [32, 32] and v["poison_left"]["type_minus77"] == 0
-    pe = out["plane_estimated"]
-    assert pe["verified"] is True and pe["frames_checked"] == 32 and pe["all_frames"] is True
-    assert pe["mismatching_frames"] == [] and pe["poison_left"]["type_minus77"] == 0
-    ws = r["whole_step"]
-    assert ws["compulsory_bytes"] == 16.0 * 131072 * 32 and 0.0 < ws["compulsory_frac_of_peak"] < 1.0
-    assert ws["counter_bytes"] > ws["compulsory_bytes"] * 0.9 and 0.0 < ws["frac_of_peak"] < 1.0
-    # HBM time of the step from the committed counters: streamed bytes at the projection's own rate + random lines
-    hb = ws["hbm_busy"]
-    assert hb["streamed_bytes"] > ws["compulsory_bytes"] and hb["random_lines"] > 0 and 0.0 < hb["frac_of_step"] < 1.5
-    assert out["timed_loops"]["repeats"] >= 2 and out["ms_per_step_min"] <= out["ms_per_step"] <= out["ms_per_step_max"]
+def test_bench_rccl_launch_wider_than_the_node_fails_fast():
+    """`--gpus 2` over the real nccl backend on a one-GPU box: refused before any rank starts (exit 3, legible message),
+    never an N-rank number from fewer GPUs.  The worker-side check (a launcher that did start the ranks) names the rank."""
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True,
+                       timeout=300, env=_env(), cwd=str(ROOT))
+    assert r.returncode == 3 and r.stdout.strip() == "" and "needs 2 visible GPUs" in r.stderr
+    env = _env({"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2", "LOCAL_WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": "29581"})
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"] + SMALL, capture_output=True, text=True,
+                       timeout=300, env=env, cwd=str(ROOT))
+    assert r.returncode == 3 and r.stdout.strip() == "" and "rank 1" in r.stderr and "refusing to share a GPU" in r.stderr
 
 
-def test_bench_schedules_agree():
+def test_bench_schedules_agree(tmp_path):
     """The default schedule (whole steps alternating between two contexts), launch sets of a step alternating
     (`--slots`) and a single context produce verified lines with the schedule they name; the kernels-alone figures
     appear only where two contexts share the GPU."""
-    a = _run(SMALL)
-    assert a["config"]["contexts"] == 2 and a["config"]["frame_slots_per_launch"] == 32
-    assert a["roofline"]["kernel"] in ("k_project_scatter", "k_feature_fused") and a["roofline"]["exclusive"]["frac"] > 0
-    b = _run(SMALL + ["--slots", "8", "--verify-slots", "6"])  # (the opt-down: six frames instead of all)
+    a = _run(SMALL, tmp=tmp_path)
+    assert a["config"]["contexts"] == 2 and a["config"]["frame_slots_per_launch"] == 32 and a["roofline"]["alone_ms"] > 0
+    b = _run(SMALL + ["--slots", "8", "--verify-slots", "6"], tmp=tmp_path)  # (the opt-down: six frames instead of all)
     assert b["verified"] is True and b["config"]["frame_slots_per_launch"] == 8
-    assert b["verification"]["all_frames"] is False and b["verification"]["frames_checked"] == 6
-    c = _run(SMALL + ["--contexts", "1"])
-    assert c["verified"] is True and c["roofline"]["exclusive"] is None and c["config"]["contexts"] == 1
+    assert b["_detail"]["verification"]["all_frames"] is False and b["frames_checked"] == 6
+    c = _run(SMALL + ["--contexts", "1"], tmp=tmp_path)
+    assert c["verified"] is True and c["roofline"]["alone_ms"] is None and c["config"]["contexts"] == 1
     # (result types are summed over the output sets: two with the default schedule, one otherwise)
-    assert b["result_types"] == c["result_types"]
-    assert a["result_types_output_sets"] == 2 and a["result_types"] == {k: 2 * v for k, v in c["result_types"].items()}
+    ta, tb, tc = (x["_detail"]["result_types"] for x in (a, b, c))
+    assert tb == tc and ta == {k: 2 * v for k, v in tc.items()}
 
 
-def test_bench_dense_leg_two_contexts_is_verified_and_steady():
+def _legs(legs, extra=()):
+    r = subprocess.run([sys.executable, str(ROOT / "bench_support" / "run_legs.py"), "--legs", legs] + list(extra),
+                       capture_output=True, text=True, timeout=900, env=_env(), cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+def test_dense_leg_two_contexts_is_verified_and_steady():
     """Config 5 (dense clouds, tracklet layer) with two sets of sequences in turn: every sequence of the last step equals the
     oracle, the second set's outputs equal the first's, and the five repetitions agree - the 2x outliers of rounds 4-5 were
     a host stall (profiles/r5_host_stall.md); the host-side submit time per repetition is reported so that one would show."""
-    out = _run(["--only-config", "5", "--leg", "16t"])
-    leg = out["batched"]["16"] if "batched" in out else out["configs"]["5"]["batched"]["16"]
+    out = _legs("c5b16t")
+    assert out["verified"] == {"c5b16t": True} and out["errors"] == {}
+    leg = out["configs"]["5"]["batched"]["16"]
     assert leg["verified"] is True and leg["sequences_checked"] == 16 and leg["mismatching_sequences"] == []
     # the leg's own physical roofline (counter bytes of the committed S = 256 profile scaled to this launch size)
     r = leg["roofline"]
@@ -135,16 +214,3 @@ def test_bench_dense_leg_two_contexts_is_verified_and_steady():
     assert len(runs) == 5 and max(runs) <= 1.25 * min(runs), runs
     assert max(submit) < min(runs), (submit, runs)   # the host stays ahead of the device in every repetition
     assert two["classify"]["ms_per_step"] < leg["ms_per_step"] * 1.05   # (two sets in turn are not slower than one)
-
-
-def test_bench_streaming_legs_include_the_repacked_pcl_records():
-    """`streaming`: pinned 16-byte batches, pinned 32-byte batches, and 32-byte records in ordinary memory repacked by host
-    threads while staged (mld_pack_points_host) - the repacked batch equals the source clouds."""
-    args = [a for a in SMALL]
-    args[args.index("--streaming-batches") + 1] = "3"
-    out = _run(args + ["--streaming-frames", "4"])
-    st = out["streaming"]
-    assert st["stride_bytes"] == 16 and st["stride32"]["stride_bytes"] == 32
-    p = st["stride32_packed"]
-    assert p["stride_bytes"] == 16 and p["pack_threads"] >= 1 and p["packed_equals_source"] is True
-    assert p["frames"] == 12 and p["frames_per_s"] > 0

@@ -124,6 +124,14 @@ def test_rank_is_pinned_to_the_numa_node_of_its_gpu(tmp_path, monkeypatch):
         assert sorted(os.sched_getaffinity(0)) == hi
         unknown = sharding.rebind_if_device_differs(e, None, str(tmp_path))
         assert unknown["pci_matches"] is None
+        # a rank started under a restricted mask (cgroup / taskset) is never widened past it by the correction: started on
+        # the lower half only, the right node's cores (upper half) are all outside -> affinity left as guessed, reason given
+        os.sched_setaffinity(0, lo)
+        f = sharding.bind_to_gpu_numa_node(0, str(tmp_path))
+        assert f["initial_cpus"] == lo
+        kept = sharding.rebind_if_device_differs(f, "0000:85:00.0", str(tmp_path))
+        assert "corrected_after_init" not in kept and "initial affinity mask" in kept["reason"]
+        assert sorted(os.sched_getaffinity(0)) == lo
     finally:
         os.sched_setaffinity(0, have)
     assert sharding.bind_to_gpu_numa_node(0, str(tmp_path / "nothing"))["applied"] is False

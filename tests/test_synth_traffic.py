@@ -51,22 +51,14 @@ def test_committed_counter_profile_prices_every_leg():
     """profiles/traffic.json is what bench.py prices its rooflines on: the config-2 kernels at the top level and one entry
     per counter-profiled leg (config 2 at k = 7, config 3 near the returns, config 5 at 256 sequences).  A summariser that
     drops the per-leg entries would silently turn those legs' `roofline` objects into null."""
-    import importlib.util
     import json
-    import sys
     from pathlib import Path
     root = Path(__file__).resolve().parent.parent
     tj = json.loads((root / "profiles" / "traffic.json").read_text())
     for k in ("k_project_scatter", "k_classify", "k_feature_fused"):
         assert tj[k]["hbm_bytes_per_launch"] > 0 and tj[k]["launch_s"] > 0
     assert set(tj["configs"]) >= {"2k", "3n", "5b256"}
-    argv, sys.argv = sys.argv, ["bench.py"]
-    try:
-        spec = importlib.util.spec_from_file_location("bench_for_test", root / "bench.py")
-        bench = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(bench)
-    finally:
-        sys.argv = argv
+    from bench_support import rooflines as bench
     kt = {"k_project_scatter": {"avg_ms": 0.5}, "k_classify": {"avg_ms": 0.1}, "k_feature_fused": {"avg_ms": 0.8},
           "k_feature_wave": {"avg_ms": 0.01}, "k_rs_batch": {"avg_ms": 0.0}}
     for key, frames in (("2k", 1024), ("3n", 256), ("5b256", 256), ("5b16", 16)):
