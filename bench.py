@@ -288,6 +288,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
 
+    # stdout carries the contract line and nothing else: whatever a library prints there from now on (gloo's connection
+    # notes, a runtime warning) goes to stderr; the line itself is written to the saved descriptor at the very end
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -545,7 +551,7 @@ def main():
         line.pop("legs", None)
         text = json.dumps(line)
     log(f"bench.py: detail in {detail_path}")
-    print(text, flush=True)
+    os.write(line_fd, (text + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
     sys.exit(1 if verified is False else 0)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define MLD_ABI_VERSION 7
+#define MLD_ABI_VERSION 8
 
 typedef enum mld_status {
     MLD_OK = 0,
@@ -163,6 +163,16 @@ const char* mld_last_error(const mld_ctx* ctx);
 
 /* The hipStream_t the context launches on (as void*), for callers that order their own work. */
 void* mld_get_stream(mld_ctx* ctx);
+
+/*
+ * Do the streams of two contexts execute side by side?  1 = yes; 0 = they share a hardware queue of the HIP runtime
+ * (their kernels run strictly in turn: mld_order_after[_classify] / mld_set_shared_gpu then buy nothing) or are the same
+ * context; < 0 = error.  The runtime multiplexes a process's streams on a few hardware queues (four per priority unless
+ * GPU_MAX_HW_QUEUES says otherwise), so mld_create probes a new context's stream against every live context of its device
+ * and replaces it until it has a queue of its own (up to six tries); this call repeats the probe on demand (both streams
+ * are synchronised, two one-wavefront kernels run: ~50 us; 3 ms when the answer is 0).  No reference counterpart.
+ */
+int mld_contexts_concurrent(mld_ctx* a, mld_ctx* b);
 int mld_synchronize(mld_ctx* ctx);
 
 /*
@@ -215,13 +225,25 @@ int mld_set_shared_gpu(mld_ctx* ctx, int shared);
  * longer are handled by the wave-cooperative kernel (same results, ~10x the cost per feature).  Default 32 / 24: right
  * for 64-beam clouds (config 2: 11 / 2.3 neighbours on average).  Dense clouds (128 beams x 4096: 16 / 6 on average, 48
  * at most in the road window) want 48 / 24: BASELINE config 5 at batch size runs 1.8x faster with it.  LDS per wavefront
- * = (wide + narrow) * 256 bytes.  8 <= narrow <= wide <= 64.  Capacities beyond the default also select the kernel's
+ * = (wide + narrow) * 256 bytes unless mld_set_list_budget lowers it.  8 <= narrow <= wide <= 64.  Capacities beyond the default also select the kernel's
  * DENSE instantiations: the corner search over the segmented points and the histogram's depths in registers - up to 24 of
  * each at two wavefronts per SIMD when the context has the GPU to itself, up to 16 inside 168 registers when
  * mld_set_shared_gpu is on, so that another context's projection finds room beside it (config 5 at 256 sequences per
  * step: 1.12 G associations/s in round 4 -> 1.85 G with one context, 1.98 G with two in turn).
  */
 int mld_set_list_capacity(mld_ctx* ctx, int wide_entries, int narrow_entries);
+
+/*
+ * LDS entries per feature that the two lists SHARE (the narrow lists of a wavefront's 64 features are stored behind the
+ * longest of their wide lists): a feature stays on the lane-per-feature kernel when wide <= wide capacity, narrow <= narrow
+ * capacity and (longest wide list of its wavefront) + narrow <= total.
+ * LDS per wavefront = total * 256 bytes, which sets how many wavefronts of the kernel a CU holds (160 KB / that, at most
+ * four per SIMD).  A new context: capacities 32 / 24, budget 40 (10 KB, 16 wavefronts per CU; on 64-beam and 16-beam
+ * clouds no list pair comes near it: wide + narrow <= 27 on BASELINE configs 2 and 3).  mld_set_list_capacity resets the
+ * budget to wide + narrow (both lists at their longest: the dense 128-beam clouds of config 5 reach 66 of 48 + 24).
+ * wide capacity <= total_entries <= wide + narrow capacity; 0 = wide + narrow.
+ */
+int mld_set_list_budget(mld_ctx* ctx, int total_entries);
 
 /*
  * setInputCloud (DepthEstimator.cpp:220-312): projection + pixel->point map for one slot.

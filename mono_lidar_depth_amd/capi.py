@@ -12,7 +12,7 @@ from pathlib import Path
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "lib" / "libmld_hip.so"
 
-MLD_ABI_VERSION = 7  # include/mld.h
+MLD_ABI_VERSION = 8  # include/mld.h
 MLD_OK = 0
 MLD_ERR_INVALID_ARG = -1
 MLD_ERR_NOT_INITIALIZED = -2
@@ -146,6 +146,8 @@ _SIGNATURES = [
     ("mld_pair_contexts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mld_set_shared_gpu", C.c_int, [C.c_void_p, C.c_int]),
     ("mld_set_list_capacity", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("mld_set_list_budget", C.c_int, [C.c_void_p, C.c_int]),
+    ("mld_contexts_concurrent", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mld_set_cloud", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     ("mld_set_cloud_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     ("mld_set_clouds_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64), C.c_int]),

@@ -5,6 +5,8 @@
 // There is no CPU fallback: every entry point that computes goes through the HIP kernels.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -145,7 +147,8 @@ struct mld_ctx {
     int32_t* queue_slab = nullptr;   // per slot: overflow queue (2F), live queue (F)
     uint32_t* bitmaps = nullptr;  // occupancy bitmaps of all slots, contiguous
     size_t bitmap_words = 0;      // per slot
-    std::vector<SlotDesc> h_descs;
+    std::vector<SlotDesc> h_descs;      // what the device copy of the slot descriptors holds (upload_descs)
+    std::vector<SlotDesc> desc_stage;   // descriptors about to be uploaded; committed to h_descs once the upload is queued
     size_t lds_bytes = 0;     // k_feature_wave: xyz list of one window
     size_t lds_fused = 0;     // k_feature_fused: wide list + narrow list per wave
     size_t lds_classify = 0;  // k_classify: bucket counters + the slot's bitmap
@@ -235,6 +238,8 @@ struct mld_ctx {
     struct ProjShare* proj_share = nullptr;  // the pair's stream, reference counted: the last context to go destroys it
     hipEvent_t proj_fork = nullptr, proj_join = nullptr;
     size_t lds_fused_pad = 0;       // mld_set_shared_gpu
+    int queue_probe_tries = 0;      // separate_stream_from_live_contexts: probes run when the context was created
+    int queue_shared_with_live = 0; // ... live contexts whose hardware queue its stream still shares (0 = none)
     int shared_arg = 0;             // its last argument (re-applied when the list capacities change)
     int fused_blocks_per_cu = 8;    // mld_set_shared_gpu: wavefronts of k_feature_fused per CU in the shared mode
     size_t lds_per_cu = 0;          // device property
@@ -438,10 +443,12 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     c.threadPath = 1;
     c.xcdAware = 1;
     c.sortClasses = 4;
-    // list capacities of the fused kernel: 32 entries for the scanned (road) window, 24 for the narrow one - 14 KB of
-    // LDS per wavefront; longer lists overflow to the wave-cooperative kernel
+    // list capacities of the fused kernel: up to 32 entries for the scanned (road) window, up to 24 for the narrow one,
+    // 40 entries of LDS per lane for the two together (the narrow list sits behind the lane's wide list) - 10 KB per
+    // wavefront: 16 wavefronts per CU, four per SIMD; longer lists overflow to the wave-cooperative kernel
     c.k1max = 32;
     c.kMain = 24;
+    c.kTotal = 40;
 #ifdef MLD_AB_SWITCHES
     // Test / measurement build only (libmld_hip_ab.so): the shipped library has one code path and reads no environment.
     //   MLD_FORCE_WAVE_PATH=1  every feature through the wave-cooperative kernel (the parity suite runs both paths)
@@ -464,8 +471,11 @@ void build_calib(mld_ctx* ctx, const double T[12]) {
     if (const char* e = std::getenv("MLD_FRAME_HELPER")) ctx->fr_helper_on = e[0] != '0';
     if (const char* e = std::getenv("MLD_K1MAX")) c.k1max = std::min(std::max(std::atoi(e), 8), kK1MaxLimit);
     if (const char* e = std::getenv("MLD_KMAIN")) c.kMain = std::min(std::max(std::atoi(e), 8), c.k1max);
+    if (std::getenv("MLD_K1MAX") || std::getenv("MLD_KMAIN")) c.kTotal = c.k1max + c.kMain;
+    //   MLD_KTOTAL=n           LDS entries per lane shared by the two lists (k1max <= n <= k1max + kMain)
+    if (const char* e = std::getenv("MLD_KTOTAL")) c.kTotal = std::min(std::max(std::atoi(e), c.k1max), c.k1max + c.kMain);
 #endif
-    ctx->lds_fused = (size_t)(c.k1max + c.kMain) * kWave * sizeof(uint32_t);
+    ctx->lds_fused = (size_t)c.kTotal * kWave * sizeof(uint32_t);
     ctx->bm_ncol = (ctx->cam.width + 31) / 32 + 1;
     ctx->bm_ncolp = ctx->bm_ncol | 1;
     const size_t cls_fixed = (size_t)(kClsBuckets + kClsThreads / kWave + 4) * sizeof(int);
@@ -824,7 +834,11 @@ int launch_features(mld_ctx* ctx, int n_slots, int64_t max_F, bool single, int s
         // wavefronts per SIMD, which is what their LDS allows anyway, and the registers of the third for the in-register
         // corner search (up to 24 points); 1 = in the shared-GPU mode, whose point is to leave registers to the other
         // context's projection: the same within 168 registers (corner search up to 16 points)
-        const int dense = (calib.k1max > 32 || calib.kMain > 24) ? ((ctx->shared_arg & 1) ? 1 : 2) : 0;
+        int dense = (calib.k1max > 32 || calib.kMain > 24) ? ((ctx->shared_arg & 1) ? 1 : 2) : 0;
+#ifdef MLD_AB_SWITCHES
+        //   MLD_FORCE_DENSE=0|1|2  (measurement) the instantiation of the lane-per-feature kernel, whatever the capacities
+        if (const char* e = std::getenv("MLD_FORCE_DENSE")) dense = std::min(std::max(std::atoi(e), 0), 2);
+#endif
         auto kf = dense == 2 ? (calib.roadMode ? mld::k_feature_fused<1, 2> : mld::k_feature_fused<0, 2>)
                   : dense == 1 ? (calib.roadMode ? mld::k_feature_fused<1, 1> : mld::k_feature_fused<0, 1>)
                                : (calib.roadMode ? mld::k_feature_fused<1, 0> : mld::k_feature_fused<0, 0>);
@@ -856,17 +870,22 @@ int upload_descs(mld_ctx* ctx, int n_slots, hipStream_t st, int first, bool tags
     // Steady-state batches (same buffers every step) change nothing but the map tags, and a tag common to the
     // batch travels as a kernel argument: skip the upload when the device copy is still right.
     const bool tags_by_arg = !tags_in_descs && common_tag(ctx, n_slots, first) != 0u;
+    // The host cache (h_descs = what the device holds) is committed only AFTER the upload was queued: a failed upload
+    // (ring capacity, a HIP error) must leave the range dirty, or the next call would skip it and the kernels - which read
+    // the device copy only - would run on stale descriptors.
     bool dirty = false;
+    ctx->desc_stage.resize((size_t)n_slots);
     for (int i = first; i < first + n_slots; i++) {
-        SlotDesc d = ctx->slots[i].d;
+        SlotDesc& d = ctx->desc_stage[(size_t)(i - first)];
+        d = ctx->slots[i].d;
         if (tags_by_arg) d.tag = 0;
-        if (std::memcmp(&d, &ctx->h_descs[i], sizeof(SlotDesc)) != 0) {
-            ctx->h_descs[i] = d;
-            dirty = true;
-        }
+        dirty = dirty || std::memcmp(&d, &ctx->h_descs[i], sizeof(SlotDesc)) != 0;
     }
     if (!dirty) return MLD_OK;
-    return upload_small(ctx, ctx->d_slots + first, ctx->h_descs.data() + first, sizeof(SlotDesc) * n_slots, st);
+    const int rc = upload_small(ctx, ctx->d_slots + first, ctx->desc_stage.data(), sizeof(SlotDesc) * n_slots, st);
+    if (rc != MLD_OK) return rc;
+    std::memcpy(ctx->h_descs.data() + first, ctx->desc_stage.data(), sizeof(SlotDesc) * n_slots);
+    return MLD_OK;
 }
 
 int precheck_calc(mld_ctx* ctx, Slot& s, int64_t F) {
@@ -972,6 +991,70 @@ extern "C" {
 
 const char* mld_create_error(void) { return g_create_error.c_str(); }
 
+// ---------------------------------------------------------------------------- hardware queues of the contexts' streams
+// Contexts of one device are meant to run side by side (mld_order_after[_classify], mld_set_shared_gpu), but the HIP
+// runtime hands a new stream one of a few hardware queues - four per priority by default (GPU_MAX_HW_QUEUES), shared with
+// every other stream of the process: the caller's, torch's stream pool ... - and streams on one queue execute strictly in
+// turn.  Two contexts that landed on one queue lose their whole overlap, silently and for the life of the process (seen in
+// round 6: the secondary bench legs ran 1.37x slower in a process whose earlier legs had left streams behind).  So a new
+// context PROBES its stream against the stream of every live context of its device (k_probe_wait / k_probe_set) and, while
+// it shares a queue with one of them, takes another stream (the rejected ones are held until the search ends, so that the
+// runtime's least-used-queue choice moves on).
+namespace {
+std::mutex g_live_mu;
+std::vector<mld_ctx*> g_live;  // contexts between mld_create and mld_destroy
+
+// 1 = the streams run side by side, 0 = they share a hardware queue (or the GPU was too busy to tell), < 0 = HIP error
+int probe_streams_concurrent(hipStream_t waiter, hipStream_t setter) {
+    uint32_t* host = nullptr;  // [0] flag, [16] result: pinned, device-visible
+    if (hipHostMalloc((void**)&host, 128, hipHostMallocDefault) != hipSuccess) return -1;
+    host[0] = 0u;
+    host[16] = 0u;
+    int out = -1;
+    // both streams idle first: the setter must not sit behind queued work of its own stream
+    if (hipStreamSynchronize(setter) == hipSuccess && hipStreamSynchronize(waiter) == hipSuccess) {
+        hipLaunchKernelGGL(mld::k_probe_wait, dim3(1), dim3(kWave), 0, waiter, host, host + 16, 3000);  // gives up after ~3 ms
+        hipLaunchKernelGGL(mld::k_probe_set, dim3(1), dim3(kWave), 0, setter, host);
+        if (hipGetLastError() == hipSuccess && hipStreamSynchronize(waiter) == hipSuccess &&
+            hipStreamSynchronize(setter) == hipSuccess)
+            out = host[16] == 1u ? 1 : 0;
+    }
+    (void)hipHostFree(host);
+    return out;
+}
+
+// The new context's stream: distinct hardware queue from every live context of the device, if a handful of tries finds one.
+void separate_stream_from_live_contexts(mld_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    std::vector<hipStream_t> rejected;
+    ctx->queue_probe_tries = 0;
+    ctx->queue_shared_with_live = 0;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        int shared = 0;
+        for (mld_ctx* o : g_live) {
+            if (o == ctx || o->device != ctx->device || !o->stream) continue;
+            const int r = probe_streams_concurrent(ctx->stream, o->stream);
+            ctx->queue_probe_tries++;
+            if (r == 0) shared++;
+            if (r < 0) {  // (a HIP error here is not this function's to report: the context works either way)
+                (void)hipGetLastError();
+                shared = 0;
+                attempt = 99;
+                break;
+            }
+        }
+        ctx->queue_shared_with_live = shared;
+        if (!shared || attempt >= 5) break;
+        hipStream_t fresh = nullptr;
+        if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) != hipSuccess) break;
+        rejected.push_back(ctx->stream);
+        ctx->stream = fresh;
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    g_live.push_back(ctx);
+}
+}  // namespace
+
 mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const double T_cam_lidar[12], int device,
                     int max_frames, int64_t max_points, int64_t max_features, int* status_out) {
     auto bail = [&](int code, const std::string& msg) -> mld_ctx* {
@@ -1024,6 +1107,7 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     }
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
         return hip_bail(e, "hipStreamCreate");
+    separate_stream_from_live_contexts(ctx);  // (a hardware queue of its own among the device's contexts)
     if (ctx->lds_bytes > 48 * 1024) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(mld::k_feature_wave<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)ctx->lds_bytes);
@@ -1060,6 +1144,10 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
     // the upload ring at its working size now (pinning costs milliseconds): a step's largest upload is its descriptors
     // (contexts with several slots may deal their slots' features to group descriptors - 256 of them, room for 512:
     // mld_tracklets_depths_device)
+    constexpr size_t kMaxGroupDescs = 256;  // mld_tracklets_depths_device: G <= 256 / n_desc groups of n_desc descriptors
+    static_assert(kMaxGroupDescs <= 512, "the group descriptors of a launch set must fit one generation of the upload ring");
+    // (a launch set of n_seq sequences uses 2 n_seq <= max_frames slots: its TrkSeq table fits where its descriptors do)
+    static_assert(sizeof(TrkSeq) <= 2 * sizeof(SlotDesc), "a sequence's TrkSeq must fit the ring share of its two slots");
     const size_t up_descs = max_frames >= 2 ? std::max<size_t>((size_t)max_frames, 512) : 1;
     ctx->up_gen_bytes = (std::max(sizeof(SlotDesc) * up_descs, sizeof(Calib)) + 4095) / 4096 * 4096;
     if ((e = hipHostMalloc((void**)&ctx->up_base, ctx->up_gen_bytes * mld_ctx::kUpGens, hipHostMallocDefault)) != hipSuccess)
@@ -1120,6 +1208,10 @@ mld_ctx* mld_create(const mld_params* params, const mld_camera* camera, const do
 
 void mld_destroy(mld_ctx* ctx) {
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.erase(std::remove(g_live.begin(), g_live.end(), ctx), g_live.end());
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (Slot& s : ctx->slots) {
@@ -1197,6 +1289,20 @@ void mld_destroy(mld_ctx* ctx) {
 const char* mld_last_error(const mld_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 void* mld_get_stream(mld_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int mld_contexts_concurrent(mld_ctx* a, mld_ctx* b) {
+    if (!a || !b) return MLD_ERR_INVALID_ARG;
+    if (a == b) return 0;
+    if (a->device != b->device) return 1;
+    int rc = bind_device(a);
+    if (rc) return rc;
+    const int r = probe_streams_concurrent(a->stream, b->stream);
+    if (r < 0) {
+        (void)hipGetLastError();
+        return fail(a, MLD_ERR_HIP, "mld_contexts_concurrent: the probe kernels could not be run");
+    }
+    return r;
+}
 
 int mld_synchronize(mld_ctx* ctx) {
     if (!ctx) return MLD_ERR_INVALID_ARG;
@@ -1309,7 +1415,23 @@ int mld_set_list_capacity(mld_ctx* ctx, int wide_entries, int narrow_entries) {
         return fail(ctx, MLD_ERR_INVALID_ARG, "list capacities: 8 <= narrow <= wide <= 64");
     ctx->calib.k1max = wide_entries;
     ctx->calib.kMain = narrow_entries;
-    ctx->lds_fused = (size_t)(wide_entries + narrow_entries) * kWave * sizeof(uint32_t);
+    ctx->calib.kTotal = wide_entries + narrow_entries;  // room for both lists at their longest; mld_set_list_budget lowers it
+#ifdef MLD_AB_SWITCHES
+    if (const char* e = std::getenv("MLD_KTOTAL"))  // (measurement: the budget also where a caller sets the capacities)
+        ctx->calib.kTotal = std::min(std::max(std::atoi(e), wide_entries), wide_entries + narrow_entries);
+#endif
+    ctx->lds_fused = (size_t)ctx->calib.kTotal * kWave * sizeof(uint32_t);
+    return mld_set_shared_gpu(ctx, ctx->shared_arg);
+}
+
+int mld_set_list_budget(mld_ctx* ctx, int total_entries) {
+    if (!ctx) return MLD_ERR_INVALID_ARG;
+    const int wide = ctx->calib.k1max, both = ctx->calib.k1max + ctx->calib.kMain;
+    if (total_entries == 0) total_entries = both;
+    if (total_entries < wide || total_entries > both)
+        return fail(ctx, MLD_ERR_INVALID_ARG, "list budget: wide capacity <= total <= wide + narrow capacity (0 = wide + narrow)");
+    ctx->calib.kTotal = total_entries;
+    ctx->lds_fused = (size_t)total_entries * kWave * sizeof(uint32_t);
     return mld_set_shared_gpu(ctx, ctx->shared_arg);
 }
 

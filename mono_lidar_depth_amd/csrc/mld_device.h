@@ -63,8 +63,11 @@ struct Calib {
     int roadMode;  // 0 = M-estimator, 1 = max spanning triangle
     int usePCA;
     int bmStride;    // words per 32-pixel column of the occupancy bitmap (word = (x >> 5) * bmStride + y): H + slack
-    int k1max;       // thread path: neighbour list capacity per feature (entries in LDS)
-    int kMain;       // fused kernel: capacity of the narrow-window list
+    int k1max;       // lane-per-feature kernels: longest scanned-window (road-window) list a lane takes
+    int kMain;       // ... longest narrow-window list
+    int kTotal;      // ... entries of LDS per lane, shared by the two lists (the narrow lists start where the longest wide
+                     //     list of the wavefront ends): a feature stays on the lane path when k2 <= k1max, k1 <= kMain and
+                     //     (longest k2 of its wavefront) + k1 <= kTotal
     int sortClasses; // k_classify: 4 = live queue ordered by neighbour-count class, then image row; 1 = by row alone
     int xcdAware;    // 1: blocks of one slot are congruent mod 8 (same XCD under round-robin dispatch)
     int threadPath;  // 1: thread-per-feature fast path with wave-cooperative overflow; 0: wave path only

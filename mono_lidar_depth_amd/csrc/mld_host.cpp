@@ -5,7 +5,9 @@
 // 8-float map, DepthEstimator.cpp:169).  A driver that streams frames through pinned host buffers copies every cloud
 // once on the host anyway; doing that copy as a 32 -> 16 byte repack halves what then crosses PCIe, the bound of the
 // streamed path.
+#if defined(__SSE2__)
 #include <emmintrin.h>
+#endif
 
 #include <algorithm>
 #include <cstdint>
@@ -23,6 +25,7 @@ void pack_range(float* dst, const unsigned char* src, int64_t i0, int64_t i1, in
         std::memcpy(dst + 4 * i0, src + 16 * i0, (size_t)(i1 - i0) * 16);
         return;
     }
+#if defined(__SSE2__)
     for (int64_t i = i0; i < i1; i++) {
         const float* s = reinterpret_cast<const float*>(src + (size_t)i * (size_t)stride);
         const __m128 xyzp = _mm_loadu_ps(s);                                   // x y z pad
@@ -35,6 +38,17 @@ void pack_range(float* dst, const unsigned char* src, int64_t i0, int64_t i1, in
             _mm_storeu_ps(dst + 4 * i, out);
     }
     if (stream) _mm_sfence();
+#else  // hosts without SSE2: the same repack, scalar
+    (void)stream;
+    for (int64_t i = i0; i < i1; i++) {
+        const float* s = reinterpret_cast<const float*>(src + (size_t)i * (size_t)stride);
+        float* d = dst + 4 * i;
+        d[0] = s[0];
+        d[1] = s[1];
+        d[2] = s[2];
+        d[3] = s[4];
+    }
+#endif
 }
 
 }  // namespace
@@ -52,14 +66,22 @@ extern "C" int mld_pack_points_host(void* dst16, const void* src, int64_t n, int
         pack_range(dst, s, 0, n, src_stride_bytes);
         return MLD_OK;
     }
+    // No C++ exception crosses the C ABI: when a helper thread cannot be started (std::system_error under a thread limit,
+    // bad_alloc), the ranges that have no thread yet are packed by the calling thread.
     std::vector<std::thread> th;
-    th.reserve((size_t)T - 1);
     const int64_t per = ((n + T - 1) / T + 3) & ~(int64_t)3;
-    for (int t = 1; t < T; t++) {
-        const int64_t a = std::min<int64_t>(n, per * t), b = std::min<int64_t>(n, per * (t + 1));
-        if (a < b) th.emplace_back(pack_range, dst, s, a, b, src_stride_bytes);
+    int64_t next = std::min<int64_t>(n, per);  // first point no helper thread has taken
+    try {
+        th.reserve((size_t)T - 1);
+        for (int t = 1; t < T; t++) {
+            const int64_t a = std::min<int64_t>(n, per * t), b = std::min<int64_t>(n, per * (t + 1));
+            if (a < b) th.emplace_back(pack_range, dst, s, a, b, src_stride_bytes);
+            next = b;
+        }
+    } catch (...) {
     }
     pack_range(dst, s, 0, std::min<int64_t>(n, per), src_stride_bytes);
+    if (next < n) pack_range(dst, s, next, n, src_stride_bytes);  // (only after a failed thread start)
     for (std::thread& x : th) x.join();
     return MLD_OK;
 }

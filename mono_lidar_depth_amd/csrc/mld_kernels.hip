@@ -1596,7 +1596,7 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
 // ------------------------------------------------------------------------------------------------
 constexpr int kK1MaxLimit = 64;  // upper bound of Calib::k1max, the per-feature neighbour list capacity
                                  // (LDS: k1max entries x 64 lanes x 4 B per wave; relative bins need k1max < 254)
-constexpr int kK2Max = 16;  // longest list the per-thread O(n^2) triangle search accepts
+constexpr int kK2Max = 16;  // longest list of the TRIANGLE ROAD ESTIMATOR's in-lane corner search (longer ones: wave kernel)
 #ifndef MLD_TRI_SMALL
 #define MLD_TRI_SMALL 8
 #endif
@@ -1743,7 +1743,9 @@ __device__ __forceinline__ bool triangle_small(const Calib& c, const SlotRef& s,
 }
 
 // Max-spanning triangle over the thread's list entries [0, n) (PlaneEstimationCalcMaxSpanningTriangle.cpp:37-100),
-// serial loops, n <= kK2Max.  The wave iterates to the longest list; shorter lanes idle.
+// serial O(n^2) loops over memory (no register tier).  Callers: the main path for any segmented list up to the capacity
+// kMain (the in-register tiers take the short ones first), the triangle road estimator for n <= kK2Max.  The wave iterates
+// to the longest list; shorter lanes idle.
 __device__ __forceinline__ bool triangle_thread(const Calib& c, const SlotRef& s, int n, bool want, const uint32_t* lst, int lane, V3& c1,
                                 V3& c2, V3& c3) {
     bool act = want && n >= 3;
@@ -2611,11 +2613,13 @@ __global__ __launch_bounds__(kClsThreads) void k_classify(const SlotDesc* __rest
             // Lists beyond the fused kernel's capacities go straight to the wave kernel (dense clouds: every feature):
             // the narrow count is known; the scanned (road) window holds ~2.6x as many cells, so it is counted only
             // when the narrow one is already long.
-            if (k1 > c.kMain) return CLS_OVF;
-            if (road_on && 3 * k1 > c.k1max) {
+            if (k1 > c.kMain || k1 > c.kTotal) return CLS_OVF;
+            if (road_on && (3 * k1 > c.k1max || 4 * k1 > c.kTotal)) {
                 int a0, a1, anx, any_;
-                if (window_bounds(c, u, v, c.halfX2, c.halfY2, a0, a1, anx, any_) && count_window(a0, a1, anx, any_) > c.k1max)
-                    return CLS_OVF;
+                if (window_bounds(c, u, v, c.halfX2, c.halfY2, a0, a1, anx, any_)) {
+                    const int k2 = count_window(a0, a1, anx, any_);
+                    if (k2 > c.k1max || k1 + k2 > c.kTotal) return CLS_OVF;   // (both lists share kTotal entries of LDS)
+                }
             }
         }
         if ((unsigned)k1 < c.countMin) return CLS_DEAD;
@@ -2720,6 +2724,27 @@ __global__ __launch_bounds__(kWave) void k_gate(const uint32_t* __restrict__ cou
     }
 }
 
+// Do two streams run side by side?  (The HIP runtime multiplexes a process's streams on a few hardware queues - four per
+// priority by default - and two streams that share a queue execute strictly one kernel after the other: two contexts meant
+// to overlap would silently serialise.)  k_probe_wait, on one stream, polls a word that k_probe_set, launched AFTER it on
+// the other stream, sets: on distinct queues the setter runs while the waiter polls (result 1 within microseconds); on a
+// shared queue the setter cannot start before the waiter has given up (result 2 after max_polls x ~1 us).
+__global__ __launch_bounds__(kWave) void k_probe_wait(const uint32_t* flag, uint32_t* result, int max_polls) {
+    if (threadIdx.x != 0) return;
+    uint32_t seen = 2u;
+    for (int i = 0; i < max_polls; i++) {
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+            seen = 1u;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    __hip_atomic_store(result, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_probe_set(uint32_t* flag) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // A step's small tables (slot / sequence descriptors, constants) from the context's pinned host block to device memory,
 // in stream order, by load / store: no DMA engine takes part (see upload_small in mld_api.hip).
 __global__ __launch_bounds__(256) void k_upload(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src_host, int n_words) {
@@ -2736,12 +2761,15 @@ constexpr int kKeyBatchF = MLD_KEY_BATCH_F;  // map keys fetched per round trip 
 // bit 31 set for the cells that also lie inside the narrow window (xn0, yn0, nxn, nyn).  The lane's list ends up
 // holding ORIGINAL POINT INDICES (low 24 bits) | flag.  Returns the entry count (may exceed c.k1max: overflow), the
 // number of flagged entries in kflag.
-// While the keys are in registers the scan also writes the narrow list `nl` (the flagged entries' point indices, same
-// order, at most c.kMain of them) and gathers what the road fallback wants to know about the lane's list before it
-// touches a point: states = bit 0 "a far point", bit 1 "an unsure point" (k_project_scatter's plane states).
+// While the keys are in registers the scan also writes the narrow list (the flagged entries' point indices, same order)
+// BEHIND the wide lists of the wavefront: it starts at entry `nbase` = the longest wide list among the lanes (wave-uniform,
+// so that every list access keeps its scalar address arithmetic) of the c.kTotal entries of LDS per lane and may hold
+// `nroom` = min(c.kMain, c.kTotal - nbase) entries - the two lists share one budget: long road windows leave less room for
+// the narrow lists and the other way round.  It also gathers what the road fallback wants to know about the lane's list
+// before it touches a point: states = bit 0 "a far point", bit 1 "an unsure point" (k_project_scatter's plane states).
 __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef& s, int x0, int y0, int nx, int ny,
-                                                   int xn0, int yn0, int nxn, int nyn, uint32_t* lst, uint32_t* nl,
-                                                   int lane, int& kflag, uint32_t& states ST_ARG) {
+                                                   int xn0, int yn0, int nxn, int nyn, uint32_t* lst,
+                                                   int lane, int& kflag, uint32_t& states, int& nbase, int& nroom ST_ARG) {
     const int nymax = uniform(wave_max_i32(ny));
     const auto* bm = GPTR(uint32_t, s.g.bitmap);
     // windows are at most 32 cells wide here (k_classify routes wider ones to the wave kernel): 32-bit row masks
@@ -2831,6 +2859,9 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef
     const auto* mp = GPTR(uint32_t, s.g.map);
     int kn = 0;
     uint32_t st_any = 0u;
+    uint32_t* const nl = lst + kmax * kWave;   // (behind the longest wide list of the wavefront)
+    nbase = kmax;
+    nroom = min(c.kMain, c.kTotal - kmax);
     for (int e0 = 0; e0 < kmax; e0 += kKeyBatchF) {
         uint32_t cell[kKeyBatchF], key[kKeyBatchF];
 #pragma unroll
@@ -2843,7 +2874,7 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef
                 const uint32_t idx = key_index(key[q]), st = key[q] & 3u;
                 LST(e0 + q) = idx | (st << kEntStateShift) | (cell[q] & kEntNarrow);
                 st_any |= (st == kPtFar ? 1u : 0u) | (st == kPtUnsure ? 2u : 0u);
-                if ((cell[q] & kEntNarrow) && kn < c.kMain) {
+                if ((cell[q] & kEntNarrow) && kn < nroom) {
                     nl[kn * kWave + lane] = idx;
                     kn++;
                 }
@@ -2855,8 +2886,11 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef
     return k;
 }
 
-// One lane per LIVE feature (queue written by k_classify).  LDS per wave: the wide list (c.k1max entries) followed by
-// the narrow list (c.kMain entries), both transposed [entry][lane].
+// One lane per LIVE feature (queue written by k_classify).  LDS per wave: c.kTotal entries per lane, transposed
+// [entry][lane]: the lanes' wide lists (k2 <= c.k1max entries) and, behind the longest of them, their narrow lists
+// (k1 <= c.kMain entries).
+// (Rounds 1-5 kept the two lists in separate regions of k1max + kMain entries: 14 KB per wavefront at the default
+// capacities = 11 wavefronts per CU; sharing one region the same lists fit 10 KB = 16 per CU, four per SIMD.)
 #ifndef MLD_FUSED_WAVES
 #define MLD_FUSED_WAVES 3
 #endif
@@ -2865,14 +2899,13 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef
 #else
 #define MLD_FUSED_ATTR
 #endif
-// DENSE: the instantiation for long lists (dense clouds; list capacities beyond the default): two wavefronts per SIMD -
-// all the LDS of such lists allows - and therefore up to 256 registers, which the in-register corner search of main_tail
-// uses.  The other instantiation keeps to 168 registers: three wavefronts per SIMD alone, or two beside the projection
-// wavefronts of another context (mld_set_shared_gpu).
+// DENSE = 0: the default instantiation: four wavefronts per SIMD (<= 128 registers; 10 KB of LDS at the default list budget).
+// DENSE = 2: the instantiation for long lists (dense clouds; list capacities beyond the default): two wavefronts per SIMD -
+// all the LDS of such lists allows - and therefore up to 256 registers, which the in-register corner search of main_tail uses.
 // DENSE = 1: the same kernel for long lists within 168 registers (three wavefronts per SIMD's worth: tiers up to 16 points /
 // 16 depths), for the shared-GPU mode - it leaves a third of the register file to the other context's projection.
 template <int ROAD_MODE, int DENSE>
-__global__ __launch_bounds__(kWave, DENSE == 2 ? 2 : MLD_FUSED_WAVES) MLD_FUSED_ATTR void k_feature_fused(const SlotDesc* __restrict__ slots,
+__global__ __launch_bounds__(kWave, DENSE == 2 ? 2 : (DENSE == 1 ? MLD_FUSED_WAVES : 4)) MLD_FUSED_ATTR void k_feature_fused(const SlotDesc* __restrict__ slots,
                                                          const Calib* __restrict__ calib, int n_slots, int per_slot) {
     extern __shared__ __align__(16) unsigned char smem[];
     // The per-context constants stay in device memory as well (mld_ctx::d_calib): a field is fetched by a scalar load
@@ -2900,8 +2933,7 @@ __global__ __launch_bounds__(kWave, DENSE == 2 ? 2 : MLD_FUSED_WAVES) MLD_FUSED_
         ST_BEGIN(0);
         const int lane = threadIdx.x;
         const bool active = e0 + lane < count;
-        uint32_t* lst = reinterpret_cast<uint32_t*>(smem);  // wide list
-        uint32_t* nl = lst + c.k1max * kWave;               // narrow list
+        uint32_t* lst = reinterpret_cast<uint32_t*>(smem);  // wide list; the narrow list follows it (per lane)
         long long f = 0;
         double myu = 0, myv = 0;
         if (active) {
@@ -2935,9 +2967,15 @@ __global__ __launch_bounds__(kWave, DENSE == 2 ? 2 : MLD_FUSED_WAVES) MLD_FUSED_
         }
         int k1 = 0;
         uint32_t list_states = 0u;
-        const int k2 = scan_window_flagged(c, s, x0, y0, nx, ny, xn0, yn0, nxn, nyn, lst, nl, lane, k1, list_states ST_PASS);
+        int nbase = 0, nroom = 0;
+        const int k2 = scan_window_flagged(c, s, x0, y0, nx, ny, xn0, yn0, nxn, nyn, lst, lane, k1, list_states, nbase,
+                                           nroom ST_PASS);
         // (k_classify keeps windows wider than 32 cells out of the live queue)
-        bool overflow = active && (k2 > c.k1max || k1 > c.kMain);
+        bool overflow = active && (k2 > c.k1max || k1 > nroom);
+        // the narrow lists: behind the longest wide list of the wavefront.  (No room for a single entry: every lane with
+        // a narrow entry has overflowed; the reads below are clamped to the last entry of the region.)
+        uint32_t* const nl = lst + min(nbase, c.kTotal - 1) * kWave;
+        const int ncap = max(nroom, 1);  // entries the narrow list may address
         int ovf_code = -1;
         // (the narrow list - the flagged entries, same order - was written by the scan)
         ST_MARK(5);
@@ -2956,7 +2994,7 @@ __global__ __launch_bounds__(kWave, DENSE == 2 ? 2 : MLD_FUSED_WAVES) MLD_FUSED_
         }
         {
             bool ovf1 = false;
-            main_after_scan<DENSE>(c, s, nl, lane, c.kMain, k1, live, myu, myv, mytype, mydepth, ovf1 ST_PASS);
+            main_after_scan<DENSE>(c, s, nl, lane, ncap, k1, live, myu, myv, mytype, mydepth, ovf1 ST_PASS);
             if (live && ovf1) overflow = true;  // (a list the per-thread corner search cannot take: wave kernel)
         }
         // ---------------- road fallback (DepthEstimator.cpp:578-597) on the list already scanned ----------------

@@ -256,6 +256,19 @@ class DepthEstimator:
         for dense (128-beam) clouds."""
         self._check(self._lib.mld_set_list_capacity(self._ctx, int(wide), int(narrow)))
 
+    def concurrentWith(self, other: "DepthEstimator") -> bool:
+        """Whether this context's stream and `other`'s run side by side (distinct hardware queues of the HIP runtime;
+        mld_contexts_concurrent).  mld_create already looks for a queue of its own; this repeats the probe."""
+        r = self._lib.mld_contexts_concurrent(self._ctx, other._ctx)
+        if r < 0:
+            self._check(r)
+        return r == 1
+
+    def setListBudget(self, total: int):
+        """LDS entries per feature shared by the wide and the narrow list (mld_set_list_budget): 40 for a new context,
+        wide + narrow after setListCapacity; 0 = wide + narrow."""
+        self._check(self._lib.mld_set_list_budget(self._ctx, int(total)))
+
     def pairWith(self, other: "DepthEstimator"):
         """The batched projections of this context and `other` run back to back on one stream (shared, reference
         counted: either context may be closed first), each context's feature kernels on its own (mld_pair_contexts)."""

@@ -192,20 +192,31 @@ public:
         materialize();
         return _inliersIndex;
     }
-    // RansacPlane.h:116-122: a std::map<int, bool> lookup in the reference; here a bitmask over the point indices,
-    // built on the first call for the current inlier list (O(1) per call afterwards)
+    // RansacPlane.h:116-122: a std::map<int, bool> lookup in the reference; here a bitmask over the point indices, built on
+    // the first call for the current inlier list (O(1) per call afterwards).  Safe to call concurrently, as the reference's
+    // const map lookup is: the bitmask is an immutable object published through an atomic shared_ptr (two threads that
+    // find it stale each build their own).  Staleness: the key holds the list's size, storage and a fingerprint of 18
+    // sampled entries, so that a same-size rewrite in place (`_inliersIndex = other` in a subclass) is noticed too; the
+    // base class and RansacPlane invalidate explicitly wherever they rewrite the list.
     bool CheckPointInPlane(const int index) const {
         materialize();
-        if (_lookupSize != _inliersIndex.size() || _lookupData != _inliersIndex.data()) {
+        std::shared_ptr<const Lookup> lk = std::atomic_load(&_lookup);
+        const uint64_t fp = fingerprint(_inliersIndex);
+        if (!lk || lk->size != _inliersIndex.size() || lk->data != _inliersIndex.data() || lk->fp != fp) {
+            auto fresh = std::make_shared<Lookup>();
             int mx = -1;
             for (int i : _inliersIndex) mx = i > mx ? i : mx;
-            _lookup.assign((size_t)(mx + 1 + 63) / 64, 0ull);
+            fresh->bits.assign((size_t)(mx + 1 + 63) / 64, 0ull);
             for (int i : _inliersIndex)
-                if (i >= 0) _lookup[(size_t)i >> 6] |= 1ull << (i & 63);
-            _lookupSize = _inliersIndex.size();
-            _lookupData = _inliersIndex.data();
+                if (i >= 0) fresh->bits[(size_t)i >> 6] |= 1ull << (i & 63);
+            fresh->size = _inliersIndex.size();
+            fresh->data = _inliersIndex.data();
+            fresh->fp = fp;
+            lk = fresh;
+            std::atomic_store(&_lookup, lk);
         }
-        return index >= 0 && ((size_t)index >> 6) < _lookup.size() && ((_lookup[(size_t)index >> 6] >> (index & 63)) & 1ull);
+        const std::vector<uint64_t>& b = lk->bits;
+        return index >= 0 && ((size_t)index >> 6) < b.size() && ((b[(size_t)index >> 6] >> (index & 63)) & 1ull);
     }
     // A plane estimated on the GPU keeps its inlier set there (a bitmask the kernels read); the index list of
     // getInlinersIndex (RansacPlane.h:100-103) is fetched when somebody asks for it - or when the frame slot that holds
@@ -213,16 +224,29 @@ public:
     virtual void materialize() const {}
 
 protected:
-    // a subclass that rewrites _inliersIndex in place (same size, same storage) calls this
-    void inliersChanged() const { _lookupData = nullptr; }
+    // A subclass that rewrites _inliersIndex calls this (the fingerprint in CheckPointInPlane's key catches a rewrite
+    // that forgets to, unless the 18 sampled entries all kept their values).
+    void inliersChanged() const { std::atomic_store(&_lookup, std::shared_ptr<const Lookup>()); }
     bool is_segmented_ = false;
     std::array<float, 4> _modelCoeffs{{0, 0, 0, 0}};
     mutable std::vector<int> _inliersIndex;
 
 private:
-    mutable std::vector<uint64_t> _lookup;  // CheckPointInPlane's bitmask of _inliersIndex
-    mutable size_t _lookupSize = ~(size_t)0;
-    mutable const int* _lookupData = nullptr;
+    struct Lookup {  // CheckPointInPlane's bitmask of _inliersIndex + the state of the list it was built from
+        std::vector<uint64_t> bits;
+        size_t size = 0;
+        const int* data = nullptr;
+        uint64_t fp = 0;
+    };
+    static uint64_t fingerprint(const std::vector<int>& v) {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)v.size();
+        const size_t n = v.size();
+        if (!n) return h;
+        const size_t step = n > 16 ? n / 16 : 1;
+        for (size_t i = 0; i < n; i += step) h = (h ^ (uint64_t)(uint32_t)v[i]) * 0x100000001B3ull;
+        return (h ^ (uint64_t)(uint32_t)v[n - 1]) * 0x100000001B3ull;
+    }
+    mutable std::shared_ptr<const Lookup> _lookup;
 };
 
 // RansacPlane (RansacPlane.h:129-170): a GroundPlane that DepthEstimator::setInputCloud estimates on the GPU while it
@@ -236,6 +260,7 @@ public:
     void assign(const std::array<float, 4>& coeffs, std::vector<int> inliers) {
         _modelCoeffs = coeffs;
         _inliersIndex = std::move(inliers);
+        inliersChanged();
         _fetch = nullptr;
         is_segmented_ = true;
     }
@@ -243,6 +268,7 @@ public:
     void assignLazy(const std::array<float, 4>& coeffs, int64_t n_inliers, std::function<void(std::vector<int>&)> fetch) {
         _modelCoeffs = coeffs;
         _inliersIndex.clear();
+        inliersChanged();
         _numInliers = n_inliers;
         _fetch = std::move(fetch);
         is_segmented_ = true;
@@ -252,6 +278,7 @@ public:
         auto f = std::move(_fetch);
         _fetch = nullptr;
         f(_inliersIndex);
+        inliersChanged();
     }
     bool inliersPending() const { return (bool)_fetch; }
     int64_t numInliers() const { return _fetch ? _numInliers : (int64_t)_inliersIndex.size(); }

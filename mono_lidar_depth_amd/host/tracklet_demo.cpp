@@ -42,6 +42,7 @@ public:
         if (fail_) throw ExceptionPclInvalid();
         _modelCoeffs = {0.f, 0.f, 1.f, 1.73f};
         _inliersIndex = inl_;
+        inliersChanged();  // (CheckPointInPlane's bitmask belongs to the previous list)
         is_segmented_ = true;
     }
 

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, f"libmld_hip.so lacks: {missing}"
     assert declared == set(capi.EXPORTED_SYMBOLS), declared ^ set(capi.EXPORTED_SYMBOLS)
-    assert lib.mld_abi_version() == capi.MLD_ABI_VERSION == 7
+    assert lib.mld_abi_version() == capi.MLD_ABI_VERSION == 8
 
 
 def test_struct_layout_matches_header():

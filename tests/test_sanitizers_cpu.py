@@ -159,10 +159,40 @@ def test_shim_host_logic_under_asan_ubsan(tmp_path):
     src = r"""
 #include <cstdio>
 #include <set>
+#include <thread>
 #include "monolidar_fusion/DepthEstimator.h"
+// a foreign plane that rewrites its inlier list in place: same size, same storage (ADVICE r5: the lookup cache was keyed on
+// size + data pointer only).  `tell` = whether it reports the rewrite through inliersChanged().
+struct Rewriter : Mono_Lidar::GroundPlane {
+    Rewriter() : GroundPlane({0.f, 0.f, 1.f, 0.f}, {10, 20, 30, 40}) {}
+    void rewrite(bool tell) {
+        const std::vector<int> other{11, 21, 31, 41};
+        _inliersIndex = other;   // copy-assign into the existing storage
+        if (tell) inliersChanged();
+    }
+};
 int main(int argc, char** argv) {
     using namespace Mono_Lidar;
     int bad = 0;
+    for (bool tell : {true, false}) {
+        Rewriter rw;
+        bad += (rw.CheckPointInPlane(20) && !rw.CheckPointInPlane(21)) ? 0 : 1;
+        rw.rewrite(tell);
+        bad += (!rw.CheckPointInPlane(20) && rw.CheckPointInPlane(21) && rw.CheckPointInPlane(41)) ? 0 : 1;
+    }
+    {   // concurrent lookups on a fresh plane: every thread may find the bitmask missing and build its own
+        std::vector<int> many;
+        for (int i = 0; i < 50000; i++) many.push_back(3 * i);
+        GroundPlane big({0.f, 0.f, 1.f, 0.f}, many);
+        int wrong[8] = {0};
+        std::vector<std::thread> th;
+        for (int t = 0; t < 8; t++)
+            th.emplace_back([&big, &wrong, t] {
+                for (int i = 0; i < 150000; i++) wrong[t] += (big.CheckPointInPlane(i) != (i % 3 == 0)) ? 1 : 0;
+            });
+        for (auto& x : th) x.join();
+        for (int t = 0; t < 8; t++) bad += wrong[t] ? 1 : 0;
+    }
     GroundPlane gp({0.f, 0.f, 1.f, 1.73f}, {5, 1, 900000, 64, 63, 0});
     for (int i : {5, 1, 900000, 64, 63, 0}) bad += gp.CheckPointInPlane(i) ? 0 : 1;
     for (int i : {-1, 2, 65, 899999, 900001, 2147483647}) bad += gp.CheckPointInPlane(i) ? 1 : 0;
@@ -199,7 +229,7 @@ int main(int argc, char** argv) {
 """
     exe = _compile(tmp_path, "shim_asan", src, [ROOT / "mono_lidar_depth_amd" / "csrc" / "mld_params.cpp"],
                    [f"-I{ROOT / 'tests' / 'stubs'}", f"-I{ROOT / 'mono_lidar_depth_amd' / 'host'}", "-DMLD_SHIM_NO_GPU_LINK",
-                    "-Wl,--unresolved-symbols=ignore-all"])
+                    "-Wl,--unresolved-symbols=ignore-all", "-pthread"])
     y = tmp_path / "ref.yaml"
     y.write_text("pixelarea_search_witdh: 6\npixelarea_search_height: 9\ndo_use_ransac_plane: 1\n")
     r = subprocess.run([str(exe), str(y)], capture_output=True, text=True, timeout=300, env=ENV)
