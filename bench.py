@@ -61,7 +61,7 @@ def parse_args():
                          "mld_set_shared_gpu); 1 = everything on one stream, one kernel at a time")
     ap.add_argument("--shared-mode", type=int, default=1,
                     help="mld_set_shared_gpu argument of the alternating contexts: 1 = on; + 256 * n = n feature-kernel "
-                         "wavefronts per CU instead of 8")
+                         "wavefronts per CU instead of 10")
     ap.add_argument("--handover", choices=("classify", "projection"), default="classify",
                     help="two contexts: the next context's projection is released behind this context's classification "
                          "kernel (mld_order_after_classify; default) or at the end of its projection (mld_order_after)")

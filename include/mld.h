@@ -188,11 +188,11 @@ int mld_synchronize(mld_ctx* ctx);
  *
  * mld_order_after: everything submitted to `ctx` from now on starts after everything submitted to `other` so far has
  *   finished (one event; no host synchronisation).  Both contexts must live on the same device.
- * mld_set_shared_gpu(ctx, 1): the lane-per-feature kernel of `ctx` keeps to two wavefronts per SIMD (it requests more
- *   LDS per block), which leaves registers for the other context's projection wavefronts on every CU.  A context that
- *   has the GPU to itself is ~7 % slower in this mode; the alternating pair is ~20 % faster (bench.py default:
- *   0.71 instead of 0.91 ms per 1024 frames of config 2).  `shared`: bit 0 = on; bits 8..15 = wavefronts of the
- *   lane-per-feature kernel per CU in that mode (0 = the default, 8): fewer leave more of every CU to the projection.
+ * mld_set_shared_gpu(ctx, 1): the lane-per-feature kernel of `ctx` keeps to ten wavefronts per CU instead of sixteen (it
+ *   requests more LDS per block), which leaves registers for the other context's projection wavefronts on every CU.  A
+ *   context that has the GPU to itself is ~20 % slower in this mode; the alternating pair is ~20 % faster (bench.py
+ *   default: 0.68-0.72 instead of 0.89 ms per 1024 frames of config 2).  `shared`: bit 0 = on; bits 8..15 = wavefronts of
+ *   the lane-per-feature kernel per CU in that mode (0 = the default, 10): fewer leave more of every CU to the projection.
  */
 int mld_order_after(mld_ctx* ctx, mld_ctx* other);
 /*

@@ -1393,11 +1393,12 @@ int mld_order_after_classify(mld_ctx* ctx, mld_ctx* other) {
 
 int mld_set_shared_gpu(mld_ctx* ctx, int shared) {
     if (!ctx) return MLD_ERR_INVALID_ARG;
-    // k_feature_fused is capped by its LDS request: 14 KB per wavefront -> 11 per CU (3 per SIMD, which is all the
-    // VGPRs there are at 168 per wave); 20 KB -> 8 per CU, 2 per SIMD, and a third of the register file stays free
-    // for the projection wavefronts (48 VGPRs each) of a context running beside this one.
-    int blocks = (shared >> 8) & 0xFF;  // bits 8..15: wavefronts per CU (0 = the default, 8)
-    if (blocks <= 0) blocks = 8;
+    // k_feature_fused is capped by its LDS request: 10 KB of lists per wavefront (the default budget) -> 16 per CU, four per
+    // SIMD, when the context has the GPU to itself; beside another context's projection it is padded to 16 KB -> 10 per
+    // CU, so that the register file keeps room for the projection's wavefronts (52 VGPRs each).  Round 6, one box, three
+    // alternations: 8 / 10 / 12 per CU = 0.692-0.707 / 0.680-0.683 / 0.686-0.706 ms per step (LAB.md 6.5; rounds 2-5 ran 8).
+    int blocks = (shared >> 8) & 0xFF;  // bits 8..15: wavefronts per CU (0 = the default, 10)
+    if (blocks <= 0) blocks = 10;
     // 4..16 wavefronts per CU: fewer would ask for more dynamic LDS per one-wave block (53 KB and up) than the kernel
     // is enabled for, more than 16 cannot be reached at its register count anyway
     if (blocks < 4 || blocks > 16 || (shared & ~0xFF01) != 0)
