@@ -1418,7 +1418,11 @@ int mld_set_list_capacity(mld_ctx* ctx, int wide_entries, int narrow_entries) {
     ctx->calib.kMain = narrow_entries;
     ctx->calib.kTotal = wide_entries + narrow_entries;  // room for both lists at their longest; mld_set_list_budget lowers it
 #ifdef MLD_AB_SWITCHES
-    if (const char* e = std::getenv("MLD_KTOTAL"))  // (measurement: the budget also where a caller sets the capacities)
+    // (measurement: capacities / budget from the environment also where a caller sets them)
+    if (const char* e = std::getenv("MLD_CAP_WIDE")) ctx->calib.k1max = wide_entries = std::min(std::max(std::atoi(e), 8), kK1MaxLimit);
+    if (const char* e = std::getenv("MLD_CAP_NARROW")) ctx->calib.kMain = narrow_entries = std::min(std::max(std::atoi(e), 8), wide_entries);
+    ctx->calib.kTotal = wide_entries + narrow_entries;
+    if (const char* e = std::getenv("MLD_KTOTAL"))
         ctx->calib.kTotal = std::min(std::max(std::atoi(e), wide_entries), wide_entries + narrow_entries);
 #endif
     ctx->lds_fused = (size_t)ctx->calib.kTotal * kWave * sizeof(uint32_t);

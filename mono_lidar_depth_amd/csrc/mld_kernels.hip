@@ -1826,7 +1826,9 @@ __device__ __forceinline__ void enqueue_features(int32_t* queue, int32_t* count,
 // path's result (resultOld) on entry.  Lanes whose wide-window list exceeds the capacities set `overflow`.
 // ROAD_MODE: 0 = M-estimator, 1 = max-spanning triangle, -1 = decided at run time (c.roadMode).
 // The road fallback once the wide-window list (k2 entries, original point indices in the low 24 bits) is in `lst`.
-template <int ROAD_MODE>
+// RB: wide-window neighbours fetched per round trip (kRoadBatch; twice that in the DENSE 2 instantiation, whose lists are
+// long and whose two wavefronts per SIMD leave the registers: config 5 at 256 sequences -1.3 %, LAB.md 6.7)
+template <int ROAD_MODE, int RB>
 __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s, uint32_t* lst, const int lane, bool cand,
                                                 const int k2, const uint32_t list_states, const double myu,
                                                 const double myv, int& mytype,
@@ -1919,28 +1921,28 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s
         }
         const int ni = (cand && !far && kk >= 3) ? kk : 0;
         const int nimax = uniform(wave_max_i32(ni));
-        for (int e0 = 0; e0 < nimax; e0 += kRoadBatch) {
-            RawP rp[kRoadBatch];
+        for (int e0 = 0; e0 < nimax; e0 += RB) {
+            RawP rp[RB];
 #pragma unroll
-            for (int q = 0; q < kRoadBatch; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ni));
+            for (int q = 0; q < RB; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ni));
 #pragma unroll
-            for (int q = 0; q < kRoadBatch; q++)
+            for (int q = 0; q < RB; q++)
                 if (e0 + q < ni) add_inlier(raw_point(c, rp[q]));
         }
     } else {
     const int n2max = uniform(wave_max_i32(n2));
-    for (int e0 = 0; e0 < n2max; e0 += kRoadBatch) {
-        RawP rp[kRoadBatch];
-        uint32_t ids[kRoadBatch], mw[kRoadBatch];
+    for (int e0 = 0; e0 < n2max; e0 += RB) {
+        RawP rp[RB];
+        uint32_t ids[RB], mw[RB];
 #pragma unroll
-        for (int q = 0; q < kRoadBatch; q++) {
+        for (int q = 0; q < RB; q++) {
             const uint32_t ent = (e0 + q < n2) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
             ids[q] = ent & kIdxMask;
             rp[q] = load_raw(s, ids[q]);
             mw[q] = GPTR(uint32_t, s.g.inlier_mask)[ids[q] >> 5];
         }
 #pragma unroll
-        for (int q = 0; q < kRoadBatch; q++) {
+        for (int q = 0; q < RB; q++) {
           if (e0 + q < n2) {
             const uint32_t id = ids[q];
             V3 p = raw_point(c, rp[q]);
@@ -2767,6 +2769,7 @@ constexpr int kKeyBatchF = MLD_KEY_BATCH_F;  // map keys fetched per round trip 
 // `nroom` = min(c.kMain, c.kTotal - nbase) entries - the two lists share one budget: long road windows leave less room for
 // the narrow lists and the other way round.  It also gathers what the road fallback wants to know about the lane's list
 // before it touches a point: states = bit 0 "a far point", bit 1 "an unsure point" (k_project_scatter's plane states).
+template <int KB>  // map keys fetched per round trip (KB; twice that in the DENSE 2 instantiation)
 __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef& s, int x0, int y0, int nx, int ny,
                                                    int xn0, int yn0, int nxn, int nyn, uint32_t* lst,
                                                    int lane, int& kflag, uint32_t& states, int& nbase, int& nroom ST_ARG) {
@@ -2862,14 +2865,14 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef
     uint32_t* const nl = lst + kmax * kWave;   // (behind the longest wide list of the wavefront)
     nbase = kmax;
     nroom = min(c.kMain, c.kTotal - kmax);
-    for (int e0 = 0; e0 < kmax; e0 += kKeyBatchF) {
-        uint32_t cell[kKeyBatchF], key[kKeyBatchF];
+    for (int e0 = 0; e0 < kmax; e0 += KB) {
+        uint32_t cell[KB], key[KB];
 #pragma unroll
-        for (int q = 0; q < kKeyBatchF; q++) cell[q] = (e0 + q < kk) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
+        for (int q = 0; q < KB; q++) cell[q] = (e0 + q < kk) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
 #pragma unroll
-        for (int q = 0; q < kKeyBatchF; q++) key[q] = (e0 + q < kk) ? MLD_DIAG_KEY(mp[cell[q] & 0x7FFFFFFFu], s.g.tag, cell[q]) : 0u;
+        for (int q = 0; q < KB; q++) key[q] = (e0 + q < kk) ? MLD_DIAG_KEY(mp[cell[q] & 0x7FFFFFFFu], s.g.tag, cell[q]) : 0u;
 #pragma unroll
-        for (int q = 0; q < kKeyBatchF; q++)
+        for (int q = 0; q < KB; q++)
             if (e0 + q < kk) {
                 const uint32_t idx = key_index(key[q]), st = key[q] & 3u;
                 LST(e0 + q) = idx | (st << kEntStateShift) | (cell[q] & kEntNarrow);
@@ -2968,8 +2971,8 @@ __global__ __launch_bounds__(kWave, DENSE == 2 ? 2 : (DENSE == 1 ? MLD_FUSED_WAV
         int k1 = 0;
         uint32_t list_states = 0u;
         int nbase = 0, nroom = 0;
-        const int k2 = scan_window_flagged(c, s, x0, y0, nx, ny, xn0, yn0, nxn, nyn, lst, lane, k1, list_states, nbase,
-                                           nroom ST_PASS);
+        const int k2 = scan_window_flagged<DENSE == 2 ? 2 * kKeyBatchF : kKeyBatchF>(c, s, x0, y0, nx, ny, xn0, yn0, nxn, nyn, lst,
+                                                                                    lane, k1, list_states, nbase, nroom ST_PASS);
         // (k_classify keeps windows wider than 32 cells out of the live queue)
         bool overflow = active && (k2 > c.k1max || k1 > nroom);
         // the narrow lists: behind the longest wide list of the wavefront.  (No room for a single entry: every lane with
@@ -3003,7 +3006,8 @@ __global__ __launch_bounds__(kWave, DENSE == 2 ? 2 : (DENSE == 1 ? MLD_FUSED_WAV
         if (__any(cand)) {
             const int resultOld = mytype;
             bool ovf2 = false;
-            road_after_scan<ROAD_MODE>(c, s, lst, lane, cand, k2, list_states, myu, myv, mytype, mydepth, ovf2 ST_PASS);
+            road_after_scan<ROAD_MODE, DENSE == 2 ? 2 * kRoadBatch : kRoadBatch>(c, s, lst, lane, cand, k2, list_states, myu, myv,
+                                                                                mytype, mydepth, ovf2 ST_PASS);
             if (ovf2) {  // only the road part is redone by the wave kernel
                 overflow = true;
                 ovf_code = resultOld;
