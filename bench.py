@@ -521,6 +521,13 @@ def main():
         "streaming": streaming_ranks,
     }
     detail_path = Path(args.detail) if args.detail else ROOT / "gpurun_out" / "bench_detail.json"
+    try:  # (a read-only checkout: the detail goes to the temporary directory instead)
+        detail_path.parent.mkdir(parents=True, exist_ok=True)
+        if not os.access(detail_path.parent, os.W_OK):
+            raise OSError("not writable")
+    except OSError:
+        import tempfile
+        detail_path = Path(tempfile.gettempdir()) / "mld_bench_detail.json"
 
     def write_detail():
         try:

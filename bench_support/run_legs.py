@@ -153,8 +153,11 @@ def main(argv=None):
     detail = run(args)
     line = json.dumps(detail)
     if args.out:
-        Path(args.out).parent.mkdir(parents=True, exist_ok=True)
-        Path(args.out).write_text(line + "\n")
+        try:
+            Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+            Path(args.out).write_text(line + "\n")
+        except OSError as e:  # (the caller falls back to this process's stdout)
+            print(f"[run_legs] detail file not written: {e}", file=sys.stderr, flush=True)
     print(line, flush=True)
     bad = [k for k, v in detail["verified"].items() if not v]
     return 1 if (bad or detail["errors"]) else 0

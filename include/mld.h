@@ -490,6 +490,15 @@ int mld_tracklets_depths_device(mld_ctx* ctx, int n_seq, int bank_cur, int have_
  *   mld_get_point_depth_cam_visible -> getPointDepthCamVisible(index)            (DepthEstimator.h:111-113)
  */
 int mld_get_visible_count(mld_ctx* ctx, int slot, int64_t* n_visible);
+/*
+ * Which kernel answered the features of the slot's last BATCHED CalculateDepth call (mld_calculate_depths_device and the
+ * tracklet entry points; no reference counterpart): `lane_path` = features the classification queued for the
+ * lane-per-feature kernel, `handed_over` = features the wave-cooperative kernel worked on (lists beyond the capacities /
+ * the budget of mld_set_list_capacity / mld_set_list_budget, windows wider than 32 cells, road fits whose error estimate
+ * asks for the QR route; a feature handed over by the lane kernel counts in both).  The feedback for choosing capacities:
+ * a wave-kernel feature costs ~10x a lane-path one.  Synchronises the context's stream.
+ */
+int mld_get_path_counts(mld_ctx* ctx, int slot, int64_t* lane_path, int64_t* handed_over);
 int mld_get_visible_image_points(mld_ctx* ctx, int slot, double* uv_out, int64_t capacity);
 int mld_get_point_index(mld_ctx* ctx, int slot, int32_t* index_out, int64_t capacity);
 int mld_get_cloud_camera_cs(mld_ctx* ctx, int slot, double* xyz_out, int64_t capacity);

@@ -148,6 +148,7 @@ _SIGNATURES = [
     ("mld_set_list_capacity", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("mld_set_list_budget", C.c_int, [C.c_void_p, C.c_int]),
     ("mld_contexts_concurrent", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("mld_get_path_counts", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("mld_set_cloud", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     ("mld_set_cloud_device", C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     ("mld_set_clouds_device", C.c_int, [C.c_void_p, C.c_int, _P(C.c_void_p), _P(C.c_int64), C.c_int]),

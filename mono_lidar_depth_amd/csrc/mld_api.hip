@@ -2895,6 +2895,21 @@ int mld_tracklets_depth(mld_ctx* ctx, int slot_cur, int slot_last, const float* 
 }
 
 // ---------------------------------------------------------------------------- getters
+int mld_get_path_counts(mld_ctx* ctx, int slot, int64_t* lane_path, int64_t* handed_over) {
+    int rc = check_slot(ctx, slot);
+    if (rc) return rc;
+    if (!lane_path || !handed_over) return fail(ctx, MLD_ERR_INVALID_ARG, "null output");
+    if ((rc = bind_device(ctx))) return rc;
+    const Slot& s = ctx->slots[slot];
+    int32_t live = 0, ovf = 0;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (s.d.live_count) HIP_TRY(ctx, hipMemcpy(&live, s.d.live_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (s.d.ovf_count) HIP_TRY(ctx, hipMemcpy(&ovf, s.d.ovf_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+    *lane_path = live;
+    *handed_over = ovf;
+    return MLD_OK;
+}
+
 int mld_get_visible_count(mld_ctx* ctx, int slot, int64_t* n_visible) {
     int rc = check_slot(ctx, slot);
     if (rc) return rc;

@@ -2764,10 +2764,10 @@ constexpr int kKeyBatchF = MLD_KEY_BATCH_F;  // map keys fetched per round trip 
 // holding ORIGINAL POINT INDICES (low 24 bits) | flag.  Returns the entry count (may exceed c.k1max: overflow), the
 // number of flagged entries in kflag.
 // While the keys are in registers the scan also writes the narrow list (the flagged entries' point indices, same order)
-// BEHIND the wide lists of the wavefront: it starts at entry `nbase` = the longest wide list among the lanes (wave-uniform,
-// so that every list access keeps its scalar address arithmetic) of the c.kTotal entries of LDS per lane and may hold
-// `nroom` = min(c.kMain, c.kTotal - nbase) entries - the two lists share one budget: long road windows leave less room for
-// the narrow lists and the other way round.  It also gathers what the road fallback wants to know about the lane's list
+// BEHIND the wide lists of the wavefront: it starts at row `nbase` (wave-uniform, so that every list access keeps its
+// scalar address arithmetic; normally the length of the longest wide list among the lanes) of the c.kTotal rows of LDS and
+// may hold `nroom` = min(c.kMain, c.kTotal - nbase) entries - the two lists share one budget: long road windows leave less
+// room for the narrow lists and the other way round.  It also gathers what the road fallback wants to know about the lane's list
 // before it touches a point: states = bit 0 "a far point", bit 1 "an unsure point" (k_project_scatter's plane states).
 template <int KB>  // map keys fetched per round trip (KB; twice that in the DENSE 2 instantiation)
 __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef& s, int x0, int y0, int nx, int ny,
@@ -2862,9 +2862,25 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef
     const auto* mp = GPTR(uint32_t, s.g.map);
     int kn = 0;
     uint32_t st_any = 0u;
-    uint32_t* const nl = lst + kmax * kWave;   // (behind the longest wide list of the wavefront)
-    nbase = kmax;
-    nroom = min(c.kMain, c.kTotal - kmax);
+    // Where the narrow lists start: every lane has its own column of the c.kTotal rows, so a lane fits iff its wide list
+    // ends at or before the (wave-uniform) row nb and its narrow list within the c.kTotal - nb rows behind it; a lane that
+    // does not fit is handed to the wave kernel ALONE.  Two candidates - behind the longest wide list, or as far up as the
+    // longest narrow list allows - and the one that hands over fewer lanes (on 64-beam clouds the first, with nobody
+    // handed over; a lane beside a close object - 30 returns in its road window - would otherwise take its neighbours along).
+    int nb = kmax;
+    {
+        const int kfm = min(uniform(wave_max_i32(k <= c.k1max ? kf : 0)), c.kMain);
+        const int nb2 = max(c.kTotal - kfm, 0);
+        if (nb2 < nb) {
+            const int lost1 = (int)__popcll(__ballot(k <= c.k1max && kf <= c.kMain && kf > c.kTotal - nb));
+            const int lost2 = (int)__popcll(__ballot(k <= c.k1max && kf <= c.kMain && k > nb2));
+            if (lost2 < lost1) nb = nb2;
+        }
+    }
+    uint32_t* const nl = lst + nb * kWave;
+    nbase = nb;
+    nroom = min(c.kMain, c.kTotal - nb);
+    const bool fits = kk <= nb;  // (a lane whose wide list reaches beyond nb is handed over: it writes no narrow entry)
     for (int e0 = 0; e0 < kmax; e0 += KB) {
         uint32_t cell[KB], key[KB];
 #pragma unroll
@@ -2877,7 +2893,7 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef
                 const uint32_t idx = key_index(key[q]), st = key[q] & 3u;
                 LST(e0 + q) = idx | (st << kEntStateShift) | (cell[q] & kEntNarrow);
                 st_any |= (st == kPtFar ? 1u : 0u) | (st == kPtUnsure ? 2u : 0u);
-                if ((cell[q] & kEntNarrow) && kn < nroom) {
+                if ((cell[q] & kEntNarrow) && kn < nroom && fits) {
                     nl[kn * kWave + lane] = idx;
                     kn++;
                 }
@@ -2974,7 +2990,7 @@ __global__ __launch_bounds__(kWave, DENSE == 2 ? 2 : (DENSE == 1 ? MLD_FUSED_WAV
         const int k2 = scan_window_flagged<DENSE == 2 ? 2 * kKeyBatchF : kKeyBatchF>(c, s, x0, y0, nx, ny, xn0, yn0, nxn, nyn, lst,
                                                                                     lane, k1, list_states, nbase, nroom ST_PASS);
         // (k_classify keeps windows wider than 32 cells out of the live queue)
-        bool overflow = active && (k2 > c.k1max || k1 > nroom);
+        bool overflow = active && (k2 > c.k1max || k2 > nbase || k1 > nroom);
         // the narrow lists: behind the longest wide list of the wavefront.  (No room for a single entry: every lane with
         // a narrow entry has overflowed; the reads below are clamped to the last entry of the region.)
         uint32_t* const nl = lst + min(nbase, c.kTotal - 1) * kWave;

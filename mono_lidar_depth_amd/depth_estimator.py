@@ -264,6 +264,13 @@ class DepthEstimator:
             self._check(r)
         return r == 1
 
+    def pathCounts(self, slot: int = 0):
+        """(features queued for the lane-per-feature kernel, features the wave-cooperative kernel worked on) in the
+        slot's last batched CalculateDepth call (mld_get_path_counts)."""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.mld_get_path_counts(self._ctx, int(slot), C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def setListBudget(self, total: int):
         """LDS entries per feature shared by the wide and the narrow list (mld_set_list_budget): 40 for a new context,
         wide + narrow after setListCapacity; 0 = wide + narrow."""
