@@ -1662,17 +1662,12 @@ __device__ __forceinline__ RawP load_raw(const SlotRef& s, uint32_t i) {
     MLD_DIAG_FAKE_POINT(i);
     const unsigned char* cl = s.g.cloud;
     const unsigned char* p = cl + (size_t)i * (size_t)s.g.stride;
+    // one 12-byte load whatever the cloud's alignment (a 16-byte load for aligned clouds was a uniform branch per point:
+    // control flow between the loads of a batch, and with it the compiler's `s_waitcnt vmcnt(0)` at every join)
     RawP r;
-    if ((((size_t)cl) & 15) == 0) {
-        f32x4 q = *GPTR(f32x4, p);
-        r.x = q.x;
-        r.y = q.y;
-        r.z = q.z;
-    } else {
-        r.x = GPTR(float, p)[0];
-        r.y = GPTR(float, p)[1];
-        r.z = GPTR(float, p)[2];
-    }
+    r.x = GPTR(float, p)[0];
+    r.y = GPTR(float, p)[1];
+    r.z = GPTR(float, p)[2];
     return r;
 }
 __device__ __forceinline__ double raw_z(const Calib& c, RawP r) {
@@ -1681,7 +1676,10 @@ __device__ __forceinline__ double raw_z(const Calib& c, RawP r) {
 __device__ __forceinline__ V3 raw_point(const Calib& c, RawP r) { return lidar_to_cam(c, (double)r.x, (double)r.y, (double)r.z); }
 // list entry e of this lane, or 0 (a valid point index whenever any list is non-empty) beyond the list end
 // (lcap: capacity of the list `lst` addresses - the wide list's c.k1max or the narrow list's c.kMain)
-#define LST_ID(e, n) (((e) < (n)) ? (LST(min((e), lcap - 1)) & kIdxMask) : 0u)
+// (The LDS read is unconditional and the result masked: written as a select, the compiler predicates the read - a branch
+//  and a full `s_waitcnt vmcnt(0)` per entry, which serialises the batch of point loads the entries are fetched for.)
+#define LST_ID(e, n) (LST(min((e), lcap - 1)) & kIdxMask & (0u - (uint32_t)((e) < (n))))
+#define LST_IF(cond, e, cap) (LST(min((e), (cap) - 1)) & (0u - (uint32_t)(cond)))
 
 // Max-spanning triangle for lists of at most M entries, fully unrolled: all M points are fetched in one batch and
 // kept in registers, pairs are visited in the reference's (i,j) order with strict '>' (first maximal pair wins),
@@ -1911,7 +1909,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s
         for (int e = 0; e < n2fmax; e += 4) {
             uint32_t ent[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) ent[q] = (e + q < n2f) ? LST(min(e + q, c.k1max - 1)) : 0u;
+            for (int q = 0; q < 4; q++) ent[q] = LST_IF(e + q < n2f, e + q, c.k1max);
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (((ent[q] >> kEntStateShift) & 3u) == kPtInlier) {
@@ -1936,7 +1934,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s
         uint32_t ids[RB], mw[RB];
 #pragma unroll
         for (int q = 0; q < RB; q++) {
-            const uint32_t ent = (e0 + q < n2) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
+            const uint32_t ent = LST_IF(e0 + q < n2, e0 + q, c.k1max);
             ids[q] = ent & kIdxMask;
             rp[q] = load_raw(s, ids[q]);
             mw[q] = GPTR(uint32_t, s.g.inlier_mask)[ids[q] >> 5];
@@ -2168,7 +2166,7 @@ __device__ __forceinline__ void main_hist(const Calib& c, const SlotRef& s, uint
         int kk = 0;
 #pragma unroll
         for (int q = 0; q < kZc; q++) {
-            const uint32_t packed = (q < ks) ? LST(q) : 0u;
+            const uint32_t packed = LST_IF(q < ks, q, lcap);
             const int rel = (int)((relw[q >> 2] >> (8 * (q & 3))) & 0xFFu);
             const double z = zc[q];
             const double d = (999. < z) ? 999. : z;
@@ -2186,7 +2184,7 @@ __device__ __forceinline__ void main_hist(const Calib& c, const SlotRef& s, uint
             uint32_t packed[kBatch];
 #pragma unroll
             for (int q = 0; q < kBatch; q++) {
-                packed[q] = (e0 + q < ks) ? LST(min(e0 + q, lcap - 1)) : 0u;
+                packed[q] = LST_IF(e0 + q < ks, e0 + q, lcap);
                 rp[q] = load_raw(s, packed[q] & kIdxMask);
             }
 #pragma unroll
@@ -2784,6 +2782,8 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef
     const auto* col1 = col0 + c.bmStride;
     const int sh = x0 & 31;
     const int nxmax = uniform(wave_max_i32(nx));
+    const int kclamp = c.kTotal - 1;  // last row of a lane's column
+    const bool packed = nxmax <= 16;  // (wave-uniform) which of the two walks below wrote the codes
     for (int r0 = 0; r0 < nymax; r0 += 16) {
         // sixteen rows (four 16-byte pieces from each of the two word columns) in ONE round trip
         u32x4u a[4], b2[4];
@@ -2803,7 +2803,7 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef
         ST_USE_U32(a[3][0]);
         ST_USE_U32(b2[3][0]);
         ST_MARK(2);
-        if (nxmax <= 16) {
+        if (packed) {
             // Windows up to 16 cells wide (the C0 parameter set: 7 and 13): two rows are packed into one 32-bit word
             // (16 bits each) and the set bits of a word are walked in one loop.  A wavefront iterates to the largest
             // bit count among its lanes, and lanes hit the LiDAR rings in different rows: per pair of rows that maximum
@@ -2821,15 +2821,16 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef
                     const uint32_t fa = (rowa >= yn0 && rowa < yn0 + nyn) ? nmask : 0u;
                     const uint32_t fb = (rowa + 1 >= yn0 && rowa + 1 < yn0 + nyn) ? nmask : 0u;
                     const uint32_t flags = fa | (fb << 16);
-                    const uint32_t rowbase = (uint32_t)(rowa * c.W + x0);
+                    // (the walk stores a CODE per set bit - row pair and bit position; the key loop below turns it into
+                    //  the cell index, eight entries at a time, instead of this serial loop doing it bit by bit.  A lane
+                    //  past its capacity keeps counting and writes to the last row of its column: it is handed over)
+                    const uint32_t pairbase = (uint32_t)((r0 >> 1) + h) << 5;  // wave-uniform
+                    kf += __popc(b & flags);   // (counted per word, not per bit)
                     while (b) {
                         const uint32_t p = (uint32_t)__ffs((int)b) - 1u;
                         b &= b - 1u;
-                        const uint32_t fl = (flags >> p) & 1u;
-                        const uint32_t cell = rowbase + ((p & 16u) ? (uint32_t)c.W : 0u) + (p & 15u);
-                        if (k < c.k1max) LST(k) = cell | (fl << 31);
+                        LST(min(k, kclamp)) = pairbase | p | ((flags >> p) << 31);
                         k++;
-                        kf += (int)fl;
                     }
                 }
             }
@@ -2841,15 +2842,14 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef
                 const uint32_t v = __builtin_amdgcn_alignbit(b2[q >> 2][q & 3], a[q >> 2][q & 3], (uint32_t)sh);
                 uint32_t b = ((r0 + q) < ny) ? (v & colmask) : 0u;
                 const int row = y0 + r0 + q;
-                const uint32_t rowbase = (uint32_t)(row * c.W + x0);
+                const uint32_t rowcode = (uint32_t)(r0 + q) << 5;  // wave-uniform
                 const uint32_t rowflags = (row >= yn0 && row < yn0 + nyn) ? nmask : 0u;
+                kf += __popc(b & rowflags);
                 while (b) {
                     const uint32_t col = (uint32_t)__ffs((int)b) - 1u;
                     b &= b - 1u;
-                    const uint32_t fl = (rowflags >> col) & 1u;
-                    if (k < c.k1max) LST(k) = (rowbase + col) | (fl << 31);
+                    LST(min(k, kclamp)) = rowcode | col | ((rowflags >> col) << 31);
                     k++;
-                    kf += (int)fl;
                 }
             }
         }
@@ -2884,9 +2884,18 @@ __device__ __forceinline__ int scan_window_flagged(const Calib& c, const SlotRef
     for (int e0 = 0; e0 < kmax; e0 += KB) {
         uint32_t cell[KB], key[KB];
 #pragma unroll
-        for (int q = 0; q < KB; q++) cell[q] = (e0 + q < kk) ? LST(min(e0 + q, c.k1max - 1)) : 0u;
+        for (int q = 0; q < KB; q++) {
+            // code of the bit walk -> cell index (x + y W) | narrow flag
+            const uint32_t code = LST_IF(e0 + q < kk, e0 + q, c.k1max);
+            const uint32_t v = code & 0x7FFFFFFFu;
+            const uint32_t row = packed ? (((v >> 5) << 1) + ((v >> 4) & 1u)) : (v >> 5);
+            const uint32_t col = packed ? (v & 15u) : (v & 31u);
+            cell[q] = ((uint32_t)__mul24(y0 + (int)row, c.W) + (uint32_t)(x0 + (int)col)) | (code & kEntNarrow);
+        }
 #pragma unroll
-        for (int q = 0; q < KB; q++) key[q] = (e0 + q < kk) ? MLD_DIAG_KEY(mp[cell[q] & 0x7FFFFFFFu], s.g.tag, cell[q]) : 0u;
+        // (an unconditional load from a selected address - cell 0 beyond the lane's list - instead of a predicated one: a
+        //  select per entry where a predicated load is a branch per entry)
+        for (int q = 0; q < KB; q++) key[q] = MLD_DIAG_KEY(mp[(e0 + q < kk) ? (cell[q] & 0x7FFFFFFFu) : 0u], s.g.tag, cell[q]);
 #pragma unroll
         for (int q = 0; q < KB; q++)
             if (e0 + q < kk) {
