@@ -677,7 +677,8 @@ int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int sl
     bool aligned = true;
     for (int i = slot; i < slot + (single ? 1 : n_slots); i++)
         aligned = aligned && (((uintptr_t)ctx->slots[i].d.cloud) & 15) == 0;
-    auto kp = aligned ? mld::k_project_scatter<true> : mld::k_project_scatter<false>;
+    // magic = ceil(2^32 / per_slot): the kernel divides block indices by per_slot with a multiplication (div_by_magic)
+    const uint32_t ps_magic = per_slot > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)per_slot - 1) / (uint64_t)per_slot) : 0u;
     if (ctx->order_wait_pending) {  // mld_order_after_classify
         ctx->order_wait_pending = false;
         if (ctx->gate_counter) {
@@ -692,12 +693,14 @@ int launch_project(mld_ctx* ctx, int n_slots, int64_t max_n, bool single, int sl
     }
     ScopedTimer tm(ctx, 0, st);
     if (single) {
-        hipLaunchKernelGGL(kp, dim3(per_slot), dim3(kProjThreads), 0, st, ctx->d_slots, ctx->slots[slot].d, 1, ctx->calib, 1,
-                           per_slot, 0u);
+        auto kp = aligned ? mld::k_project_scatter<true, true> : mld::k_project_scatter<false, true>;
+        hipLaunchKernelGGL(kp, dim3(per_slot), dim3(kProjThreads), 0, st, ctx->d_slots, ctx->slots[slot].d, ctx->calib, 1,
+                           per_slot, ps_magic, 0u);
     } else {
         // (batch: the slots [slot, slot + n_slots))
+        auto kp = aligned ? mld::k_project_scatter<true, false> : mld::k_project_scatter<false, false>;
         hipLaunchKernelGGL(kp, dim3((unsigned)per_slot * n_slots), dim3(kProjThreads), ctx->proj_lds, st, ctx->d_slots + slot,
-                           SlotDesc{}, 0, ctx->calib, n_slots, per_slot, common_tag(ctx, n_slots, slot));
+                           SlotDesc{}, ctx->calib, n_slots, per_slot, ps_magic, common_tag(ctx, n_slots, slot));
     }
     HIP_TRY(ctx, hipGetLastError());
     return MLD_OK;

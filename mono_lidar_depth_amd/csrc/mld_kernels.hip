@@ -33,6 +33,8 @@ namespace mld {
 // instruction.  They are always device-global memory: cast to address space 1 so global_load/store/atomic is emitted.
 #define GPTR(T, p) ((const T __attribute__((address_space(1)))*)(p))
 #define GPTRW(T, p) ((T __attribute__((address_space(1)))*)(p))
+// ... and in the constant address space: wave-uniform addresses of memory no kernel writes while this one runs - scalar loads
+#define CPTR(T, p) ((const T __attribute__((address_space(4)))*)(p))
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));  // 16-byte load from a 4-byte aligned address
 
@@ -123,6 +125,29 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 // cloud stay in one L2.  The last n_slots % 8 slots (and batches of fewer than 8) use the plain slot-major order.
 // This is a speed-only mapping; nothing depends on placement.
 // (a negative n_slots selects the plain mapping throughout: MLD_NO_XCD=1, for A/B measurements)
+// The same with the division by per_slot replaced by a multiplication with magic = ceil(2^32 / per_slot) (host side:
+// div_magic) and one correction step: the quotient estimate umulhi(q, magic) is never too small and at most one too large.
+// (The compiler's generic 32-bit division is ~35 scalar instructions in front of everything else a wavefront does.)
+__device__ __forceinline__ int div_by_magic(int q, int d, uint32_t magic) {
+    int e = (int)__umulhi((uint32_t)q, magic);
+    e -= (q - e * d < 0) ? 1 : 0;
+    return e;
+}
+__device__ __forceinline__ void decode_block_magic(int b, int n_slots, int per_slot, uint32_t magic, int& slot, int& j) {
+    const int n8 = n_slots > 0 ? (n_slots & ~7) : 0;
+    const int b8 = n8 * per_slot;
+    if (b < b8) {
+        const int x = b & 7, q = b >> 3;
+        const int sq = div_by_magic(q, per_slot, magic);
+        j = q - sq * per_slot;
+        slot = sq * 8 + x;
+    } else {
+        const int r = b - b8;
+        const int sr = div_by_magic(r, per_slot, magic);
+        slot = n8 + sr;
+        j = r - sr * per_slot;
+    }
+}
 __device__ __forceinline__ void decode_block(int b, int n_slots, int per_slot, int& slot, int& j) {
     const int n8 = n_slots > 0 ? (n_slots & ~7) : 0;
     const int b8 = n8 * per_slot;
@@ -180,16 +205,10 @@ __device__ __forceinline__ void apply_plane_dev(SlotDesc& s) {
 // Raw float point -> camera frame (DepthEstimator.cpp:169,173).
 __device__ __forceinline__ void load_point(const SlotDesc& s, long long i, double& x, double& y, double& z) {
     const unsigned char* p = s.cloud + (size_t)i * (size_t)s.stride;
-    if ((((size_t)s.cloud) & 15) == 0) {
-        f32x4 q = *GPTR(f32x4, p);
-        x = (double)q.x;
-        y = (double)q.y;
-        z = (double)q.z;
-    } else {
-        x = (double)GPTR(float, p)[0];
-        y = (double)GPTR(float, p)[1];
-        z = (double)GPTR(float, p)[2];
-    }
+    // (one 12-byte load whatever the cloud's alignment: see load_raw)
+    x = (double)GPTR(float, p)[0];
+    y = (double)GPTR(float, p)[1];
+    z = (double)GPTR(float, p)[2];
 }
 __device__ __forceinline__ V3 lidar_to_cam(const Calib& c, double x, double y, double z) {
     V3 r;
@@ -230,9 +249,12 @@ constexpr int kProjPerThread = MLD_PROJ_PER_THREAD;
 // sequence, and a point's load is waited for where the point is first used.  (With both sequences in one kernel their
 // results meet in register copies behind the loads, i.e. every load of the thread is waited for before the first
 // point is touched.)
-template <bool ALIGNED16>
+// SINGLE: the one-frame call - its slot descriptor travels by value (no upload in front of the kernel); batches read
+// theirs in device memory.  (As one kernel with a run-time flag every descriptor field was a select between the two behind
+// a uniform branch: fourteen of them in front of the first point load.)
+template <bool ALIGNED16, bool SINGLE>
 __global__ __launch_bounds__(kProjThreads) MLD_PROJ_ATTR void k_project_scatter(const SlotDesc* __restrict__ slots, SlotDesc single,
-                                                                  int use_single, Calib c, int n_slots, int per_slot,
+                                                                  Calib c, int n_slots, int per_slot, uint32_t ps_magic,
                                                                   uint32_t tag_all) {
     // Raised issue priority: beside another context's feature kernels (long f64 sequences, always ready to issue)
     // the few instructions a projection wave needs between its loads and its atomics would otherwise wait their
@@ -241,51 +263,26 @@ __global__ __launch_bounds__(kProjThreads) MLD_PROJ_ATTR void k_project_scatter(
 #define MLD_PROJ_PRIO 3
 #endif
     __builtin_amdgcn_s_setprio(MLD_PROJ_PRIO);
-    int slot, j;
-    decode_block((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, slot, j);
-    SlotDesc s = use_single ? single : slots[slot];  // block-uniform: scalar loads, field by field
-    if (tag_all) s.tag = tag_all;
-    // Ground-plane state of the visible points (rides in the map keys when the plane is already known).  "Far" is the
-    // distance test of CalculateDepthSegmentationPlane (DepthEstimator.cpp:810-815): camera -> lidar in f64, float,
-    // un-normalised float plane distance > threshold - a property of the point alone.  The f64 round trip returns the
-    // raw float coordinates up to e = far_elin * m1 + far_econst (host bound), so the distance evaluated on the RAW
-    // floats differs from the reference's by at most cs (2^-24 m1 + 2 e) + 8 * 2^-24 (cs m1 + |d|), cs = |a|+|b|+|c|: a
-    // point is marked far / near only beyond a margin of several times that, otherwise "unsure" (exact test in the
-    // feature kernel; a handful of points per frame at most).
-    const bool flags_on = s.mask_in_key != 0;
-    float pa = s.coeffs[0], pb = s.coeffs[1], pcz = s.coeffs[2], pd = s.coeffs[3];
-    float fmg0 = s.far_mg0, fmg1 = s.far_mg1;  // (far_margins: prepared once per plane, not per wavefront)
-    if (flags_on && s.plane_dev) {  // the plane of a batched estimation lives in device memory
-        const auto* q = GPTR(PlaneDev, s.plane_dev);
-        pa = q->coeffs[0];
-        pb = q->coeffs[1];
-        pcz = q->coeffs[2];
-        pd = q->coeffs[3];
-        fmg0 = q->far_mg0;
-        fmg1 = q->far_mg1;
-    }
-    {
-        // block-uniform values: into scalar registers (the register file decides how many projection wavefronts fit
-        // beside the other context's feature kernel)
-        auto sreg = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-        pa = sreg(pa);
-        pb = sreg(pb);
-        pcz = sreg(pcz);
-        pd = sreg(pd);
-        fmg0 = sreg(fmg0);
-        fmg1 = sreg(fmg1);
-    }
-    const float thrf = c.roadDistThrF;
+    int slot = 0, j = (int)blockIdx.x;
+    if (!SINGLE) decode_block_magic((int)blockIdx.x, c.xcdAware ? n_slots : -n_slots, per_slot, ps_magic, slot, j);
+    // ---- FIRST what the point loads need - cloud, point count, stride - and the loads themselves; the rest of the
+    // descriptor and the plane's parameters are fetched while they are in flight.  (Round 6: the prologue used to resolve
+    // the whole descriptor and - through six VECTOR loads and read-first-lanes, a full memory round trip - the plane's
+    // coefficients before the first point load was issued: four dependent round trips per wavefront instead of two.)
+    const SlotDesc& sg = slots[SINGLE ? 0 : slot];  // (never dereferenced when SINGLE)
+    const unsigned char* cl = SINGLE ? single.cloud : sg.cloud;
     // 32-bit index and offset arithmetic throughout: a cloud has at most 2^23 - 1 points of 16 or 32 bytes
-    const int n = (int)s.n;
+    const int n = (int)(SINGLE ? single.n : sg.n);
+    const int stride = SINGLE ? single.stride : sg.stride;
     const int blk0 = j * (kProjThreads * kProjPerThread);
+    // (cloud pointer and stride are fetched WITH the count - one scalar round trip - not behind the test below)
+    asm volatile("" ::"s"(stride), "s"((uint32_t)(uintptr_t)cl), "s"((uint32_t)((uintptr_t)cl >> 32)));
     if (blk0 >= n) return;  // block-uniform (the clouds of a batch may differ in size)
     const int base = blk0 + (int)threadIdx.x;
-    const uint32_t sh = (s.stride == 32) ? 5u : 4u;
-    const unsigned char* cl = s.cloud;
+    const uint32_t sh = (stride == 32) ? 5u : 4u;
     float fx[kProjPerThread], fy[kProjPerThread], fz[kProjPerThread];
     // every lane loads a valid point (index clamped to the cloud); lanes beyond the end are masked out of the result
-    if (ALIGNED16 || (((size_t)s.cloud) & 15) == 0) {
+    if (ALIGNED16 || (((size_t)cl) & 15) == 0) {
 #pragma unroll
         for (int r = 0; r < kProjPerThread; r++) {
             const int i = min(base + r * kProjThreads, n - 1);
@@ -305,6 +302,58 @@ __global__ __launch_bounds__(kProjThreads) MLD_PROJ_ATTR void k_project_scatter(
             fz[r] = q[2];
         }
     }
+    __builtin_amdgcn_sched_barrier(0);  // (nothing below moves in front of the loads, no load behind what follows)
+    // ---- the rest of the slot: tag, map, bitmap, inlier mask; ground-plane state of the visible points (rides in the map
+    // keys when the plane is already known).  "Far" is the distance test of CalculateDepthSegmentationPlane
+    // (DepthEstimator.cpp:810-815): camera -> lidar in f64, float, un-normalised float plane distance > threshold - a
+    // property of the point alone.  The f64 round trip returns the raw float coordinates up to e = far_elin * m1 +
+    // far_econst (host bound), so the distance evaluated on the RAW floats differs from the reference's by at most
+    // cs (2^-24 m1 + 2 e) + 8 * 2^-24 (cs m1 + |d|), cs = |a|+|b|+|c|: a point is marked far / near only beyond a margin of
+    // several times that, otherwise "unsure" (exact test in the feature kernel; a handful of points per frame at most).
+    struct {
+        uint32_t* map;
+        uint32_t* bitmap;
+        const uint32_t* inlier_mask;
+        uint32_t tag;
+    } s;
+    s.map = SINGLE ? single.map : sg.map;
+    s.bitmap = SINGLE ? single.bitmap : sg.bitmap;
+    s.inlier_mask = SINGLE ? single.inlier_mask : sg.inlier_mask;
+    s.tag = tag_all ? tag_all : (SINGLE ? single.tag : sg.tag);
+    const bool flags_on = (SINGLE ? single.mask_in_key : sg.mask_in_key) != 0;
+    float pa, pb, pcz, pd, fmg0, fmg1;  // (far_margins: prepared once per plane, not per wavefront)
+    if (SINGLE) {
+        pa = single.coeffs[0];
+        pb = single.coeffs[1];
+        pcz = single.coeffs[2];
+        pd = single.coeffs[3];
+        fmg0 = single.far_mg0;
+        fmg1 = single.far_mg1;
+        if (flags_on && single.plane_dev) {  // the plane of an estimation on the device lives in device memory
+            const auto* q = CPTR(PlaneDev, single.plane_dev);
+            pa = q->coeffs[0];
+            pb = q->coeffs[1];
+            pcz = q->coeffs[2];
+            pd = q->coeffs[3];
+            fmg0 = q->far_mg0;
+            fmg1 = q->far_mg1;
+        }
+    } else {
+        // block-uniform addresses in memory nothing writes while this kernel runs: scalar loads (constant address space),
+        // into scalar registers (the register file decides how many projection wavefronts fit beside the other context's
+        // feature kernel)
+        const PlaneDev* pdv = sg.plane_dev;
+        const bool dev = flags_on && pdv;
+        const auto* cf = CPTR(float, dev ? pdv->coeffs : sg.coeffs);
+        const auto* mg = CPTR(float, dev ? &pdv->far_mg0 : &sg.far_mg0);
+        pa = cf[0];
+        pb = cf[1];
+        pcz = cf[2];
+        pd = cf[3];
+        fmg0 = mg[0];
+        fmg1 = mg[1];
+    }
+    const float thrf = c.roadDistThrF;
     const double Wd = (double)c.W, Hd = (double)c.H;
     const float Wf = (float)c.W, Hf = (float)c.H;
     // translation terms of the single-precision transform: used by every point, kept in vector registers
@@ -1627,7 +1676,10 @@ constexpr int kZcMid = MLD_KZC_MID, kZcDense = MLD_KZC_DENSE;  // ... and in the
 #define MLD_ROAD_BATCH 4
 #endif
 constexpr int kRoadBatch = MLD_ROAD_BATCH;  // wide-window neighbours fetched per round trip by the road fallback
-constexpr int kBatch = 4;    // list entries fetched ahead of use in the per-lane list loops  // lists up to this length use the fully unrolled in-register triangle search
+#ifndef MLD_LIST_BATCH
+#define MLD_LIST_BATCH 4
+#endif
+constexpr int kBatch = MLD_LIST_BATCH;    // list entries fetched ahead of use in the per-lane list loops  // lists up to this length use the fully unrolled in-register triangle search
 
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
@@ -2756,6 +2808,10 @@ __global__ __launch_bounds__(256) void k_upload(uint32_t* __restrict__ dst, cons
 #define MLD_KEY_BATCH_F 8
 #endif
 constexpr int kKeyBatchF = MLD_KEY_BATCH_F;  // map keys fetched per round trip by the fused kernel
+#ifndef MLD_DENSE_BATCH_MUL
+#define MLD_DENSE_BATCH_MUL 2
+#endif
+constexpr int kDenseBatchMul = MLD_DENSE_BATCH_MUL;  // the DENSE 2 instantiation fetches that many times the keys / road points
 
 // One scan of the window (x0, y0, nx, ny) through the occupancy bitmap; entries in the reference's row-major order,
 // bit 31 set for the cells that also lie inside the narrow window (xn0, yn0, nxn, nyn).  The lane's list ends up
@@ -2996,7 +3052,7 @@ __global__ __launch_bounds__(kWave, DENSE == 2 ? 2 : (DENSE == 1 ? MLD_FUSED_WAV
         int k1 = 0;
         uint32_t list_states = 0u;
         int nbase = 0, nroom = 0;
-        const int k2 = scan_window_flagged<DENSE == 2 ? 2 * kKeyBatchF : kKeyBatchF>(c, s, x0, y0, nx, ny, xn0, yn0, nxn, nyn, lst,
+        const int k2 = scan_window_flagged<DENSE == 2 ? kDenseBatchMul * kKeyBatchF : kKeyBatchF>(c, s, x0, y0, nx, ny, xn0, yn0, nxn, nyn, lst,
                                                                                     lane, k1, list_states, nbase, nroom ST_PASS);
         // (k_classify keeps windows wider than 32 cells out of the live queue)
         bool overflow = active && (k2 > c.k1max || k2 > nbase || k1 > nroom);
@@ -3031,7 +3087,7 @@ __global__ __launch_bounds__(kWave, DENSE == 2 ? 2 : (DENSE == 1 ? MLD_FUSED_WAV
         if (__any(cand)) {
             const int resultOld = mytype;
             bool ovf2 = false;
-            road_after_scan<ROAD_MODE, DENSE == 2 ? 2 * kRoadBatch : kRoadBatch>(c, s, lst, lane, cand, k2, list_states, myu, myv,
+            road_after_scan<ROAD_MODE, DENSE == 2 ? kDenseBatchMul * kRoadBatch : kRoadBatch>(c, s, lst, lane, cand, k2, list_states, myu, myv,
                                                                                 mytype, mydepth, ovf2 ST_PASS);
             if (ovf2) {  // only the road part is redone by the wave kernel
                 overflow = true;
