@@ -500,29 +500,45 @@ __device__ int gather_window(const Calib& c, const SlotDesc& s, double u, double
     const int ncell = nx * ny;
     const float rnx = 1.0f / (float)nx;
     int k = 0;
-    for (int base = 0; base < ncell; base += kWave) {
-        int cidx = base + lane;
-        bool has = false;
-        int orig = 0;
-        if (cidx < ncell) {
-            int row = (int)(((float)cidx + 0.5f) * rnx);
-            int col = cidx - row * nx;
-            uint32_t key = GPTR(uint32_t, s.map)[(size_t)(x0 + col) + (size_t)(y0 + row) * (size_t)c.W];
-            has = (key >> kTagShift) == s.tag && (!inliers_only || (key & 3u) == kPtInlier);
-            orig = (int)key_index(key);
+    // Three 64-cell groups per pass - the road window of the reference's parameters (13 x 14 cells) in one -: their keys
+    // are fetched together, then their points together (two memory round trips per pass instead of two per group;
+    // unconditional loads from selected addresses: a predicated load is a branch and a full wait per group, LAB.md 6.14).
+    constexpr int KG = 3;
+    for (int base = 0; base < ncell; base += KG * kWave) {
+        uint32_t key[KG];
+        bool val[KG];
+#pragma unroll
+        for (int g = 0; g < KG; g++) {
+            const int cidx = base + g * kWave + lane;
+            val[g] = cidx < ncell;
+            const int row = (int)(((float)cidx + 0.5f) * rnx);
+            const int col = cidx - row * nx;
+            const size_t off = val[g] ? ((size_t)(x0 + col) + (size_t)(y0 + row) * (size_t)c.W) : (size_t)0;
+            key[g] = GPTR(uint32_t, s.map)[off];
         }
-        unsigned long long m = __ballot(has);
-        int rank = k + prefix_count(m);
-        if (has && rank < c.cap) {
-            double x, y, z;
-            load_point(s, orig, x, y, z);
-            V3 pc = lidar_to_cam(c, x, y, z);
-            L.x[rank] = pc.x;
-            L.y[rank] = pc.y;
-            L.z[rank] = pc.z;
-            L.idx[rank] = orig;
+        int orig[KG], rank[KG];
+        bool take[KG];
+#pragma unroll
+        for (int g = 0; g < KG; g++) {
+            const bool has = val[g] && (key[g] >> kTagShift) == s.tag && (!inliers_only || (key[g] & 3u) == kPtInlier);
+            orig[g] = (int)key_index(key[g]);
+            const unsigned long long m = __ballot(has);
+            rank[g] = k + prefix_count(m);
+            take[g] = has && rank[g] < c.cap;
+            k += __popcll(m);
         }
-        k += __popcll(m);
+        double px[KG], py[KG], pz[KG];
+#pragma unroll
+        for (int g = 0; g < KG; g++) load_point(s, take[g] ? orig[g] : 0, px[g], py[g], pz[g]);
+#pragma unroll
+        for (int g = 0; g < KG; g++)
+            if (take[g]) {
+                const V3 pc = lidar_to_cam(c, px[g], py[g], pz[g]);
+                L.x[rank[g]] = pc.x;
+                L.y[rank[g]] = pc.y;
+                L.z[rank[g]] = pc.z;
+                L.idx[rank[g]] = orig[g];
+            }
     }
     k = uniform(k);
     return k < c.cap ? k : c.cap;
@@ -544,19 +560,27 @@ __device__ void window_states(const Calib& c, const SlotDesc& s, double u, doubl
     ny = uniform(ny);
     const int ncell = nx * ny;
     const float rnx = 1.0f / (float)nx;
-    for (int base = 0; base < ncell; base += kWave) {
-        const int cidx = base + lane;
-        uint32_t st = 0xFFu;
-        if (cidx < ncell) {
+    constexpr int KG = 3;  // (as gather_window: the keys of three 64-cell groups in one round trip)
+    for (int base = 0; base < ncell; base += KG * kWave) {
+        uint32_t key[KG];
+        bool val[KG];
+#pragma unroll
+        for (int g = 0; g < KG; g++) {
+            const int cidx = base + g * kWave + lane;
+            val[g] = cidx < ncell;
             const int row = (int)(((float)cidx + 0.5f) * rnx);
             const int col = cidx - row * nx;
-            const uint32_t key = GPTR(uint32_t, s.map)[(size_t)(x0 + col) + (size_t)(y0 + row) * (size_t)c.W];
-            if ((key >> kTagShift) == s.tag) st = key & 3u;
+            const size_t off = val[g] ? ((size_t)(x0 + col) + (size_t)(y0 + row) * (size_t)c.W) : (size_t)0;
+            key[g] = GPTR(uint32_t, s.map)[off];
         }
-        k_all += (int)__popcll(__ballot(st != 0xFFu));
-        k_inl += (int)__popcll(__ballot(st == kPtInlier));
-        any_far = any_far || (__ballot(st == kPtFar) != 0ull);
-        any_unsure = any_unsure || (__ballot(st == kPtUnsure) != 0ull);
+#pragma unroll
+        for (int g = 0; g < KG; g++) {
+            const uint32_t st = (val[g] && (key[g] >> kTagShift) == s.tag) ? (key[g] & 3u) : 0xFFu;
+            k_all += (int)__popcll(__ballot(st != 0xFFu));
+            k_inl += (int)__popcll(__ballot(st == kPtInlier));
+            any_far = any_far || (__ballot(st == kPtFar) != 0ull);
+            any_unsure = any_unsure || (__ballot(st == kPtUnsure) != 0ull);
+        }
     }
 }
 
