@@ -1674,6 +1674,7 @@ constexpr int kK2Max = 16;  // longest list of the TRIANGLE ROAD ESTIMATOR's in-
 #define MLD_TRI_SMALL 8
 #endif
 constexpr int kTriSmall = MLD_TRI_SMALL;
+constexpr int kTriTiny = 4;  // short tier of the default instantiation (segmented lists of at most 4 points in the wavefront)
 #ifndef MLD_TRI_MID
 #define MLD_TRI_MID 12
 #endif
@@ -1696,6 +1697,7 @@ constexpr int kZcDefault = MLD_KZC;  // list entries whose depth stays in regist
 #define MLD_KZC_DENSE 24
 #endif
 constexpr int kZcMid = MLD_KZC_MID, kZcDense = MLD_KZC_DENSE;  // ... and in the further tiers of the DENSE instantiation
+constexpr int kZcTiny = 4, kZcShort = 8;  // ... and in the short tiers of the default one
 #ifndef MLD_ROAD_BATCH
 #define MLD_ROAD_BATCH 4
 #endif
@@ -2337,7 +2339,9 @@ __device__ __forceinline__ void main_tail(const Calib& c, const SlotRef& s, uint
         // (DENSE 2: tiers up to 24 points; DENSE 1 - the dense kernel beside another context's projection, 168 registers -
         // up to 16; the default instantiation 8)
         constexpr int kTop = DENSE == 2 ? kTriHuge : (DENSE == 1 ? kTriLarge : kTriSmall);
-        if (ksmax <= kTriSmall || ksmax > kTop) {
+        if (DENSE == 0 && ksmax <= kTriTiny) {
+            ok = triangle_small<DENSE == 0 ? kTriTiny : 1>(c, s, ks, live, lst, lane, lcap, c1, c2, c3);  // 6 pairs instead of 28
+        } else if (ksmax <= kTriSmall || ksmax > kTop) {
             ok = triangle_small<kTriSmall>(c, s, ks, live && ks <= kTriSmall, lst, lane, lcap, c1, c2, c3);
             if (ksmax > kTriSmall) {  // longer segmented lists: the generic serial loops
                 V3 d1, d2, d3;
@@ -2421,11 +2425,17 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotRef& s
     double minZ, maxZ;
     // (DENSE: a wavefront whose longest list exceeds the first tier keeps 16 / 24 depths in registers - one memory round
     // trip for the depths instead of three passes of four-entry round trips over the tail)
-    const int kmax0 = DENSE ? uniform(wave_max_i32(live ? k : 0)) : 0;
+    const int kmax0 = uniform(wave_max_i32(live ? k : 0));
     if (DENSE && kmax0 > kZcDefault && (kmax0 <= kZcMid || DENSE == 1))
         main_hist<DENSE ? kZcMid : kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
     else if (DENSE == 2 && kmax0 > kZcMid)
         main_hist<DENSE == 2 ? kZcDense : kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
+    // (default instantiation: wavefronts whose longest narrow list has at most 4 / 8 entries - k_classify orders the queue
+    //  by list length; random features on a 64-beam cloud: most of them - fetch and bin 4 / 8 depths instead of 12)
+    else if (DENSE == 0 && kmax0 <= kZcTiny)
+        main_hist<DENSE == 0 ? kZcTiny : kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
+    else if (DENSE == 0 && kmax0 <= kZcShort)
+        main_hist<DENSE == 0 ? kZcShort : kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
     else
         main_hist<kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
     main_tail<DENSE>(c, s, lst, lane, lcap, ks, live, minZ, maxZ, myu, myv, mytype, mydepth, overflow ST_PASS);
