@@ -73,3 +73,37 @@ def test_list_budget_argument_bounds():
         est.setListBudget(47)
     est.setListBudget(72)
     est.close()
+
+
+def test_path_counts_report_what_the_budget_hands_over(dense_frames):
+    """mld_get_path_counts: features queued for the lane-per-feature kernel / features the wave-cooperative kernel worked on
+    in the slot's last batched call - the feedback for choosing capacities.  On the dense cloud a tighter budget hands more
+    features over, and the results stay the oracle's (test above); nothing is counted before the first batched call."""
+    P, clouds, planes, uvs, ref = dense_frames
+    dev = torch.device("cuda:0")
+    B, F = len(clouds), uvs[0].shape[0]
+    counts = {}
+    for budget in (72, 56, 48):
+        est = make_estimator(P, max_frames=B, max_features=F)
+        est.setListCapacity(48, 24)
+        est.setListBudget(budget)
+        assert est.pathCounts(0) == (0, 0)
+        d_clouds = [torch.from_numpy(c).to(dev) for c in clouds]
+        d_masks = [torch.from_numpy(_mask(p[1], c.shape[0])).to(dev) for p, c in zip(planes, clouds)]
+        d_uvs = [torch.from_numpy(u).to(dev) for u in uvs]
+        d_depth = [torch.empty((F,), dtype=torch.float64, device=dev) for _ in range(B)]
+        d_type = [torch.empty((F,), dtype=torch.int32, device=dev) for _ in range(B)]
+        batch = est.prepareBatch(d_clouds, d_uvs, d_depth, d_type, np.stack([p[0] for p in planes]), d_masks, stride_bytes=16)
+        est.runBatch(batch)
+        est.synchronize()
+        counts[budget] = [est.pathCounts(b) for b in range(B)]
+        for b in range(B):
+            lane, handed = counts[budget][b]
+            dead = int((ref[b][1] == 2).sum())   # RadiusSearchInsufficientPoints: settled by the classification itself
+            assert 0 < lane <= F and 0 <= handed <= F
+            assert lane + handed >= F - dead   # every feature with neighbours went to (at least) one of the two kernels
+        with pytest.raises(DepthEstimatorError):
+            est.pathCounts(B)   # no such slot
+        est.close()
+    for b in range(B):
+        assert counts[48][b][1] > counts[56][b][1] > counts[72][b][1]
