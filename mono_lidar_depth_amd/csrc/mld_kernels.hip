@@ -2339,13 +2339,8 @@ __device__ __forceinline__ void main_tail(const Calib& c, const SlotRef& s, uint
         // (DENSE 2: tiers up to 24 points; DENSE 1 - the dense kernel beside another context's projection, 168 registers -
         // up to 16; the default instantiation 8)
         constexpr int kTop = DENSE == 2 ? kTriHuge : (DENSE == 1 ? kTriLarge : kTriSmall);
-#ifdef MLD_DENSE_SHORT
-        if (ksmax <= kTriTiny) {
-            ok = triangle_small<kTriTiny>(c, s, ks, live, lst, lane, lcap, c1, c2, c3);
-#else
         if (DENSE == 0 && ksmax <= kTriTiny) {
             ok = triangle_small<DENSE == 0 ? kTriTiny : 1>(c, s, ks, live, lst, lane, lcap, c1, c2, c3);  // 6 pairs instead of 28
-#endif
         } else if (ksmax <= kTriSmall || ksmax > kTop) {
             ok = triangle_small<kTriSmall>(c, s, ks, live && ks <= kTriSmall, lst, lane, lcap, c1, c2, c3);
             if (ksmax > kTriSmall) {  // longer segmented lists: the generic serial loops
@@ -2437,17 +2432,12 @@ __device__ __forceinline__ void main_after_scan(const Calib& c, const SlotRef& s
         main_hist<DENSE == 2 ? kZcDense : kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
     // (default instantiation: wavefronts whose longest narrow list has at most 4 / 8 entries - k_classify orders the queue
     //  by list length; random features on a 64-beam cloud: most of them - fetch and bin 4 / 8 depths instead of 12)
-#ifdef MLD_DENSE_SHORT
-    else if (kmax0 <= kZcTiny)
-        main_hist<kZcTiny>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
-    else if (kmax0 <= kZcShort)
-        main_hist<kZcShort>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
-#else
+    // (the DENSE instantiations keep 12 as their shortest tier: with the short ones as well config 5 at S = 256 ran 2.5 %
+    //  SLOWER - 52 instead of 46 spilled registers, 32 k instructions -, LAB.md 6.20)
     else if (DENSE == 0 && kmax0 <= kZcTiny)
         main_hist<DENSE == 0 ? kZcTiny : kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
     else if (DENSE == 0 && kmax0 <= kZcShort)
         main_hist<DENSE == 0 ? kZcShort : kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
-#endif
     else
         main_hist<kZcDefault>(c, s, lst, lane, lcap, k, live, mytype, ks, minZ, maxZ ST_PASS);
     main_tail<DENSE>(c, s, lst, lane, lcap, ks, live, minZ, maxZ, myu, myv, mytype, mydepth, overflow ST_PASS);
