@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the "LOW priority" rows need profiles/tools/libs/pairprio.so: profiles/patches/r6_pair_low_prio.patch + mkvariant.sh pairprio -DMLD_PAIR_LOW_PRIO)
 C2="--steps 60 --warmup 5 --repeats 3 --cpu-seconds 0 --legs none --verify-slots 32 --no-exclusive"
 show() { python -c "
 import json,sys
