@@ -52,3 +52,50 @@ def test_calibration_broadcast_over_rccl_single_rank():
                 "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_numa_pinning_against_the_real_sysfs_of_the_gpu_box():
+    """`bind_to_gpu_numa_node` + `rebind_if_device_differs` against the box's own /sys and the PCI address the runtime
+    reports (the CPU suite only has a fake sysfs): whatever the box looks like - GPUs without a NUMA node, more GPUs in sysfs
+    than are visible, a restricted affinity mask -, the rank ends inside the mask it was started under, with at least one
+    core, and when the device is found in sysfs with a NUMA node, pinned to THAT node's cores."""
+    code = textwrap.dedent("""
+        import json, os, sys
+        sys.path.insert(0, %r)
+        from mono_lidar_depth_amd import sharding
+        start = sorted(os.sched_getaffinity(0))
+        info = sharding.bind_to_gpu_numa_node(0)                 # before any GPU call, as bench.py's worker does
+        guessed = sorted(os.sched_getaffinity(0))
+        import torch
+        pr = torch.cuda.get_device_properties(0)
+        pci = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        info = sharding.rebind_if_device_differs(info, pci)
+        final = sorted(os.sched_getaffinity(0))
+        nodes = dict((k.lower(), v) for k, v in sharding.gpu_numa_nodes())
+        out = {"info": {k: v for k, v in info.items() if k != "initial_cpus"}, "start": len(start), "final": len(final),
+               "inside": set(final) <= set(start), "sysfs_gpus": len(nodes), "device_in_sysfs": pci.lower() in nodes,
+               "device_node": nodes.get(pci.lower())}
+        if out["device_in_sysfs"] and nodes[pci.lower()] >= 0:
+            with open(f"/sys/devices/system/node/node{nodes[pci.lower()]}/cpulist") as f:
+                node_cpus = set(sharding._parse_cpulist(f.read()))
+            out["node_cpus"] = len(node_cpus)
+            out["on_node"] = (set(final) <= node_cpus) if (node_cpus & set(start)) else None
+        torch.zeros(8, device="cuda").sum().item()                # the GPU still works from the pinned process
+        print("NUMA " + json.dumps(out))
+    """ % str(ROOT))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    import json
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("NUMA ")][-1][5:])
+    print(out)
+    assert out["inside"] and out["final"] >= 1, out
+    info = out["info"]
+    assert info["pci_device"] and info["local_rank"] == 0, out
+    if out["device_in_sysfs"]:
+        # the guess either named the device or the re-bind corrected it (or had a stated reason not to)
+        assert info["pci_matches"] or info.get("corrected_after_init") or info.get("reason"), out
+        if out.get("on_node") is not None and not info.get("reason"):
+            assert out["on_node"], out
+            assert info["numa_node"] == out["device_node"], out
+    else:
+        assert info["pci_matches"] in (False, None), out
