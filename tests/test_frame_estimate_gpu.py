@@ -184,6 +184,7 @@ def test_frames_in_turn_on_two_slots_and_the_timing_breakdown():
     est = make_estimator(P, max_frames=2)
     est.timingEnable(True)
     ref = make_oracle(P)
+    ransac_plane_us = []
     for it in range(6):
         cloud = synth.make_cloud(synth.HDL64_KITTI, seed=20, frame=it)
         uv = synth.make_features(1000, seed=200 + it)
@@ -196,13 +197,15 @@ def test_frames_in_turn_on_two_slots_and_the_timing_breakdown():
         assert tm["h2d_us"] > 0 and tm["plane_us"] > 0 and tm["kernels_us"] > 0 and tm["d2h_us"] > 0
         assert tm["gpu_us"] >= tm["h2d_us"] + tm["plane_us"] + tm["kernels_us"] + tm["d2h_us"] - 1.0
         assert tm["total_us"] >= tm["api_us"] + tm["wait_us"] - 1.0
+        ransac_plane_us.append(tm["plane_us"])
     est.timingEnable(False)
     # a supplied plane through the same machinery: no plane phase
     cloud = synth.make_cloud(synth.HDL64_KITTI, seed=20, frame=9)
     coeffs, inl = synth.make_ground_plane(cloud)
     est.timingEnable(True)
     est.CalculateDepth(cloud, synth.make_features(500, seed=3), GroundPlane(coeffs, inl))
-    assert est.frameTiming()["plane_us"] < 30.0  # (only the wait for the side stream's small inputs)
+    # (only the wait for the side stream's small inputs: ~10-20 us; the estimation itself takes 45-60)
+    assert est.frameTiming()["plane_us"] < max(30.0, 0.8 * min(ransac_plane_us)), (est.frameTiming(), ransac_plane_us)
 
 
 def test_large_cloud_with_the_pass_through_takes_the_per_slot_estimator():
