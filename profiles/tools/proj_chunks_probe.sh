@@ -3,7 +3,7 @@
 # projection blocks (k_rs_batch: 16 wavefronts, 150 KB of LDS, all of a SIMD's registers; k_classify: 16 wavefronts, 63 KB) get
 # in at the boundaries?  The plane-estimated leg in both schedules, and the headline step.
 mkdir -p gpurun_out
-export MLD_HIP_LIBRARY=$PWD/mono_lidar_depth_amd/lib/libmld_hip_ab.so
+export MLD_HIP_LIBRARY=${MLD_PROBE_LIB:-$PWD/mono_lidar_depth_amd/lib/libmld_hip_ab.so}
 est() {
 python bench_support/run_legs.py --legs estimated --est-steps 40 $1 2>gpurun_out/est.err | tail -1 | python -c "
 import json,sys
@@ -20,6 +20,6 @@ for c in ${@:-1 4 8 16}; do
   export MLD_PROJ_CHUNKS=$c
   est ""
   est "--est-schedule alternate"
-  head ""
-  head "--handover projection"
+  [ -n "$MLD_PROBE_EST_ONLY" ] || head ""
+  [ -n "$MLD_PROBE_EST_ONLY" ] || head "--handover projection"
 done
