@@ -1349,7 +1349,7 @@ __device__ __forceinline__ void finish_road(const Calib& c, bool triangle, doubl
 // the OUTCOME - a depth handed out with more than 2e-5 m of it, a threshold decision within ten times of it - or the input
 // is not finite, the caller hands the feature to the wave kernel (road_qr: SVD accuracy).  LAB.md 5.33, 5.34.
 __device__ __forceinline__ bool finish_road_fast(const Calib& c, double u, double v, const double r[kRecFields],
-                                                 int& out_type, double& out_depth) {
+                                                 const double sw, const double cdev, int& out_type, double& out_depth) {
     const V3 dir = viewing_ray(c, u, v);
     const V3 support = {0, 0, 0};
     const V3 center = {r[0], r[1], r[2]};
@@ -1386,8 +1386,17 @@ __device__ __forceinline__ bool finish_road_fast(const Calib& c, double u, doubl
 #endif
     const double raw = depth;
     const double den = gap * nd;
+    // The sums' rounding relative to the trace: a few 1e-15 from the reciprocal estimates of the update, and - West's
+    // update subtracts a ROUNDED running mean from every point - 2^-53 |mean| per deviation, i.e. up to
+    // ~4 * 2^-53 |mean| sum(w |dev|) <= 4 * 2^-53 |mean| sqrt(sw * trace) in the scatter.  With the sums taken about the
+    // camera's origin, returns 75 m away that are collinear to 0.3 mm (three returns of one azimuth) carried 7e-14 of the
+    // trace, not 1e-14 (profiles/tools/random_sweep.py, seeds 112686 and 110803 on the lane-per-feature route: 1.1e-4 m
+    // and 3.5e-5 m with estimates of 1.5e-5 and 8e-6; LAB.md 6.24).  The sums are therefore taken about the list's first
+    // point (road_after_scan) - |mean| is then the set's own extent, cdev - and twice that bound enters the estimate
+    // (sw = sum of the weights); it matters where the origin is not an inlier (the general loop, a far object first).
+    const double errc = fmax(MLD_ROAD_ERR_C, 8.8817841970012523e-16 * cdev * sqrt(sw / (r[3] + r[6] + r[8])));
     // (est = 0 only for a clean estimate; a vanishing or NaN denominator gives +inf / NaN, which fails every test below)
-    const double est = fabs(raw) * MLD_ROAD_ERR_C / den;
+    const double est = fabs(raw) * errc / den;
     int type = MLD_SuccessRoad;
     const int th = apply_thresholds(c, r[9], r[10], depth);
     if (th) type = th;
@@ -1933,6 +1942,9 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s
     // reciprocal estimates + Newton steps (road tolerance)
     double sw = 0, mx = 0, my = 0, mz = 0;
     double q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0;
+    // origin of the sums: the first point of the list (for neighbouring returns the differences are exact, and the running
+    // mean - whose rounding the scatter inherits - is then as small as the set is wide, not as far as it is away)
+    V3 org = {0.0, 0.0, 0.0};
     const auto* pl = GPTR(double, s.plane);
     const V3 pn = {pl[0], pl[1], pl[2]};
     const double prior_off = pl[3];
@@ -1953,11 +1965,12 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s
             const double w = fast_rcp(fabs(vdot(pn, p) + prior_off));
             const double swn = sw + w;
             const double r = w * fast_rcp(swn);
-            const double dx = p.x - mx, dy = p.y - my, dz = p.z - mz;
+            const double sx = p.x - org.x, sy = p.y - org.y, sz = p.z - org.z;
+            const double dx = sx - mx, dy = sy - my, dz = sz - mz;
             mx = fma(dx, r, mx);
             my = fma(dy, r, my);
             mz = fma(dz, r, mz);
-            const double ex = p.x - mx, ey = p.y - my, ez = p.z - mz;
+            const double ex = sx - mx, ey = sy - my, ez = sz - mz;
             const double wdx = w * dx, wdy = w * dy, wdz = w * dz;
             q0 = fma(wdx, ex, q0);
             q1 = fma(wdx, ey, q1);
@@ -2001,6 +2014,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s
             RawP rp[RB];
 #pragma unroll
             for (int q = 0; q < RB; q++) rp[q] = load_raw(s, LST_ID(e0 + q, ni));
+            if (e0 == 0 && roadMode == 0) org = raw_point(c, rp[0]);  // (wave-uniform branch; a lane without inliers adds nothing)
 #pragma unroll
             for (int q = 0; q < RB; q++)
                 if (e0 + q < ni) add_inlier(raw_point(c, rp[q]));
@@ -2017,6 +2031,7 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s
             rp[q] = load_raw(s, ids[q]);
             mw[q] = GPTR(uint32_t, s.g.inlier_mask)[ids[q] >> 5];
         }
+        if (e0 == 0 && roadMode == 0) org = raw_point(c, rp[0]);  // (the window's first return: near the inliers or not, see finish_road_fast)
 #pragma unroll
         for (int q = 0; q < RB; q++) {
           if (e0 + q < n2) {
@@ -2053,9 +2068,10 @@ __device__ __forceinline__ void road_after_scan(const Calib& c, const SlotRef& s
     rr[10] = zmx;
     if (roadMode == 0) {
         // weighted centre (PlaneEstimationMEstimator.cpp:31-37) and scatter about it (:39-46)
-        rr[0] = mx; rr[1] = my; rr[2] = mz;
+        rr[0] = org.x + mx; rr[1] = org.y + my; rr[2] = org.z + mz;
         rr[3] = q0; rr[4] = q1; rr[5] = q2; rr[6] = q3; rr[7] = q4; rr[8] = q5;
-        if (cand && !finish_road_fast(c, myu, myv, rr, mytype, mydepth)) overflow = true;  // (redone by the wave kernel)
+        const double cdev = fmax(fabs(mx), fmax(fabs(my), fabs(mz)));
+        if (cand && !finish_road_fast(c, myu, myv, rr, sw, cdev, mytype, mydepth)) overflow = true;  // (redone by the wave kernel)
         ST_USE_F64(mydepth);
         ST_MARK(14);
     } else {
