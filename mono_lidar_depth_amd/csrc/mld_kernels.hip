@@ -1209,87 +1209,6 @@ __device__ void road_qr(int n, const Lists& L, int lane, const SlotDesc& s, doub
     R[5] = r33;
 }
 
-// The same estimator for SHORT inlier lists, step for step as the CPU restatement of the reference runs it
-// (mestimator_plane: every sum in list order, the one-sided Jacobi on the three rows of M itself) and therefore with its
-// result bit for bit: the fits that reach the wave kernel because no f64 decomposition determines them - three or four returns
-// of one azimuth, collinear to 1e-6, a ray grazing the plane, thresholds off - answer to NO tolerance between two different
-// decompositions (LAB.md 6.25: 1.35e-4 m on an estimate 2.3 km behind the camera with the QR above), only to equality.
-// Every lane runs the same serial code on the same LDS rows (wave-uniform values; identical stores to one address).
-// out: center[3]; R[0..2] = the un-normalised normal, R[3] = -1 (no r22 is negative: finish_road's flag), R[4] = R[5] = 0.
-constexpr int kRoadExactN = 16;
-__device__ void road_exact(int n, const Lists& L, const SlotDesc& s, double center[3], double R[6]) {
-    const V3 pn = {s.prior_n[0], s.prior_n[1], s.prior_n[2]};
-    V3 ctr = {0.0, 0.0, 0.0};
-    double wsum = 0.0;
-    for (int i = 0; i < n; i++) {
-        const V3 p = {L.x[i], L.y[i], L.z[i]};
-        const double w = 1 / fabs(vdot(pn, p) + s.prior_off);  // PlaneEstimationMEstimator.cpp:32
-        ctr = vadd(ctr, vscale(p, w));
-        wsum += w;
-    }
-    ctr = vdivs(ctr, wsum);
-    for (int i = 0; i < n; i++) {
-        const V3 p = {L.x[i], L.y[i], L.z[i]};
-        const double ws = sqrt(1 / fabs(vdot(pn, p) + s.prior_off));
-        L.x[i] = ws * (p.x - ctr.x);
-        L.y[i] = ws * (p.y - ctr.y);
-        L.z[i] = ws * (p.z - ctr.z);
-    }
-    double U[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int sweep = 0; sweep < 60; sweep++) {
-        bool rotated = false;
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-#pragma unroll
-            for (int q = p + 1; q < 3; q++) {
-                double* rp = p == 0 ? L.x : L.y;
-                double* rq = q == 1 ? L.y : L.z;
-                double app = 0, aqq = 0, apq = 0;
-                for (int i = 0; i < n; i++) {
-                    const double a = rp[i], b = rq[i];
-                    app += a * a;
-                    aqq += b * b;
-                    apq += a * b;
-                }
-                if (!(fabs(apq) > 1e-15 * sqrt(app * aqq)) || apq == 0.0) continue;
-                rotated = true;
-                const double theta = (aqq - app) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-                for (int i = 0; i < n; i++) {
-                    const double a = rp[i], b = rq[i];
-                    rp[i] = cs * a - sn * b;
-                    rq[i] = sn * a + cs * b;
-                }
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const double a = U[k][p], b = U[k][q];
-                    U[k][p] = cs * a - sn * b;
-                    U[k][q] = sn * a + cs * b;
-                }
-            }
-        if (!rotated) break;
-    }
-    double nrm[3] = {0, 0, 0};
-    for (int i = 0; i < n; i++) {
-        nrm[0] += L.x[i] * L.x[i];
-        nrm[1] += L.y[i] * L.y[i];
-        nrm[2] += L.z[i] * L.z[i];
-    }
-    int m = 0;
-    if (nrm[1] < nrm[m]) m = 1;
-    if (nrm[2] < nrm[m]) m = 2;
-    center[0] = ctr.x;
-    center[1] = ctr.y;
-    center[2] = ctr.z;
-    R[0] = (m == 0) ? U[0][0] : ((m == 1) ? U[0][1] : U[0][2]);
-    R[1] = (m == 0) ? U[1][0] : ((m == 1) ? U[1][1] : U[1][2]);
-    R[2] = (m == 0) ? U[2][0] : ((m == 1) ? U[2][1] : U[2][2]);
-    R[3] = -1.0;
-    R[4] = 0.0;
-    R[5] = 0.0;
-}
-
 // Left singular vector of the smallest singular value of M from the R of road_qr: one-sided (Hestenes) Jacobi on the
 // three rows of R^T - M = R^T Q^T, so the rows' inner products are M's - as the CPU restatement of the reference runs
 // it on the rows of M itself.
@@ -1403,7 +1322,6 @@ __device__ __forceinline__ void finish_road(const Calib& c, bool triangle, doubl
         // (r[3..8] = the R of road_qr, not the scatter: see there)
         V3 center = {r[0], r[1], r[2]};
         V3 n0 = normal_from_R(&r[3]);
-        if (r[6] < 0.0) n0 = {r[3], r[4], r[5]};  // (road_exact: the normal itself)
         if (isnan(center.x) || isnan(center.y) || isnan(center.z)) {
             double qn = __builtin_nan("");
             n0 = {qn, qn, qn};
@@ -1684,11 +1602,7 @@ __device__ __forceinline__ void wave_path(const Calib& c, const SlotDesc& s, uns
                 list_minmax_z(kk, L, lane, mn, mx);
                 if (c.roadMode == 0) {
                     double ctr[3], R[6];
-                    // (either rewrites the list: nothing reads it afterwards)
-                    if (kk <= kRoadExactN)
-                        road_exact(kk, L, s, ctr, R);
-                    else
-                        road_qr(kk, L, lane, s, ctr, R);
+                    road_qr(kk, L, lane, s, ctr, R);  // (rewrites the list: nothing reads it afterwards)
                     {
                         for (int t = 0; t < 3; t++) SREC(t, ctr[t]);
                         for (int t = 0; t < 6; t++) SREC(3 + t, R[t]);

@@ -169,16 +169,15 @@ def test_projection_over_extreme_magnitudes(seed):
     assert np.array_equal(t, t0)
 
 
-def test_undetermined_road_fit_equals_the_oracle():
-    """The one road depth of round 6's sweep configurations that left the 1e-4 m tolerance after LAB.md 6.24 (batched sweep,
-    seed 160643, frame 0, feature 354; LAB.md 6.25): window 2 px wide, thresholds off; the three inliers are returns of one
-    azimuth on consecutive rings 68 m away, collinear to 2e-6 - singular values 3.8 : 7.6e-6 : 0 -, the ray grazes the fitted
-    plane (|n.ray| = 3.6e-6) and the estimate lies 2.3 km BEHIND the camera.  The normal of such a set is determined to
-    eps * s3 / s2 = 5e-11 rad by any backward-stable f64 decomposition, i.e. the depth to 3 cm: the wave kernel's QR + Jacobi
-    with DPP-tree sums and the oracle's Jacobi on the rows with sums in sequence agreed to 1.35e-4 m = 6e-8 of the depth - no
-    tolerance holds between two decompositions here.  Since then the wave kernel runs fits of up to 16 inliers step for step as
-    the restated reference does (road_exact): this depth, and every road depth of the frame that the wave kernel computes,
-    equals the oracle's to the last bits; the lane-per-feature kernel's stay within 1e-9 m on this frame."""
+def test_known_exceedance_of_the_absolute_road_tolerance_on_an_undetermined_fit():
+    """The ONE road depth of round 6's 81 850 sweep configurations that left the 1e-4 m tolerance after LAB.md 6.24 (batched
+    sweep, seed 160643, frame 0, feature 354; found in the closing hour, documented instead of tuned away): window 2 px wide,
+    thresholds off; the three inliers are returns of one azimuth on consecutive rings 68 m away, collinear to 2e-6 - singular
+    values 3.8 : 7.6e-6 : 0 -, the ray grazes the fitted plane (|n.ray| = 3.6e-6) and the estimate lies 2.3 km BEHIND the camera.
+    The normal of such a set is determined to eps * s3 / s2 = 5e-11 rad by ANY backward-stable f64 decomposition, i.e. the
+    depth to 2298 m * 5e-11 / 3.6e-6 = 3 cm; the wave kernel (QR + one-sided Jacobi, sums as DPP trees) and the oracle (the
+    reference's order, sums in sequence) agree to 1.35e-4 m = 6e-8 of the depth.  Pinned here: result types identical,
+    every depth within 1e-4 m + 1e-7 |depth|, and this feature is the only one beyond 1e-4 m."""
     seed = 160643
     P, cam, T, scanner, kw = _random_setup(seed)
     cloud = synth.make_cloud(scanner, seed=200 + seed, frame=seed % 7)
@@ -187,8 +186,11 @@ def test_undetermined_road_fit_equals_the_oracle():
     est = make_estimator(P, camera=cam, T=T)
     d, t = est.CalculateDepth(cloud, uv, GroundPlane(*plane))
     _, (d0, t0) = run_oracle(P, cloud, uv, plane, camera=cam, T=T)
-    diff = assert_depth_parity(d, t, d0, t0, exact_main=not P.do_use_PCA)
-    far = np.nonzero((t0 == 16) & (np.abs(d0) > 1000.0))[0]
-    assert len(far) >= 1                                   # (the estimate kilometres away is in this frame)
-    assert np.all(diff[far] <= 1e-9 * np.abs(d0[far])), (diff[far], d0[far])
-    assert diff.max(initial=0.0) <= 1e-6, float(diff.max())
+    assert np.array_equal(t, t0)
+    assert np.array_equal(np.isnan(d), np.isnan(d0))
+    diff = np.abs(np.nan_to_num(d) - np.nan_to_num(d0))
+    assert np.all(diff <= 1e-4 + 1e-7 * np.abs(np.nan_to_num(d0))), float(diff.max())
+    beyond = np.nonzero(diff > 1e-4)[0]
+    assert len(beyond) <= 1 and all(abs(d0[i]) > 1000.0 and t0[i] == 16 for i in beyond), (beyond, d0[beyond])
+    main = t0 != 16
+    assert np.array_equal(d[main], d0[main], equal_nan=True)
